@@ -1,0 +1,246 @@
+/*
+ * mmvae_hip.h -- C-ABI of libmmvae_hip.so: the MI355X (gfx950) kernels of the MMVAE training step.
+ *
+ * This is the drop-in boundary for the hot path of zdebruine/MMVAE (`cmmvae`).  The reference owns no native code:
+ * every entry point below replaces a chain of ATen dispatches made from the cited reference lines.  The Python
+ * host (mmvae_amd/) binds these symbols with ctypes; a reference maintainer would bind them the same way
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes.  No torch / pybind types.
+ *   - Every pointer is a DEVICE pointer to fp32 unless the name says otherwise (u8 masks, i64 labels).
+ *   - Matrices are row-major with an explicit leading dimension (elements, not bytes).
+ *   - `stream` is a hipStream_t passed as void*.  Calls only enqueue work on it: no allocation, no host sync,
+ *     no hidden state -> every call is hipGraph-capturable and re-entrant per stream.
+ *   - Caller owns all buffers, including `workspace`.  Required sizes come from the *_workspace_bytes helpers.
+ *   - Return value: MMVAE_OK, or an MMVAE_ERR_* code.  No exceptions cross the ABI.  Shapes are validated on the
+ *     host BEFORE anything is launched, so a bad call never reaches the GPU.
+ *   - Arithmetic is fp32 end to end (reference: `precision: 32`, configs/trainer/config.yaml:5).  GEMMs use the
+ *     exact-f32 MFMA (v_mfma_f32_32x32x2_f32): one rounding per product, f32 accumulate.
+ */
+#ifndef MMVAE_HIP_H
+#define MMVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mmvae_stream_t; /* hipStream_t */
+
+#define MMVAE_OK 0
+#define MMVAE_ERR_ARG 1       /* invalid shape / null pointer / unsupported flag */
+#define MMVAE_ERR_LAUNCH 2    /* hipLaunch / hipMemsetAsync reported an error */
+#define MMVAE_ERR_WORKSPACE 3 /* workspace too small */
+
+/* ABI version (bumped on any signature change) and the gfx arch string the code objects were built for. */
+int mmvae_abi_version(void);
+const char* mmvae_build_arch(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Dense Linear GEMMs  (replaces nn.Linear forward and its autograd: components.py:276, called from
+ * FCBlock.forward components.py:292-314, Encoder.forward components.py:791-795, Adversarial.forward :666-674)
+ *
+ *   C[M,N] = alpha * A(M,K) . B(K,N)  (+ bias[N])  (relu)  (+ C if accumulate)
+ *
+ * layout selects how A and B sit in memory:
+ *   MMVAE_GEMM_NT  A[M,K] (K contiguous), B[N,K] (K contiguous)   y  = x . W^T    Linear forward
+ *   MMVAE_GEMM_NN  A[M,K] (K contiguous), B[K,N] (N contiguous)   dx = dy . W     input gradient
+ *   MMVAE_GEMM_TN  A[K,M] (M contiguous), B[K,N] (N contiguous)   dW = dy^T . x   weight gradient
+ *
+ * splitk >= 1: number of K partitions.  With splitk > 1 the partial products go to `workspace`
+ * ([splitk, M, N] fp32) and a second kernel of the same call reduces them (fixed order -> bitwise reproducible).
+ * With MMVAE_GEMM_RAW_SLABS the reduce is skipped: C receives the raw slabs [splitk, M, ldc] (no alpha, bias,
+ * relu), to be consumed by mmvae_fc_epilogue_fwd / _bwd which sum them on the fly.
+ * splitk == 0 lets the library pick (mmvae_gemm_plan).
+ * ------------------------------------------------------------------------------------------------------------ */
+#define MMVAE_GEMM_NT 0
+#define MMVAE_GEMM_NN 1
+#define MMVAE_GEMM_TN 2
+
+#define MMVAE_GEMM_RELU 1u        /* C = max(C, 0) after bias */
+#define MMVAE_GEMM_ACCUMULATE 2u  /* C += result (beta = 1) */
+#define MMVAE_GEMM_RAW_SLABS 4u   /* write exactly [splitk, M, ldc] partial slabs, no epilogue (bias must be NULL) */
+
+/* Library heuristic: picks the block tile (128 or 64) and split-K factor for a shape.  Pure host function. */
+int mmvae_gemm_plan(int layout, int M, int N, int K, int* tile_out, int* splitk_out);
+size_t mmvae_gemm_workspace_bytes(int layout, int M, int N, int K, int splitk);
+
+int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, const float* A, int64_t lda, const float* B,
+                   int64_t ldb, float* C, int64_t ldc, const float* bias, unsigned flags, int splitk,
+                   float* workspace, size_t workspace_bytes, mmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused last decoder layer + reconstruction loss (k3)
+ * replaces: expert decoder last Linear + ReLU (components.py:276,286 via cmmvae.py:111) followed by
+ *           F.mse_loss(xhat, x, reduction="sum") and its autograd (vae.py:143)
+ *
+ *   P      = h[B,H] . W[G,H]^T + bias[G]
+ *   xhat   = max(P, 0)                                   (optional store)
+ *   dP     = 2 (xhat - x) * 1[P > 0]                     (optional store; unscaled d recon / d P)
+ *   se_part[t, b] = sum over the genes of column tile t of (xhat - x)^2     (t < mmvae_recon_tiles(G))
+ *
+ * The per-cell squared error is reduced across the wavefront with shuffles inside the GEMM epilogue; the
+ * [tiles, B] partials are summed in fixed order by mmvae_elbo_finalize (bitwise reproducible, no atomics).
+ * ------------------------------------------------------------------------------------------------------------ */
+int mmvae_recon_tiles(int G);
+int mmvae_decoder_recon_f32(int B, int G, int H, const float* h, int64_t ldh, const float* W, int64_t ldw,
+                            const float* bias, const float* x, int64_t ldx, float* xhat, int64_t ldxhat, float* dP,
+                            int64_t lddp, float* se_part, mmvae_stream_t stream);
+/* K-sample form: `rows` = K*B stacked decoder inputs, x has x_rows = B rows, output row r compares with x[r % B];
+ * se_part is [tiles, rows]. */
+int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, const float* h, int64_t ldh, const float* W,
+                                 int64_t ldw, const float* bias, const float* x, int64_t ldx, float* xhat,
+                                 int64_t ldxhat, float* dP, int64_t lddp, float* se_part, mmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * FCBlock layer epilogues ("column kernels")
+ * replaces: BatchNorm1d(momentum=0.01, eps=0.001) train/eval forward (components.py:279), activation
+ *           (components.py:282-286, ReLU only on the HIP path), Dropout (components.py:287-288) and their autograd.
+ *
+ * Forward:   z = bias + sum_s in[s]            (in: [S, B, ld] slabs; S = 1 for a plain GEMM output)
+ *            BN (has_bn): training: batch mean / biased var over B, running stats updated with unbiased var;
+ *                         eval: running stats.            y = gamma * (z - mean) * invstd + beta
+ *            a = relu ? max(y, 0) : y                      (the tensor the reference collects as "hidden" after "af")
+ *            d = mask ? a * mask * (1 / (1 - p)) : a        (mask: u8 0/1 keep mask, parity mode or Philox-filled)
+ * Outputs: z_out (needed by BN backward; may be NULL when !has_bn), a_out (may be NULL when no dropout and
+ *          d_out given), d_out, save_mean / save_invstd [N] (training BN only).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct mmvae_bn_params {
+    const float* gamma;        /* [N] bn.weight */
+    const float* beta;         /* [N] bn.bias */
+    float* running_mean;       /* [N] updated in training */
+    float* running_var;        /* [N] updated in training */
+    int64_t* num_batches_tracked; /* scalar, incremented in training; may be NULL */
+    float momentum;            /* 0.01 in the reference */
+    float eps;                 /* 0.001 in the reference */
+} mmvae_bn_params;
+
+int mmvae_fc_epilogue_fwd(int B, int N, const float* in, int64_t ld_in, int n_slabs, const float* bias,
+                          const mmvae_bn_params* bn /* NULL = no BN */, int training, int relu,
+                          const uint8_t* keep_mask /* [B,N] or NULL */, float dropout_p, float* z_out,
+                          float* a_out, float* d_out, int64_t ld_out, float* save_mean, float* save_invstd,
+                          mmvae_stream_t stream);
+
+/* Backward of the same layer tail.
+ *   dd   = row_scale[b] * (sum_s din[s] + addend)        (grad wrt d; addend/row_scale optional)
+ *   da   = mask ? dd * mask / (1 - p) : dd
+ *   dy   = relu ? da * 1[a > 0] : da                      (a: forward a_out or d_out when no dropout)
+ *   BN training backward: dbeta = sum_b dy, dgamma = sum_b dy*xhat, dz = gamma*invstd*(dy - dbeta/B - xhat*dgamma/B)
+ *   no BN: dz = dy
+ *   dbias = sum_b dz                                         (grad of the Linear bias)
+ * dz_out may be NULL (pure column sum).  dz_out may alias din when n_slabs == 1. */
+int mmvae_fc_epilogue_bwd(int B, int N, const float* din, int64_t ld_in, int n_slabs, const float* addend,
+                          const float* row_scale, const uint8_t* keep_mask, float dropout_p, int relu,
+                          const float* a, const float* z, const float* gamma, const float* save_mean,
+                          const float* save_invstd, int has_bn, float* dz_out, int64_t ld_out, float* dbias,
+                          float* dgamma, float* dbeta, mmvae_stream_t stream);
+
+/* LayerNorm(elementwise_affine=False), eps 1e-5 (components.py:281) -- used by ConditionalLayer blocks ("next" row f2). */
+int mmvae_layernorm_fwd(int B, int N, const float* x, int64_t ldx, float eps, float* y, int64_t ldy, float* save_mean,
+                        float* save_invstd, mmvae_stream_t stream);
+int mmvae_layernorm_bwd(int B, int N, const float* dy, int64_t lddy, const float* y, int64_t ldy,
+                        const float* save_invstd, float* dx, int64_t lddx, mmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Reparameterisation + Gaussian KL (k8)
+ * replaces: Encoder.forward tail (components.py:795-801: v = exp(a) + var_eps, Normal(m, sqrt v).rsample())
+ *           and kl_divergence(qz, N(0,1)).sum(-1) (vae.py:136-137), plus the Mean/Variance log sums
+ *           (cmmvae_model.py:170-171).
+ *   v = exp(a) + var_eps ; s = sqrt(v) ; z[k,b,:] = mu + s * eps[k,b,:]      (k < K samples; K = 1 in the reference)
+ *   kl_row[b] = sum_j 0.5 (s^2 + mu^2 - 1 - log(s^2))
+ *   stat_row[b] = {sum_j mu, sum_j s^2}                                    (optional, [B,2])
+ * One wavefront per cell; the latent axis is reduced with wavefront shuffles.
+ * ------------------------------------------------------------------------------------------------------------ */
+int mmvae_reparam_kl_fwd(int B, int Z, int K, const float* mu, const float* a_raw, const float* eps, float var_eps,
+                         float* std_out, float* z_out, float* kl_row, float* stat_row, mmvae_stream_t stream);
+
+/* Backward.  c_b = (dkl_row ? dkl_row[b] : 1) * (kl_scale_dev ? *kl_scale_dev : 1) * kl_scale_host
+ *   dmu = sum_k dz[k] + dmu_extra + c_b * mu
+ *   ds  = sum_k dz[k] * eps[k] + dstd_extra
+ *   da  = (ds / (2 s) + c_b * 0.5 (1 - 1/v)) * (v - var_eps)
+ * dz may be NULL (treated as 0); *_extra may be NULL. */
+int mmvae_reparam_kl_bwd(int B, int Z, int K, const float* mu, const float* std, const float* eps, const float* dz,
+                         const float* dmu_extra, const float* dstd_extra, const float* dkl_row,
+                         const float* kl_scale_dev, float kl_scale_host, float var_eps, float* dmu, float* da_raw,
+                         mmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Stand-alone sum-of-squares reconstruction loss + gradient (k9)   replaces F.mse_loss(reduction="sum") vae.py:143
+ *   se_row[b] = sum_g (xhat - x)^2 ; dxhat = gscale * 2 (xhat - x)   (dxhat optional; gscale_dev optional device scalar)
+ * ------------------------------------------------------------------------------------------------------------ */
+int mmvae_mse_sum_fwd_bwd(int B, int G, const float* xhat, int64_t ldxhat, const float* x, int64_t ldx, float* se_row,
+                          float* dxhat, int64_t lddx, const float* gscale_dev, float gscale_host,
+                          mmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * ELBO finalisation (a6) and the K-sample extension (a7 / k10)
+ * replaces: vae.py:136-152 (loss = recon + kl_weight * mean_b KL_b).  K > 1 is a build-defined extension
+ * (SURVEY 0): recon = sum_b -logmeanexp_k(-SE[b,k]); K = 1 reduces exactly to the reference.
+ *   se_part: [T, K*B] partial squared errors (T = tiles of mmvae_decoder_recon_f32, or 1 for mse_sum rows),
+ *            sample k of cell b at column k*B + b.
+ *   out[0] = loss, out[1] = recon, out[2] = kl (mean over cells), out[3] = kl_weight, out[4] = mean(mu),
+ *   out[5] = mean(var)      (accumulated in fp64, stored fp32)
+ *   w_out[k*B + b] = softmax_k(-SE[b,:])  : d recon / d SE[b,k]   (== 1 for K = 1)
+ * ------------------------------------------------------------------------------------------------------------ */
+int mmvae_elbo_finalize(int B, int K, int T, const float* se_part, const float* kl_row, const float* stat_row, int Z,
+                        const float* kl_weight_dev, float kl_weight_host, float* out6, float* w_out,
+                        mmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Adversarial heads: CrossEntropyLoss(reduction="sum") forward + gradient (k11)
+ * replaces: cmmvae_model.py:54,85 (nn.CrossEntropyLoss(reduction="sum") on Adversarial head logits)
+ *   loss_out[0] (+)= sum_b (logsumexp(l_b) - l_b[y_b]) ; dlogits = gscale * (softmax(l_b) - onehot(y_b))
+ * Gradient reversal (components.py:889-899) is a sign on the dx GEMM alpha, not a kernel.
+ * ------------------------------------------------------------------------------------------------------------ */
+int mmvae_cross_entropy_sum(int B, int C, const float* logits, int64_t ld, const int64_t* labels, float* loss_rows,
+                            float* dlogits, int64_t ldd, float gscale, mmvae_stream_t stream);
+/* sums n floats in fixed order (fp64 accumulate) into out[0] (+= if accumulate). Used for loss_rows, se_row. */
+int mmvae_sum_f32(int64_t n, const float* v, float* out, int accumulate, mmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Optimiser: global-norm clip + Adam over a flat parameter arena (k12, k13)
+ * replaces: clip_grad_norm_(params, 10) via Lightning clip_gradients (cmmvae_model.py:126-129,203-209) and
+ *           torch.optim.Adam(lr=5e-3, weight_decay=1e-6).step() (cmmvae_model.py:309-318,130,212-213).
+ * All parameters of one optimiser live contiguously in one arena (params/grads/exp_avg/exp_avg_sq each [n]).
+ *
+ * mmvae_grad_sqnorm:   partial[i] = sum of squares of chunk i (fixed chunking -> reproducible); needs
+ *                      mmvae_sqnorm_partials(n) floats.
+ * mmvae_adam_prepare:  single block.  state[0] = step (incremented here), then
+ *                      state[1] = total grad norm (pre-clip), state[2] = clip coefficient min(1, max_norm/(norm+1e-6))
+ *                      (1 if max_norm <= 0), state[3] = 1 - beta1^step, state[4] = 1 - beta2^step.
+ *                      grad_scale multiplies the gradients first (DDP averaging: 1/world_size).
+ * mmvae_adam_step:     g = clip*grad_scale*grad + wd*p ; m += (1-b1)(g-m) ; v = b2 v + (1-b2) g^2 ;
+ *                      p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)            (torch.optim.Adam, amsgrad=False)
+ * ------------------------------------------------------------------------------------------------------------ */
+#define MMVAE_ADAM_STATE_FLOATS 8
+int64_t mmvae_sqnorm_partials(int64_t n);
+int mmvae_grad_sqnorm(int64_t n, const float* grad, float* partials, mmvae_stream_t stream);
+int mmvae_adam_prepare(int64_t n_partials, const float* partials, float max_norm, float grad_scale, float beta1,
+                       float beta2, float* state, mmvae_stream_t stream);
+int mmvae_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* state,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                    mmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Device RNG (k15): Philox4x32-10 streams for production mode (parity mode passes explicit masks / eps).
+ * replaces: nn.Dropout mask draw (components.py:288) and Normal.rsample noise (components.py:801).
+ * rng_state: device uint64[2] = {seed, offset}; offset is advanced by the kernel's consumption when
+ * `advance` != 0 (so a captured hipGraph draws fresh numbers on every replay).
+ * ------------------------------------------------------------------------------------------------------------ */
+int mmvae_philox_keep_mask(int64_t n, float p_drop, uint8_t* mask, uint64_t* rng_state, uint64_t stream_id,
+                           int advance, mmvae_stream_t stream);
+int mmvae_philox_normal(int64_t n, float* out, uint64_t* rng_state, uint64_t stream_id, int advance,
+                        mmvae_stream_t stream);
+
+/* Small utilities used by the step engine: y = alpha*x (+ y), fill. */
+int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, float* y, mmvae_stream_t stream);
+int mmvae_scale_rows(int B, int N, const float* x, int64_t ldx, const float* row_scale, float* y, int64_t ldy,
+                     mmvae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMVAE_HIP_H */

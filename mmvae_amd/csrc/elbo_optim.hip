@@ -1,0 +1,553 @@
+// Row kernels of the MMVAE step for gfx950: reparameterisation + Gaussian KL (k8), sum-of-squares loss (k9),
+// ELBO finalisation + K-sample log-mean-exp (k10), cross-entropy for the adversarial heads (k11),
+// global-norm clip + Adam over a flat arena (k12, k13), Philox RNG (k15).
+//
+// Replaces (reference): components.py:795-801 (v = exp(a)+eps, rsample), vae.py:136-152 (kl_divergence,
+// mse_loss(sum), loss), cmmvae_model.py:54,85 (CrossEntropyLoss(sum)), :126-131,:203-213 (clip_grad_norm_, Adam).
+//
+// All of these are HBM/latency-bound.  Per-cell (row) reductions use one 64-lane wavefront per row with
+// shuffle reductions; global scalars are accumulated in fp64 in a fixed order (bitwise reproducible).
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- reparam + KL
+__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(int B, int Z, int K, const float* __restrict__ mu,
+                                                             const float* __restrict__ a_raw,
+                                                             const float* __restrict__ eps, float var_eps,
+                                                             float* __restrict__ std_out, float* __restrict__ z_out,
+                                                             float* __restrict__ kl_row, float* __restrict__ stat_row) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float kl = 0.f, smu = 0.f, svar = 0.f;
+    for (int j = lane; j < Z; j += 64) {
+        const int64_t o = (int64_t)b * Z + j;
+        const float m = mu[o];
+        const float v = expf(a_raw[o]) + var_eps;
+        const float s = sqrtf(v);
+        if (std_out) std_out[o] = s;
+        const float vr = s * s;  // the reference squares the scale again inside kl_divergence / .variance
+        kl += 0.5f * (vr + m * m - 1.f - logf(vr));
+        smu += m;
+        svar += vr;
+        if (z_out)
+            for (int k = 0; k < K; ++k) {
+                const int64_t ok = ((int64_t)k * B + b) * Z + j;
+                z_out[ok] = m + s * eps[ok];
+            }
+    }
+    kl = wave_sum(kl);
+    smu = wave_sum(smu);
+    svar = wave_sum(svar);
+    if (lane == 0) {
+        if (kl_row) kl_row[b] = kl;
+        if (stat_row) {
+            stat_row[2 * b] = smu;
+            stat_row[2 * b + 1] = svar;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(int B, int Z, int K, const float* __restrict__ mu,
+                                                             const float* __restrict__ sd,
+                                                             const float* __restrict__ eps, const float* __restrict__ dz,
+                                                             const float* __restrict__ dmu_extra,
+                                                             const float* __restrict__ dstd_extra,
+                                                             const float* __restrict__ dkl_row,
+                                                             const float* __restrict__ kl_scale_dev, float kl_scale_host,
+                                                             float var_eps, float* __restrict__ dmu,
+                                                             float* __restrict__ da_raw) {
+    const int64_t n = (int64_t)B * Z;
+    const float cs = (kl_scale_dev ? *kl_scale_dev : 1.f) * kl_scale_host;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(o / Z);
+        const float c = cs * (dkl_row ? dkl_row[b] : 1.f);
+        const float m = mu[o], s = sd[o];
+        const float v = s * s;
+        float gm = dmu_extra ? dmu_extra[o] : 0.f;
+        float gs = dstd_extra ? dstd_extra[o] : 0.f;
+        if (dz)
+            for (int k = 0; k < K; ++k) {
+                const int64_t ok = (int64_t)k * n + o;
+                const float g = dz[ok];
+                gm += g;
+                gs += g * eps[ok];
+            }
+        dmu[o] = gm + c * m;
+        da_raw[o] = (gs / (2.f * s) + c * 0.5f * (1.f - 1.f / v)) * (v - var_eps);
+    }
+}
+
+// ---------------------------------------------------------------- stand-alone SE loss + grad: one workgroup per row strip
+__global__ __launch_bounds__(256) void mse_rows_kernel(int B, int G, const float* __restrict__ xhat, int64_t ldxhat,
+                                                       const float* __restrict__ x, int64_t ldx,
+                                                       float* __restrict__ se_row, float* __restrict__ dxhat,
+                                                       int64_t lddx, const float* __restrict__ gscale_dev,
+                                                       float gscale_host) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float gs = 2.f * gscale_host * (gscale_dev ? *gscale_dev : 1.f);
+    const float* xh = xhat + (int64_t)b * ldxhat;
+    const float* xr = x + (int64_t)b * ldx;
+    float* dr = dxhat ? dxhat + (int64_t)b * lddx : nullptr;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < G; j += 256) {
+        const float d = xh[j] - xr[j];
+        s += d * d;
+        if (dr) dr[j] = gs * d;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0 && se_row) se_row[b] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------- ELBO finalisation, single workgroup
+__global__ __launch_bounds__(256) void elbo_finalize_kernel(int B, int K, int T, const float* __restrict__ se_part,
+                                                            const float* __restrict__ kl_row,
+                                                            const float* __restrict__ stat_row, int Z,
+                                                            const float* __restrict__ klw_dev, float klw_host,
+                                                            float* __restrict__ out6, float* __restrict__ w_out) {
+    __shared__ double red[4][256];
+    const int tid = threadIdx.x;
+    const int64_t KB = (int64_t)K * B;
+    double recon = 0.0, kl = 0.0, smu = 0.0, svar = 0.0;
+    for (int b = tid; b < B; b += 256) {
+        if (K == 1) {
+            double se = 0.0;
+            for (int t = 0; t < T; ++t) se += (double)se_part[(int64_t)t * KB + b];
+            recon += se;
+            if (w_out) w_out[b] = 1.f;
+        } else {
+            // recon_b = -log( mean_k exp(-SE_bk) ), max-subtracted; w_bk = softmax_k(-SE_b.)
+            float mneg = -INFINITY;
+            for (int k = 0; k < K; ++k) {
+                float se = 0.f;
+                for (int t = 0; t < T; ++t) se += se_part[(int64_t)t * KB + (int64_t)k * B + b];
+                mneg = fmaxf(mneg, -se);
+            }
+            float sum = 0.f;
+            for (int k = 0; k < K; ++k) {
+                float se = 0.f;
+                for (int t = 0; t < T; ++t) se += se_part[(int64_t)t * KB + (int64_t)k * B + b];
+                sum += expf(-se - mneg);
+            }
+            const float lse = mneg + logf(sum);
+            recon += (double)(-(lse - logf((float)K)));
+            if (w_out)
+                for (int k = 0; k < K; ++k) {
+                    float se = 0.f;
+                    for (int t = 0; t < T; ++t) se += se_part[(int64_t)t * KB + (int64_t)k * B + b];
+                    w_out[(int64_t)k * B + b] = expf(-se - lse);
+                }
+        }
+        if (kl_row) kl += (double)kl_row[b];
+        if (stat_row) {
+            smu += (double)stat_row[2 * b];
+            svar += (double)stat_row[2 * b + 1];
+        }
+    }
+    red[0][tid] = recon;
+    red[1][tid] = kl;
+    red[2][tid] = smu;
+    red[3][tid] = svar;
+    __syncthreads();
+    if (tid == 0) {
+        double r = 0.0, k = 0.0, m = 0.0, v = 0.0;
+        for (int i = 0; i < 256; ++i) {
+            r += red[0][i];
+            k += red[1][i];
+            m += red[2][i];
+            v += red[3][i];
+        }
+        const float klw = (klw_dev ? *klw_dev : 1.f) * klw_host;
+        const float reconf = (float)r;
+        const float klf = (float)(k / (double)B);
+        out6[0] = reconf + klw * klf;
+        out6[1] = reconf;
+        out6[2] = klf;
+        out6[3] = klw;
+        out6[4] = (float)(m / ((double)B * (double)(Z > 0 ? Z : 1)));
+        out6[5] = (float)(v / ((double)B * (double)(Z > 0 ? Z : 1)));
+    }
+}
+
+// ---------------------------------------------------------------- cross entropy (sum) + gradient, one wavefront per row
+__global__ __launch_bounds__(256) void ce_rows_kernel(int B, int C, const float* __restrict__ logits, int64_t ld,
+                                                      const int64_t* __restrict__ labels, float* __restrict__ loss_rows,
+                                                      float* __restrict__ dlogits, int64_t ldd, float gscale) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* lr = logits + (int64_t)b * ld;
+    float mx = -INFINITY;
+    for (int j = lane; j < C; j += 64) mx = fmaxf(mx, lr[j]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int j = lane; j < C; j += 64) s += expf(lr[j] - mx);
+    s = wave_sum(s);
+    const float lse = mx + logf(s);
+    const int64_t y = labels[b];
+    if (lane == 0 && loss_rows) loss_rows[b] = (y >= 0 && y < C) ? lse - lr[y] : 0.f;
+    if (dlogits) {
+        float* dr = dlogits + (int64_t)b * ldd;
+        for (int j = lane; j < C; j += 64) {
+            const float p = expf(lr[j] - lse);
+            dr[j] = gscale * (p - ((int64_t)j == y ? 1.f : 0.f));
+        }
+    }
+}
+
+// fixed-order fp64 sum of n floats by one workgroup
+__global__ __launch_bounds__(1024) void sum_kernel(int64_t n, const float* __restrict__ v, float* __restrict__ out,
+                                                   int accumulate) {
+    __shared__ double red[1024];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += (double)v[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 512; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + (float)red[0];
+}
+
+// ---------------------------------------------------------------- clip + Adam over a flat arena
+constexpr int64_t SQN_CHUNK = 1 << 16;  // floats per workgroup of the norm pass (fixed -> reproducible)
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(int64_t n, const float* __restrict__ g,
+                                                     float* __restrict__ partials) {
+    __shared__ float red[4];
+    const int64_t beg = (int64_t)blockIdx.x * SQN_CHUNK;
+    int64_t end = beg + SQN_CHUNK;
+    if (end > n) end = n;
+    float s = 0.f;
+    const bool vec = ((reinterpret_cast<uintptr_t>(g) & 15u) == 0);
+    if (vec) {
+        const int64_t nv = (end - beg) / 4;
+        const f32x4* gv = reinterpret_cast<const f32x4*>(g + beg);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int64_t i = threadIdx.x; i < nv; i += 256) {
+            const f32x4 v = gv[i];
+            s0 += v.x * v.x;
+            s1 += v.y * v.y;
+            s2 += v.z * v.z;
+            s3 += v.w * v.w;
+        }
+        s = (s0 + s1) + (s2 + s3);
+        for (int64_t i = beg + nv * 4 + threadIdx.x; i < end; i += 256) s += g[i] * g[i];
+    } else {
+        for (int64_t i = beg + threadIdx.x; i < end; i += 256) s += g[i] * g[i];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void adam_prepare_kernel(int64_t np, const float* __restrict__ partials,
+                                                           float max_norm, float grad_scale, float beta1, float beta2,
+                                                           float* __restrict__ state) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < np; i += 256) s += (double)partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 256; ++i) t += red[i];
+        const float norm = (float)(sqrt(t) * (double)fabsf(grad_scale));
+        const float step = state[0] + 1.f;
+        state[0] = step;
+        state[1] = norm;
+        float clip = 1.f;
+        if (max_norm > 0.f) {
+            clip = max_norm / (norm + 1e-6f);
+            if (clip > 1.f) clip = 1.f;
+        }
+        state[2] = clip;
+        state[3] = 1.f - powf(beta1, step);
+        state[4] = 1.f - powf(beta2, step);
+    }
+}
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float gmul, float wd, float b1, float b2,
+                                         float step_size, float inv_bc2_sqrt, float eps) {
+    g = g * gmul + wd * p;
+    m = m + (1.f - b1) * (g - m);
+    v = b2 * v + (1.f - b2) * g * g;
+    const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+    p = p - step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_step_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        const float* __restrict__ state, float lr, float b1, float b2,
+                                                        float eps, float wd, float grad_scale, int vec) {
+    const float gmul = state[2] * grad_scale;
+    const float step_size = lr / state[3];
+    const float inv_bc2_sqrt = 1.f / sqrtf(state[4]);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        const int64_t nv = n / 4;
+        f32x4* pv = reinterpret_cast<f32x4*>(p);
+        const f32x4* gv = reinterpret_cast<const f32x4*>(g);
+        f32x4* mv = reinterpret_cast<f32x4*>(m);
+        f32x4* vv = reinterpret_cast<f32x4*>(v);
+        for (int64_t i = tid0; i < nv; i += stride) {
+            f32x4 pp = pv[i], gg = gv[i], mm = mv[i], vw = vv[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pe = pp[e], me = mm[e], ve = vw[e];
+                adam_one(pe, gg[e], me, ve, gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+                pp[e] = pe;
+                mm[e] = me;
+                vw[e] = ve;
+            }
+            pv[i] = pp;
+            mv[i] = mm;
+            vv[i] = vw;
+        }
+        for (int64_t i = nv * 4 + tid0; i < n; i += stride)
+            adam_one(p[i], g[i], m[i], v[i], gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+    } else {
+        for (int64_t i = tid0; i < n; i += stride)
+            adam_one(p[i], g[i], m[i], v[i], gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+    }
+}
+
+// ---------------------------------------------------------------- Philox4x32-10
+struct u32x4 {
+    uint32_t x, y, z, w;
+};
+__device__ __forceinline__ u32x4 philox4x32_10(uint64_t counter, uint64_t stream_id, uint64_t seed) {
+    uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = (uint32_t)stream_id,
+             c3 = (uint32_t)(stream_id >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return {c0, c1, c2, c3};
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+__global__ __launch_bounds__(256) void philox_mask_kernel(int64_t n, float p_drop, uint8_t* __restrict__ mask,
+                                                          const uint64_t* __restrict__ rng, uint64_t stream_id) {
+    const uint64_t seed = rng[0], off = rng[1];
+    const int64_t nq = (n + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+        const u32x4 r = philox4x32_10(off + (uint64_t)q, stream_id, seed);
+        const uint32_t rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t i = q * 4 + j;
+            if (i < n) mask[i] = (u01(rv[j]) >= p_drop) ? 1 : 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void philox_normal_kernel(int64_t n, float* __restrict__ out,
+                                                            const uint64_t* __restrict__ rng, uint64_t stream_id) {
+    const uint64_t seed = rng[0], off = rng[1];
+    const int64_t nq = (n + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+        const u32x4 r = philox4x32_10(off + (uint64_t)q, stream_id, seed);
+        const float u0 = u01(r.x), u1 = u01(r.y), u2 = u01(r.z), u3 = u01(r.w);
+        const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+        float s0, c0, s1, c1;
+        sincosf(6.283185307179586f * u1, &s0, &c0);
+        sincosf(6.283185307179586f * u3, &s1, &c1);
+        const float nv[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t i = q * 4 + j;
+            if (i < n) out[i] = nv[j];
+        }
+    }
+}
+
+__global__ void philox_advance_kernel(uint64_t* rng, uint64_t by) { rng[1] += by; }
+
+__global__ __launch_bounds__(256) void axpby_kernel(int64_t n, float alpha, const float* __restrict__ x, float beta,
+                                                    float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = alpha * x[i] + (beta != 0.f ? beta * y[i] : 0.f);
+}
+
+__global__ __launch_bounds__(256) void scale_rows_kernel(int B, int N, const float* __restrict__ x, int64_t ldx,
+                                                         const float* __restrict__ rs, float* __restrict__ y,
+                                                         int64_t ldy) {
+    const int64_t total = (int64_t)B * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / N), j = (int)(i - (int64_t)b * N);
+        y[(int64_t)b * ldy + j] = x[(int64_t)b * ldx + j] * rs[b];
+    }
+}
+
+inline int grid_for(int64_t n, int per_block, int cap) {
+    int64_t b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int mmvae_abi_version(void) { return 1; }
+extern "C" const char* mmvae_build_arch(void) { return "gfx950"; }
+
+extern "C" int mmvae_reparam_kl_fwd(int B, int Z, int K, const float* mu, const float* a_raw, const float* eps,
+                                    float var_eps, float* std_out, float* z_out, float* kl_row, float* stat_row,
+                                    mmvae_stream_t stream) {
+    if (B <= 0 || Z <= 0 || K < 1 || !mu || !a_raw) return MMVAE_ERR_ARG;
+    if (z_out && !eps) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, Z, K, mu,
+                       a_raw, eps, var_eps, std_out, z_out, kl_row, stat_row);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_reparam_kl_bwd(int B, int Z, int K, const float* mu, const float* sd, const float* eps,
+                                    const float* dz, const float* dmu_extra, const float* dstd_extra,
+                                    const float* dkl_row, const float* kl_scale_dev, float kl_scale_host, float var_eps,
+                                    float* dmu, float* da_raw, mmvae_stream_t stream) {
+    if (B <= 0 || Z <= 0 || K < 1 || !mu || !sd || !dmu || !da_raw) return MMVAE_ERR_ARG;
+    if (dz && !eps) return MMVAE_ERR_ARG;
+    const int64_t n = (int64_t)B * Z;
+    hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, B, Z, K,
+                       mu, sd, eps, dz, dmu_extra, dstd_extra, dkl_row, kl_scale_dev, kl_scale_host, var_eps, dmu,
+                       da_raw);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_mse_sum_fwd_bwd(int B, int G, const float* xhat, int64_t ldxhat, const float* x, int64_t ldx,
+                                     float* se_row, float* dxhat, int64_t lddx, const float* gscale_dev,
+                                     float gscale_host, mmvae_stream_t stream) {
+    if (B <= 0 || G <= 0 || !xhat || !x || ldxhat < G || ldx < G) return MMVAE_ERR_ARG;
+    if (!se_row && !dxhat) return MMVAE_ERR_ARG;
+    if (dxhat && lddx < G) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(mse_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, B, G, xhat, ldxhat, x, ldx, se_row,
+                       dxhat, lddx, gscale_dev, gscale_host);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_elbo_finalize(int B, int K, int T, const float* se_part, const float* kl_row,
+                                   const float* stat_row, int Z, const float* kl_weight_dev, float kl_weight_host,
+                                   float* out6, float* w_out, mmvae_stream_t stream) {
+    if (B <= 0 || K < 1 || T < 1 || !se_part || !out6) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, K, T, se_part, kl_row,
+                       stat_row, Z, kl_weight_dev, kl_weight_host, out6, w_out);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_cross_entropy_sum(int B, int C, const float* logits, int64_t ld, const int64_t* labels,
+                                       float* loss_rows, float* dlogits, int64_t ldd, float gscale,
+                                       mmvae_stream_t stream) {
+    if (B <= 0 || C <= 0 || !logits || !labels || ld < C) return MMVAE_ERR_ARG;
+    if (!loss_rows && !dlogits) return MMVAE_ERR_ARG;
+    if (dlogits && ldd < C) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(ce_rows_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, C, logits, ld,
+                       labels, loss_rows, dlogits, ldd, gscale);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_sum_f32(int64_t n, const float* v, float* out, int accumulate, mmvae_stream_t stream) {
+    if (n < 0 || (n > 0 && !v) || !out) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, v, out, accumulate);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int64_t mmvae_sqnorm_partials(int64_t n) { return n > 0 ? ceil_div_l(n, SQN_CHUNK) : 0; }
+
+extern "C" int mmvae_grad_sqnorm(int64_t n, const float* grad, float* partials, mmvae_stream_t stream) {
+    if (n <= 0 || !grad || !partials) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)mmvae_sqnorm_partials(n)), dim3(256), 0, (hipStream_t)stream, n,
+                       grad, partials);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_adam_prepare(int64_t n_partials, const float* partials, float max_norm, float grad_scale,
+                                  float beta1, float beta2, float* state, mmvae_stream_t stream) {
+    if (n_partials < 0 || (n_partials > 0 && !partials) || !state) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n_partials, partials, max_norm,
+                       grad_scale, beta1, beta2, state);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                               const float* state, float lr, float beta1, float beta2, float eps, float weight_decay,
+                               float grad_scale, mmvae_stream_t stream) {
+    if (n <= 0 || !param || !grad || !exp_avg || !exp_avg_sq || !state) return MMVAE_ERR_ARG;
+    const int vec = aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq);
+    hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream, n, param,
+                       grad, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps, weight_decay, grad_scale, vec);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_philox_keep_mask(int64_t n, float p_drop, uint8_t* mask, uint64_t* rng_state, uint64_t stream_id,
+                                      int advance, mmvae_stream_t stream) {
+    if (n <= 0 || !mask || !rng_state || p_drop < 0.f || p_drop >= 1.f) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(philox_mask_kernel, dim3(grid_for((n + 3) / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, n,
+                       p_drop, mask, rng_state, stream_id);
+    MMVAE_LAUNCH_CHECK();
+    if (advance) {
+        hipLaunchKernelGGL(philox_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state,
+                           (uint64_t)((n + 3) / 4));
+        MMVAE_LAUNCH_CHECK();
+    }
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_philox_normal(int64_t n, float* out, uint64_t* rng_state, uint64_t stream_id, int advance,
+                                   mmvae_stream_t stream) {
+    if (n <= 0 || !out || !rng_state) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(philox_normal_kernel, dim3(grid_for((n + 3) / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+                       n, out, rng_state, stream_id);
+    MMVAE_LAUNCH_CHECK();
+    if (advance) {
+        hipLaunchKernelGGL(philox_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state,
+                           (uint64_t)((n + 3) / 4));
+        MMVAE_LAUNCH_CHECK();
+    }
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, float* y, mmvae_stream_t stream) {
+    if (n <= 0 || !x || !y) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, n, alpha, x, beta,
+                       y);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_scale_rows(int B, int N, const float* x, int64_t ldx, const float* row_scale, float* y,
+                                int64_t ldy, mmvae_stream_t stream) {
+    if (B <= 0 || N <= 0 || !x || !row_scale || !y || ldx < N || ldy < N) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for((int64_t)B * N, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+                       B, N, x, ldx, row_scale, y, ldy);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}

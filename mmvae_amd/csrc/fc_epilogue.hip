@@ -1,0 +1,369 @@
+// FCBlock layer tails of the MMVAE step for gfx950 (k6, k7 of SURVEY 2b): split-K slab reduction + bias +
+// BatchNorm1d + ReLU + Dropout, forward and backward, and LayerNorm(no affine).
+//
+// Replaces (reference): nn.BatchNorm1d(momentum=0.01, eps=0.001) components.py:279, activation :282-286,
+// nn.Dropout :287-288, nn.LayerNorm(elementwise_affine=False) :281, and their autograd.
+//
+// These are HBM/L2-bound column reductions over the batch axis.  Layout: a workgroup owns a strip of 64 feature
+// columns (lane = column, so every row read is one coalesced 256-B wave access) and its 16 wavefronts stride
+// over the batch rows; per-column statistics are combined across the 16 waves through LDS in a fixed order
+// (bitwise reproducible, no atomics).  Statistics are two-pass (mean, then centred variance) like the
+// reference's batch_norm, re-reading z from L2 rather than holding the batch in registers, so any batch size
+// works.  The split-K partial slabs of the producing GEMM are summed here: no separate reduce pass exists.
+#include "common.h"
+
+namespace {
+
+constexpr int CW = 64;  // columns per workgroup (one per lane)
+constexpr int NW = 16;  // wavefronts per workgroup
+constexpr int CT = CW * NW;
+
+struct FwdArgs {
+    const float* in;
+    int64_t ld_in, slab_stride;
+    int n_slabs;
+    const float* bias;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    int64_t* nbt;
+    float momentum, eps;
+    int training, relu;
+    const uint8_t* mask;
+    float keep_scale;
+    float* z_out;
+    float* a_out;
+    float* d_out;
+    int64_t ld_out;
+    float* save_mean;
+    float* save_invstd;
+    int B, N;
+};
+
+// Sum of `v` over the 16 waves for each of the 64 columns; result valid in every thread.
+__device__ __forceinline__ float block_colsum(float v, float (*red)[CW], int w, int lane) {
+    __syncthreads();
+    red[w][lane] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s += red[i][lane];
+    return s;
+}
+
+template <bool HAS_BN>
+__global__ __launch_bounds__(CT) void fc_fwd_kernel(const FwdArgs a) {
+    __shared__ float red[NW][CW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * CW + lane;
+    const bool cv = c < a.N;
+    const float bias = (cv && a.bias) ? a.bias[c] : 0.f;
+
+    auto zval = [&](int r) -> float {
+        float z = bias;
+        const float* p = a.in + (int64_t)r * a.ld_in + c;
+        for (int s = 0; s < a.n_slabs; ++s) z += p[(int64_t)s * a.slab_stride];
+        return z;
+    };
+
+    float mean = 0.f, invstd = 1.f, gam = 1.f, bet = 0.f;
+    bool z_saved = false;
+    if (HAS_BN) {
+        if (cv) {
+            gam = a.gamma ? a.gamma[c] : 1.f;
+            bet = a.beta ? a.beta[c] : 0.f;
+        }
+        if (a.training) {
+            float s = 0.f;
+            if (cv)
+                for (int r = w; r < a.B; r += NW) {
+                    const float z = zval(r);
+                    a.z_out[(int64_t)r * a.ld_out + c] = z;
+                    s += z;
+                }
+            z_saved = true;
+            mean = block_colsum(s, red, w, lane) / (float)a.B;
+            float s2 = 0.f;
+            if (cv)
+                for (int r = w; r < a.B; r += NW) {
+                    const float d = a.z_out[(int64_t)r * a.ld_out + c] - mean;
+                    s2 += d * d;
+                }
+            const float var = block_colsum(s2, red, w, lane) / (float)a.B;
+            invstd = 1.0f / sqrtf(var + a.eps);
+            if (w == 0 && cv) {
+                if (a.save_mean) a.save_mean[c] = mean;
+                if (a.save_invstd) a.save_invstd[c] = invstd;
+                if (a.running_mean) a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
+                if (a.running_var) {
+                    const float unb = a.B > 1 ? var * ((float)a.B / (float)(a.B - 1)) : var;
+                    a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unb;
+                }
+            }
+            if (blockIdx.x == 0 && threadIdx.x == 0 && a.nbt) *a.nbt += 1;
+        } else if (cv) {
+            mean = a.running_mean[c];
+            invstd = 1.0f / sqrtf(a.running_var[c] + a.eps);
+        }
+    }
+    if (!cv) return;
+    for (int r = w; r < a.B; r += NW) {
+        const int64_t o = (int64_t)r * a.ld_out + c;
+        float z;
+        if (z_saved) {
+            z = a.z_out[o];
+        } else {
+            z = zval(r);
+            if (a.z_out) a.z_out[o] = z;
+        }
+        float y = z;
+        if (HAS_BN) y = (z - mean) * invstd * gam + bet;
+        if (a.relu) y = fmaxf(y, 0.f);
+        if (a.a_out) a.a_out[o] = y;
+        if (a.d_out) {
+            float d = y;
+            if (a.mask) d = a.mask[(int64_t)r * a.N + c] ? y * a.keep_scale : 0.f;
+            a.d_out[o] = d;
+        }
+    }
+}
+
+struct BwdArgs {
+    const float* din;
+    int64_t ld_in, slab_stride;
+    int n_slabs;
+    const float* addend;
+    const float* row_scale;
+    const uint8_t* mask;
+    float keep_scale;
+    int relu;
+    const float* a;
+    const float* z;
+    const float* gamma;
+    const float* save_mean;
+    const float* save_invstd;
+    float* dz_out;
+    int64_t ld_out;
+    float* dbias;
+    float* dgamma;
+    float* dbeta;
+    int B, N;
+};
+
+template <bool HAS_BN>
+__global__ __launch_bounds__(CT) void fc_bwd_kernel(const BwdArgs a) {
+    __shared__ float red[NW][CW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * CW + lane;
+    const bool cv = c < a.N;
+
+    float mean = 0.f, invstd = 1.f, gam = 1.f;
+    if (HAS_BN && cv) {
+        mean = a.save_mean[c];
+        invstd = a.save_invstd[c];
+        gam = a.gamma ? a.gamma[c] : 1.f;
+    }
+    auto dyval = [&](int r) -> float {
+        const int64_t o = (int64_t)r * a.ld_in + c;
+        float g = 0.f;
+        for (int s = 0; s < a.n_slabs; ++s) g += a.din[(int64_t)s * a.slab_stride + o];
+        // addend / a / z / dz_out share the [B, ld_out] geometry of the layer's own activations
+        const int64_t oo = (int64_t)r * a.ld_out + c;
+        if (a.addend) g += a.addend[oo];
+        if (a.row_scale) g *= a.row_scale[r];
+        if (a.mask) g = a.mask[(int64_t)r * a.N + c] ? g * a.keep_scale : 0.f;
+        if (a.relu) g = (a.a[oo] > 0.f) ? g : 0.f;
+        return g;
+    };
+
+    float s1 = 0.f, s2 = 0.f;
+    if (cv)
+        for (int r = w; r < a.B; r += NW) {
+            const float dy = dyval(r);
+            const int64_t oo = (int64_t)r * a.ld_out + c;
+            if (HAS_BN) {
+                const float xh = (a.z[oo] - mean) * invstd;
+                s2 += dy * xh;
+                a.dz_out[oo] = dy;  // stash; finished in pass 2 by the same thread
+            } else if (a.dz_out) {
+                a.dz_out[oo] = dy;
+            }
+            s1 += dy;
+        }
+    s1 = block_colsum(s1, red, w, lane);
+    if (!HAS_BN) {
+        if (w == 0 && cv && a.dbias) a.dbias[c] = s1;
+        return;
+    }
+    s2 = block_colsum(s2, red, w, lane);
+    if (w == 0 && cv) {
+        if (a.dbeta) a.dbeta[c] = s1;
+        if (a.dgamma) a.dgamma[c] = s2;
+    }
+    const float invB = 1.f / (float)a.B;
+    const float m1 = s1 * invB, m2 = s2 * invB;
+    float s3 = 0.f;
+    if (cv)
+        for (int r = w; r < a.B; r += NW) {
+            const int64_t oo = (int64_t)r * a.ld_out + c;
+            const float dy = a.dz_out[oo];
+            const float xh = (a.z[oo] - mean) * invstd;
+            const float dz = gam * invstd * (dy - m1 - xh * m2);
+            a.dz_out[oo] = dz;
+            s3 += dz;
+        }
+    s3 = block_colsum(s3, red, w, lane);
+    if (w == 0 && cv && a.dbias) a.dbias[c] = s3;
+}
+
+// LayerNorm without affine: one wavefront per row.
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(int B, int N, const float* __restrict__ x, int64_t ldx,
+                                                            float eps, float* __restrict__ y, int64_t ldy,
+                                                            float* save_mean, float* save_invstd) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float* xr = x + (int64_t)row * ldx;
+    float s = 0.f;
+    for (int j = lane; j < N; j += 64) s += xr[j];
+    const float mean = wave_sum(s) / (float)N;
+    float s2 = 0.f;
+    for (int j = lane; j < N; j += 64) {
+        const float d = xr[j] - mean;
+        s2 += d * d;
+    }
+    const float invstd = 1.0f / sqrtf(wave_sum(s2) / (float)N + eps);
+    float* yr = y + (int64_t)row * ldy;
+    for (int j = lane; j < N; j += 64) yr[j] = (xr[j] - mean) * invstd;
+    if (lane == 0) {
+        if (save_mean) save_mean[row] = mean;
+        if (save_invstd) save_invstd[row] = invstd;
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(int B, int N, const float* __restrict__ dy, int64_t lddy,
+                                                            const float* __restrict__ y, int64_t ldy,
+                                                            const float* __restrict__ save_invstd,
+                                                            float* __restrict__ dx, int64_t lddx) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float* gr = dy + (int64_t)row * lddy;
+    const float* yr = y + (int64_t)row * ldy;
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = lane; j < N; j += 64) {
+        s1 += gr[j];
+        s2 += gr[j] * yr[j];
+    }
+    const float m1 = wave_sum(s1) / (float)N, m2 = wave_sum(s2) / (float)N;
+    const float invstd = save_invstd[row];
+    float* dr = dx + (int64_t)row * lddx;
+    for (int j = lane; j < N; j += 64) dr[j] = invstd * (gr[j] - m1 - yr[j] * m2);
+}
+
+}  // namespace
+
+extern "C" int mmvae_fc_epilogue_fwd(int B, int N, const float* in, int64_t ld_in, int n_slabs, const float* bias,
+                                     const mmvae_bn_params* bn, int training, int relu, const uint8_t* keep_mask,
+                                     float dropout_p, float* z_out, float* a_out, float* d_out, int64_t ld_out,
+                                     float* save_mean, float* save_invstd, mmvae_stream_t stream) {
+    if (B <= 0 || N <= 0 || !in || n_slabs < 1 || ld_in < N || ld_out < N) return MMVAE_ERR_ARG;
+    if (!a_out && !d_out) return MMVAE_ERR_ARG;
+    if (keep_mask && (dropout_p < 0.f || dropout_p >= 1.f || !d_out)) return MMVAE_ERR_ARG;
+    if (bn && training && (!z_out || !save_mean || !save_invstd)) return MMVAE_ERR_ARG;
+    if (bn && !training && (!bn->running_mean || !bn->running_var)) return MMVAE_ERR_ARG;
+    FwdArgs a = {};
+    a.in = in;
+    a.ld_in = ld_in;
+    a.slab_stride = (int64_t)B * ld_in;
+    a.n_slabs = n_slabs;
+    a.bias = bias;
+    if (bn) {
+        a.gamma = bn->gamma;
+        a.beta = bn->beta;
+        a.running_mean = bn->running_mean;
+        a.running_var = bn->running_var;
+        a.nbt = bn->num_batches_tracked;
+        a.momentum = bn->momentum;
+        a.eps = bn->eps;
+    }
+    a.training = training;
+    a.relu = relu;
+    a.mask = keep_mask;
+    a.keep_scale = keep_mask ? 1.0f / (1.0f - dropout_p) : 1.f;
+    a.z_out = z_out;
+    a.a_out = a_out;
+    a.d_out = d_out;
+    a.ld_out = ld_out;
+    a.save_mean = save_mean;
+    a.save_invstd = save_invstd;
+    a.B = B;
+    a.N = N;
+    const int grid = ceil_div_i(N, CW);
+    if (bn)
+        hipLaunchKernelGGL(fc_fwd_kernel<true>, dim3(grid), dim3(CT), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(fc_fwd_kernel<false>, dim3(grid), dim3(CT), 0, (hipStream_t)stream, a);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_fc_epilogue_bwd(int B, int N, const float* din, int64_t ld_in, int n_slabs, const float* addend,
+                                     const float* row_scale, const uint8_t* keep_mask, float dropout_p, int relu,
+                                     const float* a_act, const float* z, const float* gamma, const float* save_mean,
+                                     const float* save_invstd, int has_bn, float* dz_out, int64_t ld_out, float* dbias,
+                                     float* dgamma, float* dbeta, mmvae_stream_t stream) {
+    if (B <= 0 || N <= 0 || !din || n_slabs < 1 || ld_in < N || ld_out < N) return MMVAE_ERR_ARG;
+    if (relu && !a_act) return MMVAE_ERR_ARG;
+    if (keep_mask && (dropout_p < 0.f || dropout_p >= 1.f)) return MMVAE_ERR_ARG;
+    if (has_bn && (!z || !save_mean || !save_invstd || !dz_out)) return MMVAE_ERR_ARG;
+    if (!dz_out && !dbias) return MMVAE_ERR_ARG;
+    BwdArgs a = {};
+    a.din = din;
+    a.ld_in = ld_in;
+    a.slab_stride = (int64_t)B * ld_in;
+    a.n_slabs = n_slabs;
+    a.addend = addend;
+    a.row_scale = row_scale;
+    a.mask = keep_mask;
+    a.keep_scale = keep_mask ? 1.0f / (1.0f - dropout_p) : 1.f;
+    a.relu = relu;
+    a.a = a_act;
+    a.z = z;
+    a.gamma = gamma;
+    a.save_mean = save_mean;
+    a.save_invstd = save_invstd;
+    a.dz_out = dz_out;
+    a.ld_out = ld_out;
+    a.dbias = dbias;
+    a.dgamma = dgamma;
+    a.dbeta = dbeta;
+    a.B = B;
+    a.N = N;
+    const int grid = ceil_div_i(N, CW);
+    if (has_bn)
+        hipLaunchKernelGGL(fc_bwd_kernel<true>, dim3(grid), dim3(CT), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(fc_bwd_kernel<false>, dim3(grid), dim3(CT), 0, (hipStream_t)stream, a);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_layernorm_fwd(int B, int N, const float* x, int64_t ldx, float eps, float* y, int64_t ldy,
+                                   float* save_mean, float* save_invstd, mmvae_stream_t stream) {
+    if (B <= 0 || N <= 0 || !x || !y || ldx < N || ldy < N) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, N, x, ldx,
+                       eps, y, ldy, save_mean, save_invstd);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_layernorm_bwd(int B, int N, const float* dy, int64_t lddy, const float* y, int64_t ldy,
+                                   const float* save_invstd, float* dx, int64_t lddx, mmvae_stream_t stream) {
+    if (B <= 0 || N <= 0 || !dy || !y || !save_invstd || !dx || lddy < N || ldy < N || lddx < N) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, N, dy,
+                       lddy, y, ldy, save_invstd, dx, lddx);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}

@@ -1,0 +1,477 @@
+// fp32 MFMA GEMMs of the MMVAE step (k1-k5 of SURVEY 2b) for gfx950.
+//
+// Replaces the nn.Linear forward/backward dispatches of the reference (components.py:276 and its autograd).
+//
+// Design (MI355X-first, not a port of any BLAS):
+//   * v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate (bitwise an fmaf chain) -> parity with the
+//     reference's fp32 path, at the 157 TFLOP/s matrix peak.
+//   * 256-thread workgroups = 4 wavefronts in a 2x2 grid; block tile 128x128 (or 64x64 for the small core
+//     layers), BK = 32.  Each wave owns (BM/2)x(BN/2) as 32x32 MFMA blocks.
+//   * Operand tiles go HBM -> VGPR (16 B per lane, coalesced along the contiguous axis) -> LDS, double buffered:
+//     the global loads of k-tile t+1 are in flight while the MFMAs of k-tile t run, one barrier per k-tile.
+//   * Two LDS images, chosen per operand by which axis is contiguous in HBM, so that no transposing pass exists:
+//       KC ("K contiguous", x / W rows):   [rows][BK+4]  read with ONE ds_read_b128 per lane = 4 k-steps
+//       RC ("row contiguous", k-slices):   [BK][rows]    read with 4 ds_read_b32, lanes along the row axis
+//     The MFMA's k index is permuted (lane-half h of step j reads k = 8*kk + 4*h + j) identically for A and B,
+//     which is legal because k is summed over; it is what lets the KC image feed 4 MFMAs from one 16-byte read.
+//     The +4 float row pad makes those reads bank-conflict free (stride 144 B over the 64-bank b128 groups).
+//   * Split-K over gridDim-level slices for the K = G (20k gene) reductions that only have 32 output tiles;
+//     partial slabs are reduced in fixed order (no atomics: bitwise reproducible).
+//   * Workgroup ids are remapped so each XCD (private 4 MiB L2) gets a contiguous run of tiles, M fastest:
+//     neighbouring tiles share the same weight / activation panel in that XCD's L2.
+//   * The last decoder layer has its own epilogue: bias + ReLU + (xhat - x)^2 + dP, with the per-cell squared
+//     error reduced across the wavefront by shuffles (mmvae_decoder_recon_f32).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int KC_LD = BK + 4;  // floats per LDS row of a K-contiguous operand tile
+constexpr int NT = 256;        // threads per workgroup
+
+enum { FORM_KC = 0, FORM_RC = 1 };
+enum { EPI_STD = 0, EPI_RECON = 1 };
+
+template <int FORM, int R>
+struct Tile {
+    static constexpr int LDS_FLOATS = (FORM == FORM_KC) ? R * KC_LD : BK * R;
+    static constexpr int VECS = R / 32;  // float4 per thread per k-tile
+};
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    int64_t lda, ldb, ldc;
+    int M, N, K;
+    int mt, nt;            // tiles along M, N
+    int ktiles;            // total k-tiles
+    int ktiles_per_split;  // k-tiles per split-K slice
+    int64_t slab_stride;   // elements between split-K slabs of C (0 when splitk == 1)
+    float alpha;
+    unsigned flags;
+    // recon epilogue
+    const float* x;
+    float* xhat;
+    float* dP;
+    float* se_part;
+    int64_t ldx, ldxhat, lddp;
+    int x_rows;  // x row = output row % x_rows (K-sample decode stacks K copies of the batch)
+};
+
+// HBM -> registers.  r0: first row (KC) / column (RC) of this tile along the non-K axis, Rtot its extent.
+template <int FORM, int R, bool ALIGNED>
+__device__ __forceinline__ void load_tile(f32x4 (&reg)[R / 32], const float* __restrict__ P, int64_t ld, int r0,
+                                          int Rtot, int k0, int Kend, int tid) {
+#pragma unroll
+    for (int i = 0; i < R / 32; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (FORM == FORM_KC) {
+            const int c4 = tid & 7;
+            const int gr = r0 + (tid >> 3) + 32 * i;
+            const int gk = k0 + c4 * 4;
+            if (gr < Rtot && gk < Kend) {
+                const float* p = P + (int64_t)gr * ld + gk;
+                if (ALIGNED && gk + 3 < Kend) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+                    v.x = p[0];
+                    if (gk + 1 < Kend) v.y = p[1];
+                    if (gk + 2 < Kend) v.z = p[2];
+                    if (gk + 3 < Kend) v.w = p[3];
+                }
+            }
+        } else {
+            constexpr int C4 = R / 4;  // float4 per k-row
+            const int c4 = tid % C4;
+            const int gk = k0 + tid / C4 + (NT / C4) * i;
+            const int gr = r0 + c4 * 4;
+            if (gk < Kend && gr < Rtot) {
+                const float* p = P + (int64_t)gk * ld + gr;
+                if (ALIGNED && gr + 3 < Rtot) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+                    v.x = p[0];
+                    if (gr + 1 < Rtot) v.y = p[1];
+                    if (gr + 2 < Rtot) v.z = p[2];
+                    if (gr + 3 < Rtot) v.w = p[3];
+                }
+            }
+        }
+        reg[i] = v;
+    }
+}
+
+// registers -> LDS image
+template <int FORM, int R>
+__device__ __forceinline__ void store_tile(float* S, const f32x4 (&reg)[R / 32], int tid) {
+#pragma unroll
+    for (int i = 0; i < R / 32; ++i) {
+        if (FORM == FORM_KC) {
+            const int c4 = tid & 7;
+            const int r = (tid >> 3) + 32 * i;
+            *reinterpret_cast<f32x4*>(&S[r * KC_LD + c4 * 4]) = reg[i];
+        } else {
+            constexpr int C4 = R / 4;
+            const int c4 = tid % C4;
+            const int k = tid / C4 + (NT / C4) * i;
+            *reinterpret_cast<f32x4*>(&S[k * R + c4 * 4]) = reg[i];
+        }
+    }
+}
+
+// LDS -> MFMA operand fragment: element j of the result feeds MFMA step j of k-group kk and carries
+// k = 8*kk + 4*half + j for row/column `row` of the tile.
+template <int FORM, int R>
+__device__ __forceinline__ f32x4 load_frag(const float* S, int row, int kk, int half) {
+    if (FORM == FORM_KC) {
+        return *reinterpret_cast<const f32x4*>(&S[row * KC_LD + kk * 8 + 4 * half]);
+    } else {
+        const float* q = &S[(kk * 8 + 4 * half) * R + row];
+        f32x4 f;
+        f.x = q[0];
+        f.y = q[R];
+        f.z = q[2 * R];
+        f.w = q[3 * R];
+        return f;
+    }
+}
+
+template <int AFORM, int BFORM, int BM, int BN, bool ALIGNED, int EPI>
+__global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
+    constexpr int TM = BM / 64;  // 32x32 MFMA blocks per wave along M (wave grid is 2x2)
+    constexpr int TN = BN / 64;
+    constexpr int A_FLOATS = Tile<AFORM, BM>::LDS_FLOATS;
+    constexpr int B_FLOATS = Tile<BFORM, BN>::LDS_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[2 * A_FLOATS + 2 * B_FLOATS];
+    float* As = lds;
+    float* Bs = lds + 2 * A_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // XCD-aware (bijective) remap of the workgroup id, then z (split-K slice) slowest, M fastest.
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tiles = g.mt * g.nt;
+    const int z = L / tiles;
+    const int t = L - z * tiles;
+    const int bm = t % g.mt, bn = t / g.mt;
+
+    const int kt_beg = z * g.ktiles_per_split;
+    int kt_end = kt_beg + g.ktiles_per_split;
+    if (kt_end > g.ktiles) kt_end = g.ktiles;
+    const int nkt = kt_end - kt_beg;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
+
+    f32x4 ra[BM / 32], rb[BN / 32];
+    if (nkt > 0) {
+        load_tile<AFORM, BM, ALIGNED>(ra, g.A, g.lda, bm * BM, g.M, kt_beg * BK, g.K, tid);
+        load_tile<BFORM, BN, ALIGNED>(rb, g.B, g.ldb, bn * BN, g.N, kt_beg * BK, g.K, tid);
+        store_tile<AFORM, BM>(As, ra, tid);
+        store_tile<BFORM, BN>(Bs, rb, tid);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            const bool more = (kt + 1 < nkt);
+            if (more) {
+                const int k0 = (kt_beg + kt + 1) * BK;
+                load_tile<AFORM, BM, ALIGNED>(ra, g.A, g.lda, bm * BM, g.M, k0, g.K, tid);
+                load_tile<BFORM, BN, ALIGNED>(rb, g.B, g.ldb, bn * BN, g.N, k0, g.K, tid);
+            }
+            const float* Ac = As + cur * A_FLOATS;
+            const float* Bc = Bs + cur * B_FLOATS;
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                f32x4 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = load_frag<AFORM, BM>(Ac, wm * (BM / 2) + i * 32 + l31, kk, half);
+#pragma unroll
+                for (int n = 0; n < TN; ++n) fb[n] = load_frag<BFORM, BN>(Bc, wn * (BN / 2) + n * 32 + l31, kk, half);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int n = 0; n < TN; ++n)
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[n][j], acc[i][n], 0, 0, 0);
+            }
+            if (more) {
+                store_tile<AFORM, BM>(As + (cur ^ 1) * A_FLOATS, ra, tid);
+                store_tile<BFORM, BN>(Bs + (cur ^ 1) * B_FLOATS, rb, tid);
+            }
+            __syncthreads();
+        }
+    }
+
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+    if (EPI == EPI_STD) {
+        float* C = g.C + (int64_t)z * g.slab_stride;
+        const bool raw = (g.flags & MMVAE_GEMM_RAW_SLABS) || g.slab_stride != 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                const int col = bn * BN + wn * (BN / 2) + n * 32 + l31;
+                if (col >= g.N) continue;
+                const float bv = (!raw && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = bm * BM + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    if (row >= g.M) continue;
+                    float* cp = C + (int64_t)row * g.ldc + col;
+                    float v = acc[i][n][e];
+                    if (!raw) {
+                        v = v * g.alpha + bv;
+                        if (g.flags & MMVAE_GEMM_ACCUMULATE) v += *cp;
+                        if (g.flags & MMVAE_GEMM_RELU) v = fmaxf(v, 0.f);
+                    }
+                    *cp = v;
+                }
+            }
+    } else {
+        // bias + ReLU + squared error + dP; per-cell SE reduced over the 32 lanes that share a row.
+        float* rowsum = lds;  // [2 (wn)][BM] scratch: the operand tiles are dead after the final barrier
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rloc = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                const int row = bm * BM + rloc;
+                float s = 0.f;
+                if (row < g.M) {
+                    const int xr = row % g.x_rows;
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) {
+                        const int col = bn * BN + wn * (BN / 2) + n * 32 + l31;
+                        if (col < g.N) {
+                            const float p = acc[i][n][e] + (g.bias ? g.bias[col] : 0.f);
+                            const float xh = fmaxf(p, 0.f);
+                            const float d = xh - g.x[(int64_t)xr * g.ldx + col];
+                            s += d * d;
+                            if (g.xhat) g.xhat[(int64_t)row * g.ldxhat + col] = xh;
+                            if (g.dP) g.dP[(int64_t)row * g.lddp + col] = (p > 0.f) ? 2.f * d : 0.f;
+                        }
+                    }
+                }
+                s = half_wave_sum(s);
+                if (l31 == 0) rowsum[wn * BM + rloc] = s;
+            }
+        }
+        __syncthreads();
+        if (tid < BM) {
+            const int row = bm * BM + tid;
+            if (row < g.M) g.se_part[(int64_t)bn * g.M + row] = rowsum[tid] + rowsum[BM + tid];
+        }
+    }
+}
+
+// Fixed-order reduction of split-K slabs + the standard epilogue.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int S, int64_t slab_stride,
+                                                            int M, int N, float alpha, const float* __restrict__ bias,
+                                                            unsigned flags, float* __restrict__ C, int64_t ldc) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / N), col = (int)(idx - (int64_t)row * N);
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += slabs[(int64_t)k * slab_stride + idx];
+        float v = s * alpha + (bias ? bias[col] : 0.f);
+        float* cp = C + (int64_t)row * ldc + col;
+        if (flags & MMVAE_GEMM_ACCUMULATE) v += *cp;
+        if (flags & MMVAE_GEMM_RELU) v = fmaxf(v, 0.f);
+        *cp = v;
+    }
+}
+
+template <int AFORM, int BFORM, int BM, int BN, int EPI>
+int launch_gemm(const GemmArgs& g, bool aligned, int nblocks, hipStream_t s) {
+    if (aligned)
+        hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, BM, BN, true, EPI>), dim3(nblocks), dim3(NT), 0, s, g);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, BM, BN, false, EPI>), dim3(nblocks), dim3(NT), 0, s, g);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+void plan(int M, int N, int K, int* tile, int* splitk) {
+    const int kt = ceil_div_i(K, BK);
+    const int t128 = ceil_div_i(M, 128) * ceil_div_i(N, 128);
+    const int t64 = ceil_div_i(M, 64) * ceil_div_i(N, 64);
+    if (t128 >= 192) {
+        *tile = 128;
+        *splitk = 1;
+        return;
+    }
+    int sA = ceil_div_i(512, t128);
+    if (sA > kt / 8) sA = kt / 8;
+    if (sA < 1) sA = 1;
+    if (sA > 64) sA = 64;
+    int sB = ceil_div_i(512, t64);
+    if (sB > kt / 4) sB = kt / 4;
+    if (sB < 1) sB = 1;
+    if (sB > 64) sB = 64;
+    if (t128 * sA >= 256 || t128 * sA >= t64 * sB) {
+        *tile = 128;
+        *splitk = sA;
+    } else {
+        *tile = 64;
+        *splitk = sB;
+    }
+}
+
+}  // namespace
+
+extern "C" int mmvae_gemm_plan(int layout, int M, int N, int K, int* tile_out, int* splitk_out) {
+    if (layout < 0 || layout > 2 || M <= 0 || N <= 0 || K <= 0) return MMVAE_ERR_ARG;
+    int tile, sk;
+    plan(M, N, K, &tile, &sk);
+    if (tile_out) *tile_out = tile;
+    if (splitk_out) *splitk_out = sk;
+    return MMVAE_OK;
+}
+
+extern "C" size_t mmvae_gemm_workspace_bytes(int layout, int M, int N, int K, int splitk) {
+    if (splitk == 0) {
+        int tile;
+        if (mmvae_gemm_plan(layout, M, N, K, &tile, &splitk) != MMVAE_OK) return 0;
+    }
+    return splitk > 1 ? (size_t)splitk * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, const float* A, int64_t lda,
+                              const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, unsigned flags,
+                              int splitk, float* workspace, size_t workspace_bytes, mmvae_stream_t stream) {
+    if (layout < 0 || layout > 2 || M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return MMVAE_ERR_ARG;
+    if (splitk < 0 || ldc < N) return MMVAE_ERR_ARG;
+    // leading-dimension sanity: contiguous axis extent must fit in the stride
+    const int64_t a_inner = (layout == MMVAE_GEMM_TN) ? M : K;
+    const int64_t b_inner = (layout == MMVAE_GEMM_NT) ? K : N;
+    if (lda < a_inner || ldb < b_inner) return MMVAE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+
+    int tile, sk_auto;
+    plan(M, N, K, &tile, &sk_auto);
+    if (splitk == 0) splitk = sk_auto;
+    const int ktiles = ceil_div_i(K, BK);
+    const bool raw = (flags & MMVAE_GEMM_RAW_SLABS) != 0;
+    if (!raw && splitk > ktiles) splitk = ktiles;
+    if (raw && (flags & (MMVAE_GEMM_RELU | MMVAE_GEMM_ACCUMULATE))) return MMVAE_ERR_ARG;
+    if (raw && bias) return MMVAE_ERR_ARG;
+
+    GemmArgs g = {};
+    g.A = A;
+    g.B = B;
+    g.bias = bias;
+    g.lda = lda;
+    g.ldb = ldb;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.mt = ceil_div_i(M, tile);
+    g.nt = ceil_div_i(N, tile);
+    g.ktiles = ktiles;
+    g.ktiles_per_split = ceil_div_i(ktiles, splitk);
+    if (!raw) splitk = ceil_div_i(ktiles, g.ktiles_per_split);  // drop empty trailing slices (raw: caller sized the slabs)
+    g.alpha = alpha;
+    g.flags = flags;
+    g.x_rows = 1;
+    if (raw) {
+        g.C = C;
+        g.ldc = ldc;
+        g.slab_stride = (int64_t)M * ldc;
+    } else if (splitk > 1) {
+        if (!workspace || workspace_bytes < (size_t)splitk * M * N * sizeof(float)) return MMVAE_ERR_WORKSPACE;
+        g.C = workspace;
+        g.ldc = N;
+        g.slab_stride = (int64_t)M * N;
+    } else {
+        g.C = C;
+        g.ldc = ldc;
+        g.slab_stride = 0;
+    }
+    const bool aligned = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+    const int nblocks = g.mt * g.nt * splitk;
+    int rc;
+    if (tile == 128) {
+        if (layout == MMVAE_GEMM_NT)
+            rc = launch_gemm<FORM_KC, FORM_KC, 128, 128, EPI_STD>(g, aligned, nblocks, s);
+        else if (layout == MMVAE_GEMM_NN)
+            rc = launch_gemm<FORM_KC, FORM_RC, 128, 128, EPI_STD>(g, aligned, nblocks, s);
+        else
+            rc = launch_gemm<FORM_RC, FORM_RC, 128, 128, EPI_STD>(g, aligned, nblocks, s);
+    } else {
+        if (layout == MMVAE_GEMM_NT)
+            rc = launch_gemm<FORM_KC, FORM_KC, 64, 64, EPI_STD>(g, aligned, nblocks, s);
+        else if (layout == MMVAE_GEMM_NN)
+            rc = launch_gemm<FORM_KC, FORM_RC, 64, 64, EPI_STD>(g, aligned, nblocks, s);
+        else
+            rc = launch_gemm<FORM_RC, FORM_RC, 64, 64, EPI_STD>(g, aligned, nblocks, s);
+    }
+    if (rc != MMVAE_OK) return rc;
+    if (!raw && splitk > 1) {
+        const int64_t total = (int64_t)M * N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, workspace, splitk, (int64_t)M * N, M,
+                           N, alpha, bias, flags, C, ldc);
+        MMVAE_LAUNCH_CHECK();
+    }
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_recon_tiles(int G) { return G > 0 ? ceil_div_i(G, 128) : 0; }
+
+extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, const float* h, int64_t ldh,
+                                            const float* W, int64_t ldw, const float* bias, const float* x, int64_t ldx,
+                                            float* xhat, int64_t ldxhat, float* dP, int64_t lddp, float* se_part,
+                                            mmvae_stream_t stream) {
+    if (rows <= 0 || x_rows <= 0 || rows % x_rows != 0 || G <= 0 || H <= 0 || !h || !W || !x || !se_part)
+        return MMVAE_ERR_ARG;
+    if (ldh < H || ldw < H || ldx < G) return MMVAE_ERR_ARG;
+    if (xhat && ldxhat < G) return MMVAE_ERR_ARG;
+    if (dP && lddp < G) return MMVAE_ERR_ARG;
+    GemmArgs g = {};
+    g.A = h;
+    g.B = W;
+    g.bias = bias;
+    g.lda = ldh;
+    g.ldb = ldw;
+    g.M = rows;
+    g.N = G;
+    g.K = H;
+    g.mt = ceil_div_i(rows, 128);
+    g.nt = ceil_div_i(G, 128);
+    g.ktiles = ceil_div_i(H, BK);
+    g.ktiles_per_split = g.ktiles;
+    g.alpha = 1.f;
+    g.x = x;
+    g.xhat = xhat;
+    g.dP = dP;
+    g.se_part = se_part;
+    g.ldx = ldx;
+    g.ldxhat = ldxhat;
+    g.lddp = lddp;
+    g.x_rows = x_rows;
+    const bool aligned = aligned16(h) && aligned16(W) && (ldh % 4 == 0) && (ldw % 4 == 0);
+    return launch_gemm<FORM_KC, FORM_KC, 128, 128, EPI_RECON>(g, aligned, g.mt * g.nt, (hipStream_t)stream);
+}
+
+extern "C" int mmvae_decoder_recon_f32(int B, int G, int H, const float* h, int64_t ldh, const float* W, int64_t ldw,
+                                       const float* bias, const float* x, int64_t ldx, float* xhat, int64_t ldxhat,
+                                       float* dP, int64_t lddp, float* se_part, mmvae_stream_t stream) {
+    return mmvae_decoder_recon_rows_f32(B, B, G, H, h, ldh, W, ldw, bias, x, ldx, xhat, ldxhat, dP, lddp, se_part,
+                                        stream);
+}
