@@ -1,0 +1,117 @@
+"""ctypes binding of libmmvae_hip.so (the C-ABI declared in include/mmvae_hip.h).
+
+The library is the product: if it is missing or fails to load, every HIP-path call raises -- there is no
+fallback to torch ops or to the oracle ("no CPU fallback").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmmvae_hip.so")
+
+OK, ERR_ARG, ERR_LAUNCH, ERR_WORKSPACE = 0, 1, 2, 3
+_ERR_NAMES = {1: "MMVAE_ERR_ARG", 2: "MMVAE_ERR_LAUNCH", 3: "MMVAE_ERR_WORKSPACE"}
+
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+GEMM_RELU, GEMM_ACCUMULATE, GEMM_RAW_SLABS = 1, 2, 4
+ADAM_STATE_FLOATS = 8
+
+_p = C.c_void_p
+_i = C.c_int
+_l = C.c_int64
+_f = C.c_float
+_u = C.c_uint
+_z = C.c_size_t
+_u64 = C.c_uint64
+
+
+class BnParams(C.Structure):
+    """mirror of struct mmvae_bn_params"""
+
+    _fields_ = [
+        ("gamma", _p),
+        ("beta", _p),
+        ("running_mean", _p),
+        ("running_var", _p),
+        ("num_batches_tracked", _p),
+        ("momentum", _f),
+        ("eps", _f),
+    ]
+
+
+# name -> (restype, argtypes).  Kept in the order of include/mmvae_hip.h; tests/test_abi.py checks that every
+# symbol the header declares is listed here and exported by the .so.
+PROTOTYPES = {
+    "mmvae_abi_version": (_i, []),
+    "mmvae_build_arch": (C.c_char_p, []),
+    "mmvae_gemm_plan": (_i, [_i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "mmvae_gemm_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "mmvae_gemm_f32": (_i, [_i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _u, _i, _p, _z, _p]),
+    "mmvae_recon_tiles": (_i, [_i]),
+    "mmvae_decoder_recon_f32": (_i, [_i, _i, _i, _p, _l, _p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _p]),
+    "mmvae_decoder_recon_rows_f32": (_i, [_i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _p]),
+    "mmvae_fc_epilogue_fwd": (
+        _i,
+        [_i, _i, _p, _l, _i, _p, C.POINTER(BnParams), _i, _i, _p, _f, _p, _p, _p, _l, _p, _p, _p],
+    ),
+    "mmvae_fc_epilogue_bwd": (
+        _i,
+        [_i, _i, _p, _l, _i, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _i, _p, _l, _p, _p, _p, _p],
+    ),
+    "mmvae_layernorm_fwd": (_i, [_i, _i, _p, _l, _f, _p, _l, _p, _p, _p]),
+    "mmvae_layernorm_bwd": (_i, [_i, _i, _p, _l, _p, _l, _p, _p, _l, _p]),
+    "mmvae_reparam_kl_fwd": (_i, [_i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p, _p]),
+    "mmvae_reparam_kl_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p]),
+    "mmvae_mse_sum_fwd_bwd": (_i, [_i, _i, _p, _l, _p, _l, _p, _p, _l, _p, _f, _p]),
+    "mmvae_elbo_finalize": (_i, [_i, _i, _i, _p, _p, _p, _i, _p, _f, _p, _p, _p]),
+    "mmvae_cross_entropy_sum": (_i, [_i, _i, _p, _l, _p, _p, _p, _l, _f, _p]),
+    "mmvae_sum_f32": (_i, [_l, _p, _p, _i, _p]),
+    "mmvae_sqnorm_partials": (_l, [_l]),
+    "mmvae_grad_sqnorm": (_i, [_l, _p, _p, _p]),
+    "mmvae_adam_prepare": (_i, [_l, _p, _f, _f, _f, _f, _p, _p]),
+    "mmvae_adam_step": (_i, [_l, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _f, _p]),
+    "mmvae_philox_keep_mask": (_i, [_l, _f, _p, _p, _u64, _i, _p]),
+    "mmvae_philox_normal": (_i, [_l, _p, _p, _u64, _i, _p]),
+    "mmvae_axpby": (_i, [_l, _f, _p, _f, _p, _p]),
+    "mmvae_scale_rows": (_i, [_i, _i, _p, _l, _p, _p, _l, _p]),
+}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libmmvae_hip.so (built by __graft_entry__.build() / `make -C mmvae_amd/csrc`).  Raises loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `make -C mmvae_amd/csrc` (or __graft_entry__.build()). "
+            "mmvae_amd has no non-HIP execution path for device tensors."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise HipLibraryError(f"could not load {LIB_PATH}: {e}") from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != OK:
+        raise HipLibraryError(f"{what} failed: {_ERR_NAMES.get(rc, rc)}")

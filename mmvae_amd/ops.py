@@ -1,0 +1,479 @@
+"""Functional wrappers over the C-ABI (one Python function per entry point of include/mmvae_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream.  Every function takes device tensors, passes
+raw pointers / leading dimensions / the current stream to libmmvae_hip.so and returns tensors.  Nothing in this
+module computes with torch ops, and nothing here runs on CPU tensors (a CPU tensor raises).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import GEMM_NT, GEMM_NN, GEMM_TN, GEMM_RELU, GEMM_ACCUMULATE, GEMM_RAW_SLABS  # noqa: F401
+
+_workspaces: dict = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: Optional[torch.Tensor], name: str, dtype=torch.float32) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.HipLibraryError(
+            f"{name}: mmvae_amd HIP ops need a device tensor (got {t.device}); there is no CPU fallback. "
+            "For CPU plumbing (BASELINE config C1) enable mmvae_amd.backend.cpu_plumbing()."
+        )
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _mat(t: torch.Tensor, name: str) -> Tuple[int, int, int]:
+    """(rows, cols, ld) of a 2-D row-major view whose inner stride is 1."""
+    if t.dim() != 2:
+        raise ValueError(f"{name}: expected 2-D, got {tuple(t.shape)}")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise ValueError(f"{name}: inner stride must be 1 (got strides {t.stride()})")
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    if ld < t.shape[1]:
+        raise ValueError(f"{name}: leading dimension {ld} < cols {t.shape[1]}")
+    return t.shape[0], t.shape[1], ld
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only per-device scratch arena (split-K slabs).  Stream-ordered use only."""
+    key = (torch.device(device).index, _stream())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(nbytes // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def gemm_plan(layout: int, M: int, N: int, K: int) -> Tuple[int, int]:
+    lib = _lib.load()
+    tile, sk = C.c_int(0), C.c_int(0)
+    _lib.check(lib.mmvae_gemm_plan(layout, M, N, K, C.byref(tile), C.byref(sk)), "mmvae_gemm_plan")
+    return tile.value, sk.value
+
+
+def gemm(
+    layout: int,
+    a: torch.Tensor,
+    b: torch.Tensor,
+    *,
+    out: Optional[torch.Tensor] = None,
+    bias: Optional[torch.Tensor] = None,
+    alpha: float = 1.0,
+    relu: bool = False,
+    accumulate: bool = False,
+    splitk: int = 0,
+) -> torch.Tensor:
+    """C = alpha * op(A) op(B) (+bias)(relu)(+C).  NT: a[M,K], b[N,K]; NN: a[M,K], b[K,N]; TN: a[K,M], b[K,N]."""
+    lib = _lib.load()
+    _chk(a, "a"), _chk(b, "b"), _chk(bias, "bias")
+    ar, ac, lda = _mat(a, "a")
+    br, bc, ldb = _mat(b, "b")
+    if layout == GEMM_NT:
+        M, K, N = ar, ac, br
+        if bc != K:
+            raise ValueError(f"NT gemm: a {tuple(a.shape)} vs b {tuple(b.shape)}")
+    elif layout == GEMM_NN:
+        M, K, N = ar, ac, bc
+        if br != K:
+            raise ValueError(f"NN gemm: a {tuple(a.shape)} vs b {tuple(b.shape)}")
+    elif layout == GEMM_TN:
+        K, M, N = ar, ac, bc
+        if br != K:
+            raise ValueError(f"TN gemm: a {tuple(a.shape)} vs b {tuple(b.shape)}")
+    else:
+        raise ValueError("layout")
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs out")
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _chk(out, "out")
+    orr, oc, ldc = _mat(out, "out")
+    if (orr, oc) != (M, N):
+        raise ValueError(f"out {tuple(out.shape)} != {(M, N)}")
+    if bias is not None and (bias.numel() != N or not bias.is_contiguous()):
+        raise ValueError("bias must be contiguous [N]")
+    if splitk == 0:
+        _, splitk = gemm_plan(layout, M, N, K)
+    nbytes = lib.mmvae_gemm_workspace_bytes(layout, M, N, K, splitk)
+    ws = workspace(nbytes, a.device) if nbytes else None
+    flags = (GEMM_RELU if relu else 0) | (GEMM_ACCUMULATE if accumulate else 0)
+    rc = lib.mmvae_gemm_f32(
+        layout, M, N, K, alpha, _ptr(a), lda, _ptr(b), ldb, _ptr(out), ldc, _ptr(bias), flags, splitk, _ptr(ws),
+        nbytes, _stream(),
+    )
+    _lib.check(rc, "mmvae_gemm_f32")
+    return out
+
+
+def gemm_slabs(layout: int, a: torch.Tensor, b: torch.Tensor, splitk: int = 0) -> torch.Tensor:
+    """Raw split-K partial products [S, M, N] (no epilogue), to be summed by fc_epilogue_fwd / _bwd."""
+    lib = _lib.load()
+    _chk(a, "a"), _chk(b, "b")
+    ar, ac, lda = _mat(a, "a")
+    br, bc, ldb = _mat(b, "b")
+    if layout == GEMM_NT:
+        M, K, N = ar, ac, br
+    elif layout == GEMM_NN:
+        M, K, N = ar, ac, bc
+    else:
+        K, M, N = ar, ac, bc
+    if splitk == 0:
+        _, splitk = gemm_plan(layout, M, N, K)
+    out = torch.empty((splitk, M, N), dtype=torch.float32, device=a.device)
+    rc = lib.mmvae_gemm_f32(
+        layout, M, N, K, 1.0, _ptr(a), lda, _ptr(b), ldb, _ptr(out), N, None, GEMM_RAW_SLABS, splitk, None, 0, _stream()
+    )
+    _lib.check(rc, "mmvae_gemm_f32(raw slabs)")
+    return out
+
+
+def recon_tiles(G: int) -> int:
+    return _lib.load().mmvae_recon_tiles(G)
+
+
+def decoder_recon(
+    h: torch.Tensor,
+    W: torch.Tensor,
+    bias: Optional[torch.Tensor],
+    x: torch.Tensor,
+    *,
+    want_xhat: bool = True,
+    want_dP: bool = True,
+    xhat: Optional[torch.Tensor] = None,
+    dP: Optional[torch.Tensor] = None,
+    se_part: Optional[torch.Tensor] = None,
+):
+    """Fused last decoder layer + squared error.  h [R,H] (R = K*B rows), W [G,H], x [B,G].
+    Returns (xhat [R,G] | None, dP [R,G] | None, se_part [tiles, R])."""
+    lib = _lib.load()
+    _chk(h, "h"), _chk(W, "W"), _chk(bias, "bias"), _chk(x, "x")
+    R, H, ldh = _mat(h, "h")
+    G, H2, ldw = _mat(W, "W")
+    B, G2, ldx = _mat(x, "x")
+    if H2 != H or G2 != G or R % B != 0:
+        raise ValueError(f"decoder_recon shapes: h {tuple(h.shape)} W {tuple(W.shape)} x {tuple(x.shape)}")
+    T = lib.mmvae_recon_tiles(G)
+    if xhat is None and want_xhat:
+        xhat = torch.empty((R, G), dtype=torch.float32, device=h.device)
+    if dP is None and want_dP:
+        dP = torch.empty((R, G), dtype=torch.float32, device=h.device)
+    if se_part is None:
+        se_part = torch.empty((T, R), dtype=torch.float32, device=h.device)
+    ldxh = _mat(xhat, "xhat")[2] if xhat is not None else 0
+    lddp = _mat(dP, "dP")[2] if dP is not None else 0
+    rc = lib.mmvae_decoder_recon_rows_f32(
+        R, B, G, H, _ptr(h), ldh, _ptr(W), ldw, _ptr(bias), _ptr(x), ldx, _ptr(xhat), ldxh, _ptr(dP), lddp,
+        _ptr(se_part), _stream(),
+    )
+    _lib.check(rc, "mmvae_decoder_recon_rows_f32")
+    return xhat, dP, se_part
+
+
+def fc_epilogue_fwd(
+    inp: torch.Tensor,
+    bias: Optional[torch.Tensor],
+    *,
+    bn: Optional[dict] = None,
+    training: bool = True,
+    relu: bool = False,
+    keep_mask: Optional[torch.Tensor] = None,
+    dropout_p: float = 0.0,
+    want_a: bool = True,
+):
+    """inp: [B,N] or slabs [S,B,N].  bn: dict(gamma, beta, running_mean, running_var, num_batches_tracked,
+    momentum, eps) or None.  Returns dict(z, a, d, mean, invstd) (entries may be None)."""
+    lib = _lib.load()
+    _chk(inp, "inp"), _chk(bias, "bias"), _chk(keep_mask, "keep_mask", torch.uint8)
+    if inp.dim() == 2:
+        inp = inp.unsqueeze(0)
+    if not inp.is_contiguous():
+        raise ValueError("inp must be contiguous")
+    S, B, N = inp.shape
+    dev = inp.device
+    has_drop = keep_mask is not None
+    z = torch.empty((B, N), dtype=torch.float32, device=dev) if bn is not None else None
+    d = torch.empty((B, N), dtype=torch.float32, device=dev)
+    a = torch.empty((B, N), dtype=torch.float32, device=dev) if (has_drop and want_a) else None
+    mean = invstd = None
+    bnp = None
+    if bn is not None:
+        if training:
+            mean = torch.empty(N, dtype=torch.float32, device=dev)
+            invstd = torch.empty(N, dtype=torch.float32, device=dev)
+        nbt = bn.get("num_batches_tracked")
+        bnp = _lib.BnParams(
+            _ptr(bn.get("gamma")), _ptr(bn.get("beta")), _ptr(bn.get("running_mean")), _ptr(bn.get("running_var")),
+            _ptr(nbt) if nbt is not None else None, float(bn.get("momentum", 0.01)), float(bn.get("eps", 1e-3)),
+        )
+    if has_drop and (tuple(keep_mask.shape) != (B, N) or not keep_mask.is_contiguous()):
+        raise ValueError("keep_mask must be contiguous [B,N] uint8")
+    rc = lib.mmvae_fc_epilogue_fwd(
+        B, N, _ptr(inp), N, S, _ptr(bias), C.byref(bnp) if bnp is not None else None, int(training), int(relu),
+        _ptr(keep_mask), float(dropout_p), _ptr(z), _ptr(a), _ptr(d), N, _ptr(mean), _ptr(invstd), _stream(),
+    )
+    _lib.check(rc, "mmvae_fc_epilogue_fwd")
+    return {"z": z, "a": a if a is not None else d, "d": d, "mean": mean, "invstd": invstd}
+
+
+def fc_epilogue_bwd(
+    din: torch.Tensor,
+    *,
+    addend: Optional[torch.Tensor] = None,
+    row_scale: Optional[torch.Tensor] = None,
+    keep_mask: Optional[torch.Tensor] = None,
+    dropout_p: float = 0.0,
+    relu: bool = False,
+    a: Optional[torch.Tensor] = None,
+    z: Optional[torch.Tensor] = None,
+    gamma: Optional[torch.Tensor] = None,
+    mean: Optional[torch.Tensor] = None,
+    invstd: Optional[torch.Tensor] = None,
+    has_bn: bool = False,
+    want_dz: bool = True,
+    want_dbias: bool = True,
+    dbias_out: Optional[torch.Tensor] = None,
+    dgamma_out: Optional[torch.Tensor] = None,
+    dbeta_out: Optional[torch.Tensor] = None,
+):
+    """Backward of the layer tail.  din: [B,N] or slabs [S,B,N].  Returns (dz, dbias, dgamma, dbeta)."""
+    lib = _lib.load()
+    _chk(din, "din")
+    if din.dim() == 2:
+        din = din.unsqueeze(0)
+    if not din.is_contiguous():
+        raise ValueError("din must be contiguous")
+    S, B, N = din.shape
+    dev = din.device
+    for name, t in (("addend", addend), ("a", a), ("z", z)):
+        _chk(t, name)
+        if t is not None and (tuple(t.shape) != (B, N) or not t.is_contiguous()):
+            raise ValueError(f"{name} must be contiguous [B,N]")
+    _chk(row_scale, "row_scale"), _chk(keep_mask, "keep_mask", torch.uint8)
+    dz = torch.empty((B, N), dtype=torch.float32, device=dev) if (want_dz or has_bn) else None
+    dbias = dbias_out if dbias_out is not None else (torch.empty(N, dtype=torch.float32, device=dev) if want_dbias else None)
+    dgamma = dbeta = None
+    if has_bn:
+        dgamma = dgamma_out if dgamma_out is not None else torch.empty(N, dtype=torch.float32, device=dev)
+        dbeta = dbeta_out if dbeta_out is not None else torch.empty(N, dtype=torch.float32, device=dev)
+    rc = lib.mmvae_fc_epilogue_bwd(
+        B, N, _ptr(din), N, S, _ptr(addend), _ptr(row_scale), _ptr(keep_mask), float(dropout_p), int(relu), _ptr(a),
+        _ptr(z), _ptr(gamma), _ptr(mean), _ptr(invstd), int(has_bn), _ptr(dz), N, _ptr(dbias), _ptr(dgamma),
+        _ptr(dbeta), _stream(),
+    )
+    _lib.check(rc, "mmvae_fc_epilogue_bwd")
+    return dz, dbias, dgamma, dbeta
+
+
+def layernorm_fwd(x: torch.Tensor, eps: float = 1e-5):
+    lib = _lib.load()
+    _chk(x, "x")
+    B, N, ldx = _mat(x, "x")
+    y = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    invstd = torch.empty(B, dtype=torch.float32, device=x.device)
+    _lib.check(lib.mmvae_layernorm_fwd(B, N, _ptr(x), ldx, eps, _ptr(y), N, None, _ptr(invstd), _stream()), "layernorm_fwd")
+    return y, invstd
+
+
+def layernorm_bwd(dy: torch.Tensor, y: torch.Tensor, invstd: torch.Tensor):
+    lib = _lib.load()
+    _chk(dy, "dy"), _chk(y, "y"), _chk(invstd, "invstd")
+    B, N, lddy = _mat(dy, "dy")
+    _, _, ldy = _mat(y, "y")
+    dx = torch.empty((B, N), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.mmvae_layernorm_bwd(B, N, _ptr(dy), lddy, _ptr(y), ldy, _ptr(invstd), _ptr(dx), N, _stream()), "layernorm_bwd")
+    return dx
+
+
+def reparam_kl_fwd(mu: torch.Tensor, a_raw: torch.Tensor, eps: Optional[torch.Tensor], var_eps: float = 1e-4,
+                   want_stats: bool = True):
+    """mu, a_raw [B,Z]; eps [K,B,Z] or [B,Z] or None.  Returns (std [B,Z], z [K,B,Z]|None, kl_row [B], stat_row [B,2]|None)."""
+    lib = _lib.load()
+    _chk(mu, "mu"), _chk(a_raw, "a_raw"), _chk(eps, "eps")
+    if not (mu.is_contiguous() and a_raw.is_contiguous()):
+        raise ValueError("mu / a_raw must be contiguous")
+    B, Z = mu.shape
+    K = 1
+    z = None
+    if eps is not None:
+        if not eps.is_contiguous():
+            raise ValueError("eps must be contiguous")
+        K = eps.shape[0] if eps.dim() == 3 else 1
+        if eps.numel() != K * B * Z:
+            raise ValueError("eps shape")
+        z = torch.empty((K, B, Z) if eps.dim() == 3 else (B, Z), dtype=torch.float32, device=mu.device)
+    std = torch.empty_like(mu)
+    kl_row = torch.empty(B, dtype=torch.float32, device=mu.device)
+    stat = torch.empty((B, 2), dtype=torch.float32, device=mu.device) if want_stats else None
+    rc = lib.mmvae_reparam_kl_fwd(B, Z, K, _ptr(mu), _ptr(a_raw), _ptr(eps), var_eps, _ptr(std), _ptr(z), _ptr(kl_row),
+                                  _ptr(stat), _stream())
+    _lib.check(rc, "mmvae_reparam_kl_fwd")
+    return std, z, kl_row, stat
+
+
+def reparam_kl_bwd(mu, std, eps, dz, *, dmu_extra=None, dstd_extra=None, dkl_row=None, kl_scale_dev=None,
+                   kl_scale: float = 1.0, var_eps: float = 1e-4):
+    lib = _lib.load()
+    for n, t in (("mu", mu), ("std", std), ("eps", eps), ("dz", dz), ("dmu_extra", dmu_extra),
+                 ("dstd_extra", dstd_extra), ("dkl_row", dkl_row), ("kl_scale_dev", kl_scale_dev)):
+        _chk(t, n)
+        if t is not None and not t.is_contiguous():
+            raise ValueError(f"{n} must be contiguous")
+    B, Z = mu.shape
+    K = 1
+    if dz is not None:
+        K = dz.numel() // (B * Z)
+    dmu = torch.empty_like(mu)
+    da = torch.empty_like(mu)
+    rc = lib.mmvae_reparam_kl_bwd(B, Z, K, _ptr(mu), _ptr(std), _ptr(eps), _ptr(dz), _ptr(dmu_extra), _ptr(dstd_extra),
+                                  _ptr(dkl_row), _ptr(kl_scale_dev), float(kl_scale), var_eps, _ptr(dmu), _ptr(da),
+                                  _stream())
+    _lib.check(rc, "mmvae_reparam_kl_bwd")
+    return dmu, da
+
+
+def mse_sum_fwd_bwd(xhat: torch.Tensor, x: torch.Tensor, *, want_grad: bool = True, gscale_dev=None,
+                    gscale: float = 1.0):
+    """Returns (se_row [B], dxhat [B,G] | None) with dxhat = gscale * 2 (xhat - x)."""
+    lib = _lib.load()
+    _chk(xhat, "xhat"), _chk(x, "x"), _chk(gscale_dev, "gscale_dev")
+    B, G, ldxh = _mat(xhat, "xhat")
+    B2, G2, ldx = _mat(x, "x")
+    if (B, G) != (B2, G2):
+        raise ValueError("mse shapes")
+    se = torch.empty(B, dtype=torch.float32, device=x.device)
+    dx = torch.empty((B, G), dtype=torch.float32, device=x.device) if want_grad else None
+    rc = lib.mmvae_mse_sum_fwd_bwd(B, G, _ptr(xhat), ldxh, _ptr(x), ldx, _ptr(se), _ptr(dx), G, _ptr(gscale_dev),
+                                   float(gscale), _stream())
+    _lib.check(rc, "mmvae_mse_sum_fwd_bwd")
+    return se, dx
+
+
+def elbo_finalize(se_part: torch.Tensor, kl_row, stat_row, *, B: int, K: int = 1, Z: int = 0, kl_weight_dev=None,
+                  kl_weight: float = 1.0, want_w: bool = False):
+    """se_part [T, K*B].  Returns (out6 [6] = loss, recon, kl, kl_weight, mean(mu), mean(var); w [K*B] | None)."""
+    lib = _lib.load()
+    _chk(se_part, "se_part"), _chk(kl_row, "kl_row"), _chk(stat_row, "stat_row"), _chk(kl_weight_dev, "klw")
+    if se_part.dim() == 1:
+        se_part = se_part.unsqueeze(0)
+    if not se_part.is_contiguous() or se_part.shape[1] != K * B:
+        raise ValueError("se_part must be contiguous [T, K*B]")
+    T = se_part.shape[0]
+    out = torch.empty(6, dtype=torch.float32, device=se_part.device)
+    w = torch.empty(K * B, dtype=torch.float32, device=se_part.device) if want_w else None
+    rc = lib.mmvae_elbo_finalize(B, K, T, _ptr(se_part), _ptr(kl_row), _ptr(stat_row), Z, _ptr(kl_weight_dev),
+                                 float(kl_weight), _ptr(out), _ptr(w), _stream())
+    _lib.check(rc, "mmvae_elbo_finalize")
+    return out, w
+
+
+def cross_entropy_sum(logits: torch.Tensor, labels: torch.Tensor, *, want_grad: bool = True, gscale: float = 1.0):
+    """Returns (loss_rows [B], dlogits [B,C] | None)."""
+    lib = _lib.load()
+    _chk(logits, "logits"), _chk(labels, "labels", torch.int64)
+    B, Cn, ld = _mat(logits, "logits")
+    if labels.numel() != B or not labels.is_contiguous():
+        raise ValueError("labels must be contiguous [B] int64")
+    rows = torch.empty(B, dtype=torch.float32, device=logits.device)
+    dl = torch.empty((B, Cn), dtype=torch.float32, device=logits.device) if want_grad else None
+    rc = lib.mmvae_cross_entropy_sum(B, Cn, _ptr(logits), ld, _ptr(labels), _ptr(rows), _ptr(dl), Cn, float(gscale),
+                                     _stream())
+    _lib.check(rc, "mmvae_cross_entropy_sum")
+    return rows, dl
+
+
+def sum_f32(v: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    lib = _lib.load()
+    _chk(v, "v")
+    if not v.is_contiguous():
+        raise ValueError("v must be contiguous")
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=v.device)
+    _lib.check(lib.mmvae_sum_f32(v.numel(), _ptr(v), _ptr(out), int(accumulate), _stream()), "mmvae_sum_f32")
+    return out
+
+
+def sqnorm_partials(n: int) -> int:
+    return _lib.load().mmvae_sqnorm_partials(n)
+
+
+def clip_adam_step(param, grad, exp_avg, exp_avg_sq, state, partials, *, lr=5e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+                   weight_decay=1e-6, max_norm=0.0, grad_scale=1.0, do_norm=True, do_step=True):
+    """Global-norm clip + Adam over one flat arena.  `state`: float32[8] device tensor (step, norm, clip, bc1, bc2)."""
+    lib = _lib.load()
+    for n_, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq),
+                  ("state", state), ("partials", partials)):
+        _chk(t, n_)
+        if not t.is_contiguous():
+            raise ValueError(f"{n_} must be contiguous")
+    n = param.numel()
+    if grad.numel() != n or exp_avg.numel() != n or exp_avg_sq.numel() != n or state.numel() < 8:
+        raise ValueError("arena sizes")
+    s = _stream()
+    if do_norm:
+        npart = lib.mmvae_sqnorm_partials(n)
+        if partials.numel() < npart:
+            raise ValueError("partials too small")
+        _lib.check(lib.mmvae_grad_sqnorm(n, _ptr(grad), _ptr(partials), s), "mmvae_grad_sqnorm")
+        _lib.check(lib.mmvae_adam_prepare(npart, _ptr(partials), float(max_norm), float(grad_scale), beta1, beta2,
+                                          _ptr(state), s), "mmvae_adam_prepare")
+    if do_step:
+        _lib.check(lib.mmvae_adam_step(n, _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(state), lr,
+                                       beta1, beta2, eps, weight_decay, float(grad_scale), s), "mmvae_adam_step")
+
+
+def philox_keep_mask(shape, p_drop: float, rng_state: torch.Tensor, stream_id: int = 0, advance: bool = True,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    _chk(rng_state, "rng_state", torch.int64)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.uint8, device=rng_state.device)
+    _lib.check(lib.mmvae_philox_keep_mask(out.numel(), float(p_drop), _ptr(out), _ptr(rng_state), stream_id,
+                                          int(advance), _stream()), "mmvae_philox_keep_mask")
+    return out
+
+
+def philox_normal(shape, rng_state: torch.Tensor, stream_id: int = 1, advance: bool = True,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    _chk(rng_state, "rng_state", torch.int64)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=rng_state.device)
+    _lib.check(lib.mmvae_philox_normal(out.numel(), _ptr(out), _ptr(rng_state), stream_id, int(advance), _stream()),
+               "mmvae_philox_normal")
+    return out
+
+
+def axpby(alpha: float, x: torch.Tensor, beta: float, y: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _chk(x, "x"), _chk(y, "y")
+    if not (x.is_contiguous() and y.is_contiguous()) or x.numel() != y.numel():
+        raise ValueError("axpby needs contiguous same-size tensors")
+    _lib.check(lib.mmvae_axpby(x.numel(), float(alpha), _ptr(x), float(beta), _ptr(y), _stream()), "mmvae_axpby")
+    return y
+
+
+def scale_rows(x: torch.Tensor, row_scale: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    _chk(x, "x"), _chk(row_scale, "row_scale")
+    B, N, ldx = _mat(x, "x")
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mmvae_scale_rows(B, N, _ptr(x), ldx, _ptr(row_scale), _ptr(out), _mat(out, "out")[2], _stream()),
+               "mmvae_scale_rows")
+    return out
