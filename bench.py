@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: cells/sec through one MMVAE training step (BASELINE.json metric), on N MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = zero_grad, forward, ELBO, [adversarial D/G phases], backward, global-norm clip, Adam for the shared VAE and
+the active expert, on a synthetic batch that is already resident in HBM.  Modalities alternate round-robin on a fixed,
+rank-synchronous schedule.  N > 1: data parallel over cells (weak scaling: per-GPU batch fixed), gradients averaged
+with RCCL all-reduce over the flat gradient arenas.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c2", help="BASELINE config: c1..c5 (c2 = the configuration the metric is quoted on)")
+    ap.add_argument("--no-engine", action="store_true", help="module (autograd) path instead of the captured engine")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def time_dominant_kernel(cfg, device, iters=20):
+    """Roofline leg: the dominant kernel of the step -- the fp32 MFMA weight-gradient GEMM of a G-wide layer,
+    dW[1024, G] = dY^T[1024, B] . X[B, G] (TN layout) -- launched on the current stream with HIP events around each
+    launch.  Returns (avg seconds per launch, algorithmic FLOPs per launch)."""
+    from mmvae_amd import ops
+
+    B, G, H1 = cfg["batch"], max(cfg["experts"].values()), 1024
+    g = torch.Generator(device=device).manual_seed(1)
+    dY = torch.randn(B, H1, device=device, generator=g)
+    X = torch.randn(B, G, device=device, generator=g)
+    dW = torch.empty(H1, G, device=device)
+    for _ in range(3):
+        ops.gemm(ops.GEMM_TN, dY, X, out=dW, splitk=1)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in evs:
+        s.record()
+        ops.gemm(ops.GEMM_TN, dY, X, out=dW, splitk=1)
+        e.record()
+    torch.cuda.synchronize()
+    t = sum(s.elapsed_time(e) for s, e in evs) / iters * 1e-3
+    return t, 2.0 * H1 * G * B
+
+
+def cpu_baseline(cfg, seconds):
+    """The oracle (CPU restatement of the reference step, checked against the reference's golden vectors) timed on the
+    host cores of this box on a bounded sample of the same workload."""
+    from oracle import mmvae_oracle as O
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    B, K = cfg["batch"], cfg["K"]
+    spec = O.ModelSpec(
+        experts={eid: (O.FCSpec.make([G, 1024, 512], dropout_rate=0.1, use_batch_norm=True, relu=True),
+                       O.FCSpec.make([512, 1024, G], relu=True)) for eid, G in cfg["experts"].items()},
+        vae_encoder=O.FCSpec.make([512, 256], use_batch_norm=True, relu=True, return_hidden=True),
+        vae_decoder=O.FCSpec.make([128, 256, 512], relu=True), latent_dim=128)
+    hp = O.HParams()
+    sd = O.init_state(spec, seed=0)
+    opt_state = {}
+    eids = list(cfg["experts"].keys())
+    xs = {eid: O.synthetic_counts(B, G, seed=1234 + i) for i, (eid, G) in enumerate(cfg["experts"].items())}
+    g = torch.Generator().manual_seed(7)
+
+    def one(i):
+        nonlocal sd
+        eid = eids[i % len(eids)]
+        eps = torch.randn((K, B, 128) if K > 1 else (B, 128), generator=g)
+        masks = {f"experts.{eid}.encoder.fc_layers.0.dr": (torch.rand(B, 1024, generator=g) >= 0.1),
+                 f"experts.{eid}.encoder.fc_layers.1.dr": (torch.rand(B, 512, generator=g) >= 0.1)}
+        _, sd = O.train_step(spec, sd, opt_state, xs[eid], eid, eps, masks, None, 1.0, hp)
+
+    one(0)
+    one(1)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one(n)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 200:
+            break
+    return {"value": B * n / el, "unit": "cells/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} training steps of the same workload (B={B}, K={K}, modalities alternating) in {el:.1f} s, "
+                      f"torch {torch.__version__} CPU fp32"}
+
+
+def main():
+    a = parse()
+    from mmvae_amd import dist as mdist, synthetic
+
+    world = mdist.init_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    rank = mdist.rank()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    cfg = synthetic.CONFIGS[a.config]
+    B, K = cfg["batch"], cfg["K"]
+
+    model = synthetic.build_model(cfg["experts"], adversarial=cfg["adversarial"], n_samples=K,
+                                  use_engine=not a.no_engine, seed=0).to(device)
+    model.train()
+    model.trainer.set_stage("training")
+    model.optimizers()
+    mdist.broadcast_parameters(model)
+    mdist.attach(model)
+
+    eids = list(cfg["experts"].keys())
+    n_res = 2  # resident batches per modality
+    data = {}
+    for i, (eid, G) in enumerate(cfg["experts"].items()):
+        data[eid] = [(synthetic.synthetic_counts(B, G, seed=1234 + 97 * i + 13 * j + 1000 * rank, device=device),
+                      synthetic.synthetic_metadata(B, seed=5 + j + 1000 * rank)) for j in range(n_res)]
+
+    def step(i):
+        eid = eids[i % len(eids)]  # rank-synchronous round-robin schedule
+        x, meta = data[eid][(i // len(eids)) % n_res]
+        model.training_step((x, meta, eid), i)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    sync()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el = float(t)
+    loss = {k: float(v) for k, v in model.logged.items() if k.startswith(("loss/", "recon_loss/", "kl_loss/"))}
+
+    if rank == 0:
+        G = max(cfg["experts"].values())
+        cells_per_s = B * world * a.steps / el
+        out = {
+            "metric": "cells/sec per MMVAE train step", "value": cells_per_s, "unit": "cells/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.config}: {len(eids)}-modality MMVAE train step, {G} genes each, latent 128, "
+                                   f"K={K}, batch {B}/GPU, adversarial={cfg['adversarial']}",
+                       "global_batch": B * world, "parallelism": f"dp{world}",
+                       "path": "module" if (a.no_engine or not model._engine) else "engine(hipGraph)"},
+            "step_flops_per_cell": synthetic.flops_per_cell(G, K),
+            "step_tflops": synthetic.flops_per_cell(G, K) * cells_per_s / world / 1e12,
+            "last_losses": loss,
+        }
+        tk, fl = time_dominant_kernel(cfg, device)
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel<TN,128x128> (dW of a G-wide layer)",
+                           "achieved": fl / tk / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": fl / tk / 157.3e12,
+                           "traffic": None, "us_per_launch": tk * 1e6, "flops_per_launch": fl}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

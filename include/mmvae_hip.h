@@ -151,7 +151,7 @@ int mmvae_layernorm_bwd(int B, int N, const float* dy, int64_t lddy, const float
  *           (cmmvae_model.py:170-171).
  *   v = exp(a) + var_eps ; s = sqrt(v) ; z[k,b,:] = mu + s * eps[k,b,:]      (k < K samples; K = 1 in the reference)
  *   kl_row[b] = sum_j 0.5 (s^2 + mu^2 - 1 - log(s^2))
- *   stat_row[b] = {sum_j mu, sum_j s^2}                                    (optional, [B,2])
+ *   stat_row[0,b] = sum_j mu ; stat_row[1,b] = sum_j s^2                  (optional, [2,B])
  * One wavefront per cell; the latent axis is reduced with wavefront shuffles.
  * ------------------------------------------------------------------------------------------------------------ */
 int mmvae_reparam_kl_fwd(int B, int Z, int K, const float* mu, const float* a_raw, const float* eps, float var_eps,
@@ -192,11 +192,13 @@ int mmvae_elbo_finalize(int B, int K, int T, const float* se_part, const float* 
 /* ------------------------------------------------------------------------------------------------------------
  * Adversarial heads: CrossEntropyLoss(reduction="sum") forward + gradient (k11)
  * replaces: cmmvae_model.py:54,85 (nn.CrossEntropyLoss(reduction="sum") on Adversarial head logits)
- *   loss_out[0] (+)= sum_b (logsumexp(l_b) - l_b[y_b]) ; dlogits = gscale * (softmax(l_b) - onehot(y_b))
+ *   loss_rows[b] = logsumexp(l_b) - l_b[y_b] ; dlogits = gscale * (softmax(l_b) - onehot(y_b)),
+ *   gscale = gscale_host * (gscale_dev ? *gscale_dev : 1)
  * Gradient reversal (components.py:889-899) is a sign on the dx GEMM alpha, not a kernel.
  * ------------------------------------------------------------------------------------------------------------ */
 int mmvae_cross_entropy_sum(int B, int C, const float* logits, int64_t ld, const int64_t* labels, float* loss_rows,
-                            float* dlogits, int64_t ldd, float gscale, mmvae_stream_t stream);
+                            float* dlogits, int64_t ldd, const float* gscale_dev, float gscale_host,
+                            mmvae_stream_t stream);
 /* sums n floats in fixed order (fp64 accumulate) into out[0] (+= if accumulate). Used for loss_rows, se_row. */
 int mmvae_sum_f32(int64_t n, const float* v, float* out, int accumulate, mmvae_stream_t stream);
 
@@ -208,18 +210,21 @@ int mmvae_sum_f32(int64_t n, const float* v, float* out, int accumulate, mmvae_s
  *
  * mmvae_grad_sqnorm:   partial[i] = sum of squares of chunk i (fixed chunking -> reproducible); needs
  *                      mmvae_sqnorm_partials(n) floats.
- * mmvae_adam_prepare:  single block.  state[0] = step (incremented here), then
- *                      state[1] = total grad norm (pre-clip), state[2] = clip coefficient min(1, max_norm/(norm+1e-6))
- *                      (1 if max_norm <= 0), state[3] = 1 - beta1^step, state[4] = 1 - beta2^step.
+ * mmvae_adam_prepare:  single block.  flags & MMVAE_PREPARE_NORM: state[1] = total grad norm (pre-clip) from the
+ *                      partials (else the stored norm is kept); flags & MMVAE_PREPARE_ADVANCE: state[0] (step) += 1.
+ *                      Always: state[2] = clip coefficient min(1, max_norm/(norm+1e-6)) (1 if max_norm <= 0),
+ *                      state[3] = 1 - beta1^step, state[4] = 1 - beta2^step.
  *                      grad_scale multiplies the gradients first (DDP averaging: 1/world_size).
  * mmvae_adam_step:     g = clip*grad_scale*grad + wd*p ; m += (1-b1)(g-m) ; v = b2 v + (1-b2) g^2 ;
  *                      p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)            (torch.optim.Adam, amsgrad=False)
  * ------------------------------------------------------------------------------------------------------------ */
 #define MMVAE_ADAM_STATE_FLOATS 8
+#define MMVAE_PREPARE_NORM 1u
+#define MMVAE_PREPARE_ADVANCE 2u
 int64_t mmvae_sqnorm_partials(int64_t n);
 int mmvae_grad_sqnorm(int64_t n, const float* grad, float* partials, mmvae_stream_t stream);
 int mmvae_adam_prepare(int64_t n_partials, const float* partials, float max_norm, float grad_scale, float beta1,
-                       float beta2, float* state, mmvae_stream_t stream);
+                       float beta2, float* state, unsigned flags, mmvae_stream_t stream);
 int mmvae_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* state,
                     float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                     mmvae_stream_t stream);

@@ -18,6 +18,7 @@ _ERR_NAMES = {1: "MMVAE_ERR_ARG", 2: "MMVAE_ERR_LAUNCH", 3: "MMVAE_ERR_WORKSPACE
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 GEMM_RELU, GEMM_ACCUMULATE, GEMM_RAW_SLABS = 1, 2, 4
 ADAM_STATE_FLOATS = 8
+PREPARE_NORM, PREPARE_ADVANCE = 1, 2
 
 _p = C.c_void_p
 _i = C.c_int
@@ -67,11 +68,11 @@ PROTOTYPES = {
     "mmvae_reparam_kl_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p]),
     "mmvae_mse_sum_fwd_bwd": (_i, [_i, _i, _p, _l, _p, _l, _p, _p, _l, _p, _f, _p]),
     "mmvae_elbo_finalize": (_i, [_i, _i, _i, _p, _p, _p, _i, _p, _f, _p, _p, _p]),
-    "mmvae_cross_entropy_sum": (_i, [_i, _i, _p, _l, _p, _p, _p, _l, _f, _p]),
+    "mmvae_cross_entropy_sum": (_i, [_i, _i, _p, _l, _p, _p, _p, _l, _p, _f, _p]),
     "mmvae_sum_f32": (_i, [_l, _p, _p, _i, _p]),
     "mmvae_sqnorm_partials": (_l, [_l]),
     "mmvae_grad_sqnorm": (_i, [_l, _p, _p, _p]),
-    "mmvae_adam_prepare": (_i, [_l, _p, _f, _f, _f, _f, _p, _p]),
+    "mmvae_adam_prepare": (_i, [_l, _p, _f, _f, _f, _f, _p, _u, _p]),
     "mmvae_adam_step": (_i, [_l, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _f, _p]),
     "mmvae_philox_keep_mask": (_i, [_l, _f, _p, _p, _u64, _i, _p]),
     "mmvae_philox_normal": (_i, [_l, _p, _p, _u64, _i, _p]),

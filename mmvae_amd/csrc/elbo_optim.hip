@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(int B, int Z, int K
     if (lane == 0) {
         if (kl_row) kl_row[b] = kl;
         if (stat_row) {
-            stat_row[2 * b] = smu;
-            stat_row[2 * b + 1] = svar;
+            stat_row[b] = smu;
+            stat_row[B + b] = svar;
         }
     }
 }
@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(int B, int K, int T,
         }
         if (kl_row) kl += (double)kl_row[b];
         if (stat_row) {
-            smu += (double)stat_row[2 * b];
-            svar += (double)stat_row[2 * b + 1];
+            smu += (double)stat_row[b];
+            svar += (double)stat_row[B + b];
         }
     }
     red[0][tid] = recon;
@@ -176,7 +176,9 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(int B, int K, int T,
 // ---------------------------------------------------------------- cross entropy (sum) + gradient, one wavefront per row
 __global__ __launch_bounds__(256) void ce_rows_kernel(int B, int C, const float* __restrict__ logits, int64_t ld,
                                                       const int64_t* __restrict__ labels, float* __restrict__ loss_rows,
-                                                      float* __restrict__ dlogits, int64_t ldd, float gscale) {
+                                                      float* __restrict__ dlogits, int64_t ldd,
+                                                      const float* __restrict__ gscale_dev, float gscale_host) {
+    const float gscale = gscale_host * (gscale_dev ? *gscale_dev : 1.f);
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -249,17 +251,22 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(int64_t n, const float* __r
 
 __global__ __launch_bounds__(256) void adam_prepare_kernel(int64_t np, const float* __restrict__ partials,
                                                            float max_norm, float grad_scale, float beta1, float beta2,
-                                                           float* __restrict__ state) {
+                                                           float* __restrict__ state, unsigned flags) {
     __shared__ double red[256];
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < np; i += 256) s += (double)partials[i];
+    if (flags & MMVAE_PREPARE_NORM)
+        for (int64_t i = threadIdx.x; i < np; i += 256) s += (double)partials[i];
     red[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < 256; ++i) t += red[i];
-        const float norm = (float)(sqrt(t) * (double)fabsf(grad_scale));
-        const float step = state[0] + 1.f;
+        float norm = state[1];
+        if (flags & MMVAE_PREPARE_NORM) {
+            double t = 0.0;
+            for (int i = 0; i < 256; ++i) t += red[i];
+            norm = (float)(sqrt(t) * (double)fabsf(grad_scale));
+        }
+        float step = state[0];
+        if (flags & MMVAE_PREPARE_ADVANCE) step += 1.f;
         state[0] = step;
         state[1] = norm;
         float clip = 1.f;
@@ -459,13 +466,13 @@ extern "C" int mmvae_elbo_finalize(int B, int K, int T, const float* se_part, co
 }
 
 extern "C" int mmvae_cross_entropy_sum(int B, int C, const float* logits, int64_t ld, const int64_t* labels,
-                                       float* loss_rows, float* dlogits, int64_t ldd, float gscale,
-                                       mmvae_stream_t stream) {
+                                       float* loss_rows, float* dlogits, int64_t ldd, const float* gscale_dev,
+                                       float gscale_host, mmvae_stream_t stream) {
     if (B <= 0 || C <= 0 || !logits || !labels || ld < C) return MMVAE_ERR_ARG;
     if (!loss_rows && !dlogits) return MMVAE_ERR_ARG;
     if (dlogits && ldd < C) return MMVAE_ERR_ARG;
     hipLaunchKernelGGL(ce_rows_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, C, logits, ld,
-                       labels, loss_rows, dlogits, ldd, gscale);
+                       labels, loss_rows, dlogits, ldd, gscale_dev, gscale_host);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }
@@ -488,10 +495,11 @@ extern "C" int mmvae_grad_sqnorm(int64_t n, const float* grad, float* partials, 
 }
 
 extern "C" int mmvae_adam_prepare(int64_t n_partials, const float* partials, float max_norm, float grad_scale,
-                                  float beta1, float beta2, float* state, mmvae_stream_t stream) {
-    if (n_partials < 0 || (n_partials > 0 && !partials) || !state) return MMVAE_ERR_ARG;
+                                  float beta1, float beta2, float* state, unsigned flags, mmvae_stream_t stream) {
+    if (n_partials < 0 || !state) return MMVAE_ERR_ARG;
+    if ((flags & MMVAE_PREPARE_NORM) && n_partials > 0 && !partials) return MMVAE_ERR_ARG;
     hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n_partials, partials, max_norm,
-                       grad_scale, beta1, beta2, state);
+                       grad_scale, beta1, beta2, state, flags);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }

@@ -1,0 +1,92 @@
+"""Data parallelism over the batch axis: one process per GPU, `torch.distributed` (backend "nccl" == RCCL on ROCm, over
+xGMI).  The reference has no distributed code (`strategy: auto`, never exercised); this is the build's own.
+
+Cells are independent, so the only exchange step is the gradient all-reduce.  Because every optimiser owns ONE
+contiguous gradient arena (mmvae_amd.optim.ParamArena), the all-reduce is a few large contiguous buckets instead of
+one call per tensor.  Semantics = Lightning DDP: gradients are averaged over ranks (sum all-reduce, then the 1/world
+factor is folded into the fused clip+Adam kernel as `grad_scale`, so no extra pass over the gradients exists).
+BatchNorm statistics stay per-rank (reference `sync_batchnorm: false`, configs/trainer/config.yaml:77).
+All ranks must train the same expert on a step (rank-synchronous schedule) so the same arenas are live everywhere.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+BUCKET_BYTES = 64 << 20  # xGMI ring all-reduce is per-link bound: few, large messages
+
+
+def init_from_env(backend: Optional[str] = None) -> int:
+    """Initialise the default process group from torchrun's env (RANK / WORLD_SIZE / MASTER_*).  Returns world size."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend=backend)
+    return world
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def bucket_ranges(numel: int, bucket_bytes: int = BUCKET_BYTES) -> List[range]:
+    per = max(bucket_bytes // 4, 1)
+    return [range(s, min(s + per, numel)) for s in range(0, numel, per)]
+
+
+class GradAllReducer:
+    """Sum-all-reduces a flat gradient arena in contiguous buckets, optionally on a side stream so that it overlaps
+    with whatever the compute stream still has to do (remaining backward GEMMs / the other optimiser's update)."""
+
+    def __init__(self, group=None, bucket_bytes: int = BUCKET_BYTES, side_stream: bool = True):
+        self.group = group
+        self.bucket_bytes = bucket_bytes
+        self.stream = torch.cuda.Stream() if (side_stream and torch.cuda.is_available()) else None
+        self._pending: list = []
+
+    def launch(self, flat_grad: torch.Tensor) -> None:
+        """Enqueue the all-reduce of `flat_grad` (in place).  Returns immediately; call wait() before reading it."""
+        if world_size() == 1:
+            return
+        if self.stream is not None and flat_grad.is_cuda:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                for r in bucket_ranges(flat_grad.numel(), self.bucket_bytes):
+                    dist.all_reduce(flat_grad[r.start:r.stop], op=dist.ReduceOp.SUM, group=self.group)
+            self._pending.append(flat_grad)
+        else:
+            for r in bucket_ranges(flat_grad.numel(), self.bucket_bytes):
+                dist.all_reduce(flat_grad[r.start:r.stop], op=dist.ReduceOp.SUM, group=self.group)
+
+    def wait(self) -> None:
+        if self._pending and self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self._pending.clear()
+
+
+def attach(model, reducer: Optional[GradAllReducer] = None) -> GradAllReducer:
+    """Make every HipAdam of `model` average its gradients over the default process group."""
+    reducer = reducer or GradAllReducer()
+    w = world_size()
+    for opt in model.optimizers():
+        opt.reducer = reducer if w > 1 else None
+        opt.grad_scale = 1.0 / w
+    return reducer
+
+
+def broadcast_parameters(model, src: int = 0) -> None:
+    """Replicate rank `src`'s parameters and buffers (all ranks start from identical state)."""
+    if world_size() == 1:
+        return
+    for t in list(model.parameters()) + list(model.buffers()):
+        dist.broadcast(t.data, src=src)

@@ -1,0 +1,161 @@
+"""Trainer-facing base class of the mirror.
+
+The reference's `BaseModel` is a `lightning.pytorch.LightningModule` (cmmvae/models/base_model.py:52-355).  Lightning
+is an optional dependency here: when importable, this class derives from it and plugs into a stock Lightning
+Trainer; otherwise it provides the small part of the LightningModule surface the MMVAE step uses (log / log_dict /
+optimizers / manual_backward / clip_gradients / trainer stage flags) so mmvae_amd.trainer.Trainer can drive it.
+
+Logged scalar names are part of the drop-in boundary (`{key}/{stage}/{expert}`, base_model.py:265-297).
+"""
+from __future__ import annotations
+
+from typing import Iterable, Literal, Optional, Union
+
+import torch
+import torch.nn as nn
+
+from ..modules.base import KLAnnealingFn
+from ..modules.base import init as _init  # noqa: F401  (module import keeps `init` reachable like the reference)
+from ..modules.base.init import he_init_weights
+
+try:  # pragma: no cover - Lightning is not installed in the build image
+    import lightning.pytorch as pl
+
+    _Base = pl.LightningModule
+    HAVE_LIGHTNING = True
+except Exception:  # noqa: BLE001
+    _Base = nn.Module
+    HAVE_LIGHTNING = False
+
+
+def tag_log_dict(log_dict: dict, tags: Iterable[str] = (), sep: str = "/",
+                 key_pos: Union[Literal["first"], Literal["last"]] = "first") -> dict:
+    """{key: v} -> {"key/tag1/tag2": v} (key_pos "first") or {"tag1/tag2/key": v} ("last"); base_model.py:14-49."""
+    if key_pos not in ("first", "last"):
+        raise ValueError(f"Key position {key_pos} is not supported!")
+    tags_str = sep.join(tags)
+    if not tags_str:
+        return dict(log_dict)
+    if key_pos == "first":
+        return {f"{k}{sep}{tags_str}": v for k, v in log_dict.items()}
+    return {f"{tags_str}{sep}{k}": v for k, v in log_dict.items()}
+
+
+class _TrainerStub:
+    """Stage flags a LightningModule reads from `self.trainer` (base_model.py:158-176)."""
+
+    def __init__(self):
+        self.training = True
+        self.validating = self.sanity_checking = self.predicting = self.testing = False
+        self.global_step = 0
+
+    def set_stage(self, stage: str) -> None:
+        self.training = stage == "training"
+        self.validating = stage == "validation"
+        self.testing = stage == "test"
+        self.predicting = stage == "prediction"
+        self.sanity_checking = stage == "sanity_checking"
+
+
+class BaseModel(_Base):
+    def __init__(self, record_gradients: bool = False, save_gradients_interval: int = 25,
+                 gradient_record_cap: int = 20, kl_annealing_fn: Optional[KLAnnealingFn] = None,
+                 predict_dir: str = "", predict_save_interval: int = 600, initial_save_index: int = -1,
+                 use_he_init_weights: bool = True):
+        super().__init__()
+        self.record_gradients = record_gradients
+        self.save_gradients_interval = save_gradients_interval
+        self.gradient_record_cap = gradient_record_cap
+        self.predict_dir = predict_dir
+        self.predict_save_interval = predict_save_interval
+        self._curr_save_idx = initial_save_index
+        self._running_predictions = []
+        self.kl_annealing_fn = kl_annealing_fn or KLAnnealingFn(1.0)
+        self._use_he_init_weights = use_he_init_weights
+        if not HAVE_LIGHTNING:
+            self._trainer = _TrainerStub()
+            self._optimizers = None
+            self.automatic_optimization = True
+            self.logged: dict = {}  # name -> latest value (device scalars are kept as tensors: no host sync)
+
+    # ------------------------------------------------------------------ LightningModule surface (stand-alone mode)
+    if not HAVE_LIGHTNING:
+
+        @property
+        def trainer(self):
+            return self._trainer
+
+        @trainer.setter
+        def trainer(self, t):
+            self._trainer = t
+
+        def log(self, name, value, **kwargs):
+            self.logged[name] = value
+
+        def log_dict(self, d, **kwargs):
+            self.logged.update(d)
+
+        def optimizers(self):
+            if self._optimizers is None:
+                self._optimizers = self.configure_optimizers()
+            return self._optimizers
+
+        def manual_backward(self, loss, *args, **kwargs):
+            loss.backward(*args, **kwargs)
+
+        def clip_gradients(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm=None):
+            if gradient_clip_val is None:
+                return
+            if (gradient_clip_algorithm or "norm") != "norm":
+                raise NotImplementedError("only gradient_clip_algorithm='norm' is on the HIP path")
+            if hasattr(optimizer, "set_clip"):
+                optimizer.set_clip(float(gradient_clip_val))  # fused into HipAdam.step()
+            else:
+                params = [p for g in optimizer.param_groups for p in g["params"]]
+                torch.nn.utils.clip_grad_norm_(params, float(gradient_clip_val))
+
+        @property
+        def device(self):
+            try:
+                return next(self.parameters()).device
+            except StopIteration:
+                return torch.device("cpu")
+
+    # ------------------------------------------------------------------ shared helpers (same names as the reference)
+    def init_weights(self):
+        if self._use_he_init_weights:
+            he_init_weights(self)
+
+    @property
+    def stage_name(self) -> str:
+        t = self.trainer
+        for flag, name in (("training", "training"), ("validating", "validation"),
+                           ("sanity_checking", "sanity_checking"), ("predicting", "prediction"),
+                           ("testing", "test")):
+            if getattr(t, flag, False):
+                return name
+        return ""
+
+    def log_gradient_norms(self, optimizer_dict, tag_prefix="grad_norms"):
+        """Global L2 norm of each optimiser's gradients (base_model.py:111-123).  The reference syncs once per
+        parameter (`.item()`); HipAdam computes the norm in its fused pass and it is logged as a device scalar."""
+        for name, optimizer in optimizer_dict.items():
+            if isinstance(optimizer, dict):
+                self.log_gradient_norms(optimizer, f"{tag_prefix}/{name}")
+            elif hasattr(optimizer, "compute_grad_norm"):
+                self.log(f"{tag_prefix}/{name}", optimizer.compute_grad_norm())
+            else:
+                sq = 0.0
+                for group in optimizer.param_groups:
+                    for p in group["params"]:
+                        if p.grad is not None:
+                            sq += float(p.grad.data.norm(2)) ** 2
+                self.log(f"{tag_prefix}/{name}", sq ** 0.5)
+
+    def auto_log(self, log_dict: dict, tags: Iterable[str] = (), sep: str = "/",
+                 key_pos: Literal["first", "last"] = "first", log_sanity_checking: bool = False):
+        t = self.trainer
+        if t is not None and getattr(t, "sanity_checking", False) and not log_sanity_checking:
+            return
+        self.log_dict(tag_log_dict(log_dict, tags, sep, key_pos), on_step=bool(getattr(t, "training", True)),
+                      on_epoch=True, logger=True)

@@ -302,7 +302,7 @@ def layernorm_bwd(dy: torch.Tensor, y: torch.Tensor, invstd: torch.Tensor):
 
 def reparam_kl_fwd(mu: torch.Tensor, a_raw: torch.Tensor, eps: Optional[torch.Tensor], var_eps: float = 1e-4,
                    want_stats: bool = True):
-    """mu, a_raw [B,Z]; eps [K,B,Z] or [B,Z] or None.  Returns (std [B,Z], z [K,B,Z]|None, kl_row [B], stat_row [B,2]|None)."""
+    """mu, a_raw [B,Z]; eps [K,B,Z] or [B,Z] or None.  Returns (std [B,Z], z [K,B,Z]|None, kl_row [B], stat_row [2,B]|None)."""
     lib = _lib.load()
     _chk(mu, "mu"), _chk(a_raw, "a_raw"), _chk(eps, "eps")
     if not (mu.is_contiguous() and a_raw.is_contiguous()):
@@ -319,7 +319,7 @@ def reparam_kl_fwd(mu: torch.Tensor, a_raw: torch.Tensor, eps: Optional[torch.Te
         z = torch.empty((K, B, Z) if eps.dim() == 3 else (B, Z), dtype=torch.float32, device=mu.device)
     std = torch.empty_like(mu)
     kl_row = torch.empty(B, dtype=torch.float32, device=mu.device)
-    stat = torch.empty((B, 2), dtype=torch.float32, device=mu.device) if want_stats else None
+    stat = torch.empty((2, B), dtype=torch.float32, device=mu.device) if want_stats else None
     rc = lib.mmvae_reparam_kl_fwd(B, Z, K, _ptr(mu), _ptr(a_raw), _ptr(eps), var_eps, _ptr(std), _ptr(z), _ptr(kl_row),
                                   _ptr(stat), _stream())
     _lib.check(rc, "mmvae_reparam_kl_fwd")
@@ -382,7 +382,8 @@ def elbo_finalize(se_part: torch.Tensor, kl_row, stat_row, *, B: int, K: int = 1
     return out, w
 
 
-def cross_entropy_sum(logits: torch.Tensor, labels: torch.Tensor, *, want_grad: bool = True, gscale: float = 1.0):
+def cross_entropy_sum(logits: torch.Tensor, labels: torch.Tensor, *, want_grad: bool = True, gscale: float = 1.0,
+                      gscale_dev: Optional[torch.Tensor] = None):
     """Returns (loss_rows [B], dlogits [B,C] | None)."""
     lib = _lib.load()
     _chk(logits, "logits"), _chk(labels, "labels", torch.int64)
@@ -391,8 +392,9 @@ def cross_entropy_sum(logits: torch.Tensor, labels: torch.Tensor, *, want_grad: 
         raise ValueError("labels must be contiguous [B] int64")
     rows = torch.empty(B, dtype=torch.float32, device=logits.device)
     dl = torch.empty((B, Cn), dtype=torch.float32, device=logits.device) if want_grad else None
-    rc = lib.mmvae_cross_entropy_sum(B, Cn, _ptr(logits), ld, _ptr(labels), _ptr(rows), _ptr(dl), Cn, float(gscale),
-                                     _stream())
+    _chk(gscale_dev, "gscale_dev")
+    rc = lib.mmvae_cross_entropy_sum(B, Cn, _ptr(logits), ld, _ptr(labels), _ptr(rows), _ptr(dl), Cn,
+                                     _ptr(gscale_dev), float(gscale), _stream())
     _lib.check(rc, "mmvae_cross_entropy_sum")
     return rows, dl
 
@@ -413,8 +415,9 @@ def sqnorm_partials(n: int) -> int:
 
 
 def clip_adam_step(param, grad, exp_avg, exp_avg_sq, state, partials, *, lr=5e-3, beta1=0.9, beta2=0.999, eps=1e-8,
-                   weight_decay=1e-6, max_norm=0.0, grad_scale=1.0, do_norm=True, do_step=True):
-    """Global-norm clip + Adam over one flat arena.  `state`: float32[8] device tensor (step, norm, clip, bc1, bc2)."""
+                   weight_decay=1e-6, max_norm=0.0, grad_scale=1.0, do_norm=True, do_step=True, advance=True):
+    """Global-norm clip + Adam over one flat arena.  `state`: float32[8] device tensor (step, norm, clip, bc1, bc2).
+    do_norm: recompute the gradient norm; advance: increment the step counter; do_step: apply the update."""
     lib = _lib.load()
     for n_, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq),
                   ("state", state), ("partials", partials)):
@@ -425,13 +428,14 @@ def clip_adam_step(param, grad, exp_avg, exp_avg_sq, state, partials, *, lr=5e-3
     if grad.numel() != n or exp_avg.numel() != n or exp_avg_sq.numel() != n or state.numel() < 8:
         raise ValueError("arena sizes")
     s = _stream()
+    npart = lib.mmvae_sqnorm_partials(n)
     if do_norm:
-        npart = lib.mmvae_sqnorm_partials(n)
         if partials.numel() < npart:
             raise ValueError("partials too small")
         _lib.check(lib.mmvae_grad_sqnorm(n, _ptr(grad), _ptr(partials), s), "mmvae_grad_sqnorm")
-        _lib.check(lib.mmvae_adam_prepare(npart, _ptr(partials), float(max_norm), float(grad_scale), beta1, beta2,
-                                          _ptr(state), s), "mmvae_adam_prepare")
+    flags = (_lib.PREPARE_NORM if do_norm else 0) | (_lib.PREPARE_ADVANCE if (advance and do_step) else 0)
+    _lib.check(lib.mmvae_adam_prepare(npart, _ptr(partials), float(max_norm), float(grad_scale), beta1, beta2,
+                                      _ptr(state), flags, s), "mmvae_adam_prepare")
     if do_step:
         _lib.check(lib.mmvae_adam_step(n, _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(state), lr,
                                        beta1, beta2, eps, weight_decay, float(grad_scale), s), "mmvae_adam_step")

@@ -1,0 +1,181 @@
+"""Flat-arena Adam with fused global-norm clipping (k12 + k13).
+
+Replaces `torch.optim.Adam(module.parameters(), lr=5e-3, weight_decay=1e-6)` + Lightning `clip_gradients(opt, 10,
+"norm")` of the reference (models/cmmvae_model.py:299-324, :126-131, :203-213).
+
+MI355X-first layout: all parameters of one optimiser live contiguously in ONE fp32 arena in HBM (each tensor padded to
+16 B), with parallel arenas for gradients, exp_avg and exp_avg_sq.  `nn.Parameter.data` of every parameter is re-pointed
+at its slice, so modules, checkpoints and kernels all see the same memory, and:
+  * clip + Adam over a whole optimiser = 3 launches over one contiguous range (norm partials, prepare, update), instead
+    of ~10 tensors x several foreach launches;
+  * the DDP gradient all-reduce is a handful of large contiguous buckets of the gradient arena (mmvae_amd.dist).
+Gradients written by autograd into separate tensors (module path) are gathered into the arena with D2D copies at step();
+the graph-captured engine writes its GEMM outputs straight into the arena.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional
+
+import torch
+
+from . import backend, ops
+
+
+def _pad4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class ParamArena:
+    """Contiguous storage for a list of parameters (+ grads and Adam moments).  Device (HIP) or CPU plumbing."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params]
+        if not self.params:
+            raise ValueError("empty parameter list")
+        dev = self.params[0].device
+        if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
+            raise ValueError("all parameters of an arena must be fp32 on one device")
+        self.device = dev
+        self.offsets: List[int] = []
+        n = 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += _pad4(p.numel())
+        self.numel = n
+        self.data = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, off in zip(self.params, self.offsets):
+            view = self.data[off:off + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+
+    def view(self, arena: torch.Tensor, i: int) -> torch.Tensor:
+        p, off = self.params[i], self.offsets[i]
+        return arena[off:off + p.numel()].view(p.shape)
+
+    def grad_view(self, i: int) -> torch.Tensor:
+        return self.view(self.grad, i)
+
+    def gather_grads(self) -> None:
+        """Bring autograd-produced .grad tensors into the gradient arena (D2D copies; no-ops for arena views)."""
+        for i, p in enumerate(self.params):
+            gv = self.grad_view(i)
+            if p.grad is None:
+                gv.zero_()
+            elif p.grad.data_ptr() != gv.data_ptr():
+                gv.copy_(p.grad)
+
+
+class HipAdam(torch.optim.Optimizer):
+    """Adam (coupled L2 weight decay, amsgrad=False; identical update rule to torch.optim.Adam) over a ParamArena,
+    with the gradient-norm clip fused in.  State (`step`, last pre-clip grad norm, clip coefficient) stays on device."""
+
+    def __init__(self, params, lr: float = 5e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-6,
+                 max_grad_norm: Optional[float] = None):
+        params = list(params)
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.arena = ParamArena(params)
+        self.max_grad_norm = max_grad_norm
+        self.grad_scale = 1.0  # 1 / world_size under DDP (gradient averaging)
+        self.reducer = None  # mmvae_amd.dist.GradAllReducer under DDP
+        self._hip = self.arena.device.type == "cuda"
+        if not self._hip and not backend.cpu_plumbing_enabled():
+            raise RuntimeError("HipAdam needs device parameters (or caller-enabled backend.cpu_plumbing())")
+        dev = self.arena.device
+        self.state_dev = torch.zeros(8, dtype=torch.float32, device=dev)  # step, norm, clip, bc1, bc2
+        if self._hip:
+            self.partials = torch.empty(max(ops.sqnorm_partials(self.arena.numel), 1), dtype=torch.float32, device=dev)
+
+    # ---- Lightning-style clipping hook: remembered, applied inside step()
+    def set_clip(self, max_norm: Optional[float]) -> None:
+        self.max_grad_norm = max_norm
+
+    @property
+    def grad_norm(self) -> torch.Tensor:
+        """Pre-clip global gradient norm of the last compute_norm()/step() (device scalar; no sync)."""
+        return self.state_dev[1]
+
+    @torch.no_grad()
+    def compute_grad_norm(self) -> torch.Tensor:
+        """Gather grads into the arena and compute their global L2 norm (device scalar).  step() reuses it."""
+        a = self.arena
+        a.gather_grads()
+        self._allreduce()
+        if self._hip:
+            b1, b2 = self.param_groups[0]["betas"]
+            ops.clip_adam_step(a.data, a.grad, a.exp_avg, a.exp_avg_sq, self.state_dev, self.partials, beta1=b1,
+                               beta2=b2, max_norm=self.max_grad_norm or 0.0, grad_scale=self.grad_scale,
+                               do_norm=True, do_step=False)
+        else:
+            self.state_dev[1] = (a.grad * self.grad_scale).norm()
+        self._norm_valid = True
+        return self.state_dev[1].clone()  # detached from the state word, which the next pass overwrites
+
+    def _allreduce(self) -> None:
+        if self.reducer is not None:
+            self.reducer.launch(self.arena.grad)
+            self.reducer.wait()
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        self._norm_valid = False
+        for p in self.arena.params:
+            p.grad = None
+        # the arena itself needs no clearing: every live gradient is overwritten before it is read
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closures are not used by the MMVAE trainer")
+        a = self.arena
+        reuse = getattr(self, "_norm_valid", False)
+        if not reuse:
+            a.gather_grads()
+            self._allreduce()
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        if self._hip:
+            ops.clip_adam_step(a.data, a.grad, a.exp_avg, a.exp_avg_sq, self.state_dev, self.partials, lr=g["lr"],
+                               beta1=b1, beta2=b2, eps=g["eps"], weight_decay=g["weight_decay"],
+                               max_norm=self.max_grad_norm or 0.0, grad_scale=self.grad_scale, do_norm=not reuse)
+        else:
+            self._step_cpu_plumbing(g, b1, b2)
+        self._norm_valid = False
+
+    def _step_cpu_plumbing(self, g, b1, b2):
+        a = self.arena
+        grad = a.grad * self.grad_scale
+        norm = grad.norm()
+        clip = 1.0
+        if self.max_grad_norm:
+            clip = min(1.0, float(self.max_grad_norm) / (float(norm) + 1e-6))
+        self.state_dev[0] += 1
+        t = float(self.state_dev[0])
+        self.state_dev[1], self.state_dev[2] = norm, clip
+        grad = grad * clip + g["weight_decay"] * a.data
+        a.exp_avg.lerp_(grad, 1 - b1)
+        a.exp_avg_sq.mul_(b2).addcmul_(grad, grad, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+        denom = a.exp_avg_sq.sqrt() / (bc2 ** 0.5) + g["eps"]
+        a.data.addcdiv_(a.exp_avg, denom, value=-g["lr"] / bc1)
+
+    # ---- checkpoint surface compatible with torch.optim.Adam's per-parameter state
+    def state_dict(self):
+        a = self.arena
+        st = {i: {"step": self.state_dev[0].detach().clone().cpu(), "exp_avg": a.view(a.exp_avg, i).clone(),
+                  "exp_avg_sq": a.view(a.exp_avg_sq, i).clone()} for i in range(len(a.params))}
+        return {"state": st, "param_groups": [{**{k: v for k, v in self.param_groups[0].items() if k != "params"},
+                                               "params": list(range(len(a.params)))}]}
+
+    def load_state_dict(self, sd):
+        a = self.arena
+        for i, s in sd["state"].items():
+            i = int(i)
+            a.view(a.exp_avg, i).copy_(s["exp_avg"])
+            a.view(a.exp_avg_sq, i).copy_(s["exp_avg_sq"])
+            self.state_dev[0] = float(s["step"])
+        for k, v in sd["param_groups"][0].items():
+            if k != "params":
+                self.param_groups[0][k] = v

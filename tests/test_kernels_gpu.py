@@ -1,0 +1,335 @@
+"""Per-kernel parity tests: every C-ABI entry point of libmmvae_hip.so against a CPU computation of the same math
+(fp64 matmuls / torch autograd on CPU).  These call THROUGH the C-ABI (mmvae_amd.ops -> ctypes -> .so).
+Tolerances: GEMM outputs rel-L2 <= 2e-6 vs fp64 (exact-f32 MFMA, one rounding per product); elementwise 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.helpers import rel_l2  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    from mmvae_amd import ops as _ops, _lib
+
+    lib = _lib.load()
+    assert lib.mmvae_abi_version() == 1
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ----------------------------------------------------------------------------------------------------------- GEMM
+def _asym(m, n):
+    """Asymmetric integer-valued matrix: catches row/col swaps and k-permutation mismatches exactly."""
+    i = torch.arange(m, dtype=torch.float32).unsqueeze(1)
+    j = torch.arange(n, dtype=torch.float32).unsqueeze(0)
+    return ((3 * i + 5 * j) % 7) - 3.0 + ((i * j) % 3)
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (64, 64, 64), (33, 47, 19), (200, 136, 100), (512, 256, 96)])
+def test_gemm_exact_integers(ops, layout, M, N, K):
+    a = _asym(M, K)
+    b = _asym(K, N) + 1.0
+    ref = a.double() @ b.double()
+    A = a if layout != 2 else a.t().contiguous()
+    Bm = b.t().contiguous() if layout == 0 else b
+    out = ops.gemm(layout, dev(A), dev(Bm))
+    assert torch.equal(out.cpu().double(), ref), f"max err {(out.cpu().double() - ref).abs().max()}"
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize(
+    "M,N,K,splitk",
+    [(512, 1024, 2000, 0), (512, 512, 1024, 0), (96, 257, 300, 1), (130, 70, 1000, 5), (512, 2000, 512, 0),
+     (1024, 1200, 512, 1), (64, 48, 33, 0), (8, 24, 64, 0)],
+)
+def test_gemm_random(ops, layout, M, N, K, splitk):
+    a, b = rnd(M, K, seed=1), rnd(K, N, seed=2)
+    bias = rnd(N, seed=3)
+    ref = a.double() @ b.double() + bias.double()
+    A = a if layout != 2 else a.t().contiguous()
+    Bm = b.t().contiguous() if layout == 0 else b
+    out = ops.gemm(layout, dev(A), dev(Bm), bias=dev(bias), splitk=splitk)
+    assert rel_l2(out, ref) < 2e-6
+    out = ops.gemm(layout, dev(A), dev(Bm), bias=dev(bias), relu=True, splitk=splitk)
+    assert rel_l2(out, ref.clamp_min(0)) < 2e-6
+    c0 = rnd(M, N, seed=4)
+    out = ops.gemm(layout, dev(A), dev(Bm), out=dev(c0), alpha=-0.5, accumulate=True, splitk=splitk)
+    assert rel_l2(out, -0.5 * (a.double() @ b.double()) + c0.double()) < 2e-6
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_gemm_unaligned_strides(ops, layout):
+    """Leading dimensions that are not multiples of 4 floats (e.g. 60530 / 52437-gene matrices)."""
+    M, N, K = 70, 45, 131
+    a, b = rnd(M, K, seed=5), rnd(K, N, seed=6)
+    ref = a.double() @ b.double()
+    A = a if layout != 2 else a.t().contiguous()
+    Bm = b.t().contiguous() if layout == 0 else b
+
+    def pad(t, extra):  # view with ld = cols + extra
+        buf = torch.zeros(t.shape[0], t.shape[1] + extra)
+        buf[:, : t.shape[1]] = t
+        return dev(buf)[:, : t.shape[1]]
+
+    out = ops.gemm(layout, pad(A, 3), pad(Bm, 1))
+    assert rel_l2(out, ref) < 2e-6
+    outbuf = torch.zeros(M, N + 5, device="cuda")
+    ops.gemm(layout, pad(A, 3), pad(Bm, 1), out=outbuf[:, :N])
+    assert rel_l2(outbuf[:, :N], ref) < 2e-6
+    assert float(outbuf[:, N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_gemm_raw_slabs(ops, layout):
+    M, N, K = 100, 72, 700
+    a, b = rnd(M, K, seed=7), rnd(K, N, seed=8)
+    A = a if layout != 2 else a.t().contiguous()
+    Bm = b.t().contiguous() if layout == 0 else b
+    slabs = ops.gemm_slabs(layout, dev(A), dev(Bm), splitk=6)
+    assert slabs.shape == (6, M, N)
+    assert rel_l2(slabs.sum(0), a.double() @ b.double()) < 2e-6
+
+
+@pytest.mark.parametrize("R,B,G,H", [(8, 8, 64, 48), (33, 33, 257, 72), (128, 128, 2000, 256), (66, 33, 131, 40)])
+def test_decoder_recon(ops, R, B, G, H):
+    h, W, bias = rnd(R, H, seed=1), rnd(G, H, seed=2, scale=0.2), rnd(G, seed=3, scale=0.1)
+    x = rnd(B, G, seed=4).abs()
+    P = h.double() @ W.double().t() + bias.double()
+    xh = P.clamp_min(0)
+    xx = x.double().repeat(R // B, 1)
+    d = xh - xx
+    xhat, dP, se_part = ops.decoder_recon(dev(h), dev(W), dev(bias), dev(x))
+    assert rel_l2(xhat, xh) < 2e-6
+    assert rel_l2(se_part.sum(0), (d * d).sum(1)) < 1e-5
+    # dP = 2 d 1[P>0]; entries with |P| within rounding of 0 may flip the mask -> compare where P is clearly signed
+    ref_dp = 2 * d * (P > 0)
+    clear = P.abs() > 1e-4
+    assert rel_l2(dP.cpu().double()[clear], ref_dp[clear]) < 1e-5
+    # optional outputs off
+    _, _, se2 = ops.decoder_recon(dev(h), dev(W), dev(bias), dev(x), want_xhat=False, want_dP=False)
+    assert torch.equal(se2, se_part)
+
+
+# --------------------------------------------------------------------------------------------------- FC epilogues
+@pytest.mark.parametrize("B,N,S", [(8, 48, 1), (33, 72, 3), (512, 1024, 4), (128, 100, 1)])
+@pytest.mark.parametrize("has_bn", [True, False])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_fc_epilogue_fwd_bwd(ops, B, N, S, has_bn, p):
+    slabs = rnd(S, B, N, seed=1)
+    bias = rnd(N, seed=2, scale=0.1)
+    gamma, beta = 1 + rnd(N, seed=3, scale=0.1), rnd(N, seed=4, scale=0.1)
+    rm, rv = rnd(N, seed=5, scale=0.1), 1 + rnd(N, seed=6, scale=0.1).abs()
+    mask = (torch.rand(B, N, generator=torch.Generator().manual_seed(7)) >= p).to(torch.uint8) if p > 0 else None
+    dd = rnd(2, B, N, seed=8)
+    addend = rnd(B, N, seed=9)
+    # ---- CPU reference with autograd
+    sl = slabs.clone().requires_grad_(True)
+    bi, ga, be = (t.clone().requires_grad_(True) for t in (bias, gamma, beta))
+    z = sl.sum(0) + bi
+    if has_bn:
+        mean, var = z.mean(0), z.var(0, unbiased=False)
+        y = (z - mean) / torch.sqrt(var + 1e-3) * ga + be
+    else:
+        y = z
+    a = torch.relu(y)
+    d = a * mask.float() / (1 - p) if mask is not None else a
+    (d * (dd.sum(0) + addend)).sum().backward()
+    # ---- HIP
+    bn = None
+    rm_d, rv_d = dev(rm.clone()), dev(rv.clone())
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    if has_bn:
+        bn = dict(gamma=dev(gamma), beta=dev(beta), running_mean=rm_d, running_var=rv_d, num_batches_tracked=nbt,
+                  momentum=0.01, eps=1e-3)
+    f = ops.fc_epilogue_fwd(dev(slabs), dev(bias), bn=bn, training=True, relu=True,
+                            keep_mask=dev(mask) if mask is not None else None, dropout_p=p)
+    torch.testing.assert_close(f["a"].cpu(), a.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(f["d"].cpu(), d.detach(), rtol=1e-5, atol=1e-5)
+    if has_bn:
+        torch.testing.assert_close(f["z"].cpu(), z.detach(), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(rm_d.cpu(), 0.99 * rm + 0.01 * mean.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(rv_d.cpu(), 0.99 * rv + 0.01 * z.detach().var(0, unbiased=True), rtol=1e-5, atol=1e-6)
+        assert int(nbt) == 1
+    dz, dbias, dgamma, dbeta = ops.fc_epilogue_bwd(
+        dev(dd), addend=dev(addend), keep_mask=dev(mask) if mask is not None else None, dropout_p=p, relu=True,
+        a=f["a"], z=f["z"], gamma=dev(gamma) if has_bn else None, mean=f["mean"], invstd=f["invstd"], has_bn=has_bn)
+    assert rel_l2(dz, sl.grad[0]) < 2e-5
+    if has_bn:
+        assert rel_l2(dgamma, ga.grad) < 2e-5
+        assert rel_l2(dbeta, be.grad) < 2e-5
+        assert float(dbias.abs().max()) < 1e-3 * float(dd.abs().max()) * B  # exactly 0 in exact arithmetic
+    else:
+        assert rel_l2(dbias, bi.grad) < 2e-5
+    # ---- eval mode (running stats)
+    if has_bn:
+        fe = ops.fc_epilogue_fwd(dev(slabs), dev(bias), bn=dict(bn, running_mean=dev(rm), running_var=dev(rv)),
+                                 training=False, relu=True)
+        ye = torch.relu((z.detach() - rm) / torch.sqrt(rv + 1e-3) * gamma + beta)
+        torch.testing.assert_close(fe["d"].cpu(), ye, rtol=1e-5, atol=1e-5)
+
+
+def test_fc_epilogue_bwd_row_scale_and_colsum(ops):
+    B, N = 40, 70
+    dd, rs = rnd(B, N, seed=1), rnd(B, seed=2)
+    dz, dbias, _, _ = ops.fc_epilogue_bwd(dev(dd), row_scale=dev(rs))
+    ref = dd * rs.unsqueeze(1)
+    assert rel_l2(dz, ref) < 1e-6
+    assert rel_l2(dbias, ref.double().sum(0)) < 1e-5
+    dz2, dbias2, _, _ = ops.fc_epilogue_bwd(dev(dd), want_dz=False)
+    assert dz2 is None and rel_l2(dbias2, dd.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("B,N", [(7, 128), (33, 100), (64, 768)])
+def test_layernorm(ops, B, N):
+    x = rnd(B, N, seed=1).requires_grad_(True)
+    y = torch.nn.functional.layer_norm(x, (N,))
+    g = rnd(B, N, seed=2)
+    (y * g).sum().backward()
+    yd, invstd = ops.layernorm_fwd(dev(x.detach()))
+    torch.testing.assert_close(yd.cpu(), y.detach(), rtol=1e-5, atol=1e-5)
+    dx = ops.layernorm_bwd(dev(g), yd, invstd)
+    assert rel_l2(dx, x.grad) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ reparam / losses
+@pytest.mark.parametrize("B,Z,K", [(8, 8, 1), (33, 10, 1), (512, 128, 1), (16, 128, 3), (5, 200, 2)])
+def test_reparam_kl(ops, B, Z, K):
+    mu = rnd(B, Z, seed=1).requires_grad_(True)
+    a = rnd(B, Z, seed=2, scale=0.5).requires_grad_(True)
+    eps = rnd(K, B, Z, seed=3)
+    var = torch.exp(a) + 1e-4
+    std = var.sqrt()
+    z = mu + std * eps
+    klr = (0.5 * (std**2 + mu**2 - 1 - (std**2).log())).sum(-1)
+    gz, gkl = rnd(K, B, Z, seed=4), rnd(B, seed=5)
+    ((z * gz).sum() + 0.37 * (klr * gkl).sum()).backward()
+    sd, zd, kl_row, stat = ops.reparam_kl_fwd(dev(mu.detach()), dev(a.detach()), dev(eps))
+    torch.testing.assert_close(zd.cpu(), z.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(sd.cpu(), std.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(kl_row.cpu(), klr.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(stat.cpu()[0], mu.detach().sum(1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(stat.cpu()[1], var.detach().sum(1), rtol=1e-5, atol=1e-5)
+    dmu, da = ops.reparam_kl_bwd(dev(mu.detach()), sd, dev(eps), dev(gz), dkl_row=dev(gkl), kl_scale=0.37)
+    assert rel_l2(dmu, mu.grad) < 1e-5
+    assert rel_l2(da, a.grad) < 1e-5
+    kdev = torch.tensor([0.37], device="cuda")
+    dmu2, da2 = ops.reparam_kl_bwd(dev(mu.detach()), sd, dev(eps), dev(gz), dkl_row=dev(gkl), kl_scale_dev=kdev)
+    assert torch.equal(dmu2, dmu) and torch.equal(da2, da)
+
+
+@pytest.mark.parametrize("B,G", [(8, 64), (33, 257), (128, 2000)])
+def test_mse_sum(ops, B, G):
+    xhat, x = rnd(B, G, seed=1), rnd(B, G, seed=2)
+    se, dx = ops.mse_sum_fwd_bwd(dev(xhat), dev(x), gscale=0.5)
+    d = xhat.double() - x.double()
+    assert rel_l2(se, (d * d).sum(1)) < 1e-6
+    assert rel_l2(dx, d) < 1e-6  # 0.5 * 2 d
+
+
+@pytest.mark.parametrize("K", [1, 3, 10])
+def test_elbo_finalize(ops, K):
+    B, T, Z = 37, 5, 16
+    se_part = rnd(T, K * B, seed=1).abs() * 3
+    kl_row = rnd(B, seed=2).abs()
+    stat = rnd(2, B, seed=3)
+    out, w = ops.elbo_finalize(dev(se_part), dev(kl_row), dev(stat), B=B, K=K, Z=Z, kl_weight=0.8, want_w=True)
+    se = se_part.double().sum(0).reshape(K, B)
+    if K == 1:
+        recon = se.sum()
+        wref = torch.ones(B)
+    else:
+        recon = (-(torch.logsumexp(-se, 0) - np.log(K))).sum()
+        wref = torch.softmax(-se, 0).reshape(-1)
+    kl = kl_row.double().mean()
+    o = out.cpu().double()
+    assert abs(float(o[1]) - float(recon)) <= 1e-5 * abs(float(recon))
+    assert abs(float(o[2]) - float(kl)) <= 1e-6 * abs(float(kl))
+    assert abs(float(o[0]) - float(recon + 0.8 * kl)) <= 1e-5 * abs(float(recon))
+    assert abs(float(o[3]) - 0.8) < 1e-7
+    assert abs(float(o[4]) - float(stat[0].double().sum() / (B * Z))) < 1e-6
+    assert abs(float(o[5]) - float(stat[1].double().sum() / (B * Z))) < 1e-6
+    torch.testing.assert_close(w.cpu().double(), wref.double(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,C", [(16, 2), (33, 8), (64, 273), (32, 4644)])
+def test_cross_entropy(ops, B, C):
+    logits = rnd(B, C, seed=1, scale=2.0).requires_grad_(True)
+    y = torch.randint(0, C, (B,), generator=torch.Generator().manual_seed(2))
+    loss = torch.nn.functional.cross_entropy(logits, y, reduction="sum")
+    loss.backward()
+    rows, dl = ops.cross_entropy_sum(dev(logits.detach()), dev(y), gscale=-25.0)
+    tot = ops.sum_f32(rows)
+    assert abs(float(tot) - float(loss.detach())) <= 1e-5 * abs(float(loss.detach()))
+    assert rel_l2(dl, -25.0 * logits.grad) < 1e-5
+    gdev = torch.tensor(-5.0, device="cuda")
+    _, dl2 = ops.cross_entropy_sum(dev(logits.detach()), dev(y), gscale=5.0, gscale_dev=gdev)
+    assert rel_l2(dl2, -25.0 * logits.grad) < 1e-5
+
+
+def test_clip_adam_matches_torch(ops):
+    n = 70001
+    p0, g1, g2 = rnd(n, seed=1), rnd(n, seed=2, scale=3.0), rnd(n, seed=3, scale=0.001)
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pt], lr=5e-3, weight_decay=1e-6)
+    p, m, v = dev(p0.clone()), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    state = torch.zeros(8, device="cuda")
+    partials = torch.empty(ops.sqnorm_partials(n), device="cuda")
+    for g in (g1, g2):
+        pt.grad = g.clone()
+        norm = torch.nn.utils.clip_grad_norm_([pt], 10.0)
+        opt.step()
+        ops.clip_adam_step(p, dev(g), m, v, state, partials, max_norm=10.0)
+        assert abs(float(state[1]) - float(norm)) <= 1e-5 * float(norm)
+        assert rel_l2(p, pt.detach()) < 1e-6
+    assert float(state[0]) == 2.0
+    # torch's clip coefficient comes from an fp32 norm; ours from an fp64-accumulated one: v ~ clip^2
+    assert rel_l2(m, opt.state[pt]["exp_avg"]) < 5e-5
+    assert rel_l2(v, opt.state[pt]["exp_avg_sq"]) < 5e-5
+
+
+def test_philox_streams(ops):
+    rng = torch.tensor([1234, 0], dtype=torch.int64, device="cuda")
+    m1 = ops.philox_keep_mask((512, 1024), 0.1, rng)
+    m2 = ops.philox_keep_mask((512, 1024), 0.1, rng)
+    assert int(rng[1]) == 2 * (512 * 1024 // 4)
+    assert not torch.equal(m1, m2)
+    assert abs(float(m1.float().mean()) - 0.9) < 3e-3
+    e = ops.philox_normal((10, 512, 128), rng)
+    assert abs(float(e.mean())) < 5e-3 and abs(float(e.std()) - 1.0) < 5e-3
+    assert abs(float((e**4).mean()) - 3.0) < 0.1
+    rng2 = torch.tensor([1234, 0], dtype=torch.int64, device="cuda")
+    assert torch.equal(ops.philox_keep_mask((512, 1024), 0.1, rng2), m1)  # reproducible from (seed, offset)
+
+
+def test_small_utils(ops):
+    x, y = rnd(1000, seed=1), rnd(1000, seed=2)
+    out = ops.axpby(2.0, dev(x), -0.5, dev(y.clone()))
+    torch.testing.assert_close(out.cpu(), 2.0 * x - 0.5 * y)
+    a, rs = rnd(9, 33, seed=3), rnd(9, seed=4)
+    torch.testing.assert_close(ops.scale_rows(dev(a), dev(rs)).cpu(), a * rs.unsqueeze(1))
+
+
+def test_bad_arguments_are_rejected_on_host(ops):
+    from mmvae_amd import _lib
+
+    a, b = dev(rnd(8, 16)), dev(rnd(8, 12))
+    with pytest.raises(ValueError):
+        ops.gemm(0, a, b)  # K mismatch
+    with pytest.raises(_lib.HipLibraryError):
+        ops.gemm(0, rnd(8, 16), rnd(8, 16))  # CPU tensors: no fallback
+    lib = _lib.load()
+    assert lib.mmvae_gemm_f32(7, 8, 8, 8, 1.0, a.data_ptr(), 16, a.data_ptr(), 16, a.data_ptr(), 8, None, 0, 1, None, 0,
+                              None) == _lib.ERR_ARG
