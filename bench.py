@@ -62,7 +62,12 @@ def cpu_baseline(cfg, seconds):
     host cores of this box on a bounded sample of the same workload."""
     from oracle import mmvae_oracle as O
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    # cores actually available to this process (cgroup / affinity), not the machine's core count
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(avail, 64)))
     B, K = cfg["batch"], cfg["K"]
     spec = O.ModelSpec(
         experts={eid: (O.FCSpec.make([G, 1024, 512], dropout_rate=0.1, use_batch_norm=True, relu=True),
@@ -150,7 +155,8 @@ def main():
         t = torch.tensor([el], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t)
-    loss = {k: float(v) for k, v in model.logged.items() if k.startswith(("loss/", "recon_loss/", "kl_loss/"))}
+    loss = {k: float(v.detach() if torch.is_tensor(v) else v) for k, v in model.logged.items()
+            if k.startswith(("loss/", "recon_loss/", "kl_loss/"))}
 
     if rank == 0:
         G = max(cfg["experts"].values())

@@ -80,7 +80,7 @@ int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, const float* A,
  *   P      = h[B,H] . W[G,H]^T + bias[G]
  *   xhat   = max(P, 0)                                   (optional store)
  *   dP     = 2 (xhat - x) * 1[P > 0]                     (optional store; unscaled d recon / d P)
- *   se_part[t, b] = sum over the genes of column tile t of (xhat - x)^2     (t < mmvae_recon_tiles(G))
+ *   se_part[t, b] = sum over the genes of column tile t (160 genes) of (xhat - x)^2     (t < mmvae_recon_tiles(G))
  *
  * The per-cell squared error is reduced across the wavefront with shuffles inside the GEMM epilogue; the
  * [tiles, B] partials are summed in fixed order by mmvae_elbo_finalize (bitwise reproducible, no atomics).
@@ -118,11 +118,15 @@ typedef struct mmvae_bn_params {
     float eps;                 /* 0.001 in the reference */
 } mmvae_bn_params;
 
+/* Scratch for the per-row-chunk column partials of the two-pass statistics (needed for training BN forward, and for
+ * any backward that produces dbias / BN gradients). */
+size_t mmvae_fc_workspace_bytes(int B, int N);
+
 int mmvae_fc_epilogue_fwd(int B, int N, const float* in, int64_t ld_in, int n_slabs, const float* bias,
                           const mmvae_bn_params* bn /* NULL = no BN */, int training, int relu,
                           const uint8_t* keep_mask /* [B,N] or NULL */, float dropout_p, float* z_out,
                           float* a_out, float* d_out, int64_t ld_out, float* save_mean, float* save_invstd,
-                          mmvae_stream_t stream);
+                          float* workspace, size_t workspace_bytes, mmvae_stream_t stream);
 
 /* Backward of the same layer tail.
  *   dd   = row_scale[b] * (sum_s din[s] + addend)        (grad wrt d; addend/row_scale optional)
@@ -130,13 +134,15 @@ int mmvae_fc_epilogue_fwd(int B, int N, const float* in, int64_t ld_in, int n_sl
  *   dy   = relu ? da * 1[a > 0] : da                      (a: forward a_out or d_out when no dropout)
  *   BN training backward: dbeta = sum_b dy, dgamma = sum_b dy*xhat, dz = gamma*invstd*(dy - dbeta/B - xhat*dgamma/B)
  *   no BN: dz = dy
- *   dbias = sum_b dz                                         (grad of the Linear bias)
+ *   dbias = sum_b dz                                         (grad of the Linear bias; ahead of a BatchNorm this is
+ *                                                             zero in exact arithmetic and is evaluated in closed form)
  * dz_out may be NULL (pure column sum).  dz_out may alias din when n_slabs == 1. */
 int mmvae_fc_epilogue_bwd(int B, int N, const float* din, int64_t ld_in, int n_slabs, const float* addend,
                           const float* row_scale, const uint8_t* keep_mask, float dropout_p, int relu,
                           const float* a, const float* z, const float* gamma, const float* save_mean,
                           const float* save_invstd, int has_bn, float* dz_out, int64_t ld_out, float* dbias,
-                          float* dgamma, float* dbeta, mmvae_stream_t stream);
+                          float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes,
+                          mmvae_stream_t stream);
 
 /* LayerNorm(elementwise_affine=False), eps 1e-5 (components.py:281) -- used by ConditionalLayer blocks ("next" row f2). */
 int mmvae_layernorm_fwd(int B, int N, const float* x, int64_t ldx, float eps, float* y, int64_t ldy, float* save_mean,
@@ -183,11 +189,11 @@ int mmvae_mse_sum_fwd_bwd(int B, int G, const float* xhat, int64_t ldxhat, const
  *            sample k of cell b at column k*B + b.
  *   out[0] = loss, out[1] = recon, out[2] = kl (mean over cells), out[3] = kl_weight, out[4] = mean(mu),
  *   out[5] = mean(var)      (accumulated in fp64, stored fp32)
- *   w_out[k*B + b] = softmax_k(-SE[b,:])  : d recon / d SE[b,k]   (== 1 for K = 1)
+ *   w_out[k*B + b] = softmax_k(-SE[b,:])  : d recon / d SE[b,k]   (== 1 for K = 1).   K <= 64.
  * ------------------------------------------------------------------------------------------------------------ */
 int mmvae_elbo_finalize(int B, int K, int T, const float* se_part, const float* kl_row, const float* stat_row, int Z,
                         const float* kl_weight_dev, float kl_weight_host, float* out6, float* w_out,
-                        mmvae_stream_t stream);
+                        float* recon_row /* [B] scratch: per-cell reconstruction term */, mmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Adversarial heads: CrossEntropyLoss(reduction="sum") forward + gradient (k11)
@@ -239,6 +245,8 @@ int mmvae_philox_keep_mask(int64_t n, float p_drop, uint8_t* mask, uint64_t* rng
                            int advance, mmvae_stream_t stream);
 int mmvae_philox_normal(int64_t n, float* out, uint64_t* rng_state, uint64_t stream_id, int advance,
                         mmvae_stream_t stream);
+/* rng_state[1] += by  (one call at the end of a step whose fills used distinct stream_ids with advance = 0). */
+int mmvae_philox_advance(uint64_t* rng_state, uint64_t by, mmvae_stream_t stream);
 
 /* Small utilities used by the step engine: y = alpha*x (+ y), fill. */
 int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, float* y, mmvae_stream_t stream);

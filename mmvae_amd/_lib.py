@@ -54,20 +54,21 @@ PROTOTYPES = {
     "mmvae_recon_tiles": (_i, [_i]),
     "mmvae_decoder_recon_f32": (_i, [_i, _i, _i, _p, _l, _p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _p]),
     "mmvae_decoder_recon_rows_f32": (_i, [_i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _p]),
+    "mmvae_fc_workspace_bytes": (_z, [_i, _i]),
     "mmvae_fc_epilogue_fwd": (
         _i,
-        [_i, _i, _p, _l, _i, _p, C.POINTER(BnParams), _i, _i, _p, _f, _p, _p, _p, _l, _p, _p, _p],
+        [_i, _i, _p, _l, _i, _p, C.POINTER(BnParams), _i, _i, _p, _f, _p, _p, _p, _l, _p, _p, _p, _z, _p],
     ),
     "mmvae_fc_epilogue_bwd": (
         _i,
-        [_i, _i, _p, _l, _i, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _i, _p, _l, _p, _p, _p, _p],
+        [_i, _i, _p, _l, _i, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _i, _p, _l, _p, _p, _p, _p, _z, _p],
     ),
     "mmvae_layernorm_fwd": (_i, [_i, _i, _p, _l, _f, _p, _l, _p, _p, _p]),
     "mmvae_layernorm_bwd": (_i, [_i, _i, _p, _l, _p, _l, _p, _p, _l, _p]),
     "mmvae_reparam_kl_fwd": (_i, [_i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p, _p]),
     "mmvae_reparam_kl_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p]),
     "mmvae_mse_sum_fwd_bwd": (_i, [_i, _i, _p, _l, _p, _l, _p, _p, _l, _p, _f, _p]),
-    "mmvae_elbo_finalize": (_i, [_i, _i, _i, _p, _p, _p, _i, _p, _f, _p, _p, _p]),
+    "mmvae_elbo_finalize": (_i, [_i, _i, _i, _p, _p, _p, _i, _p, _f, _p, _p, _p, _p]),
     "mmvae_cross_entropy_sum": (_i, [_i, _i, _p, _l, _p, _p, _p, _l, _p, _f, _p]),
     "mmvae_sum_f32": (_i, [_l, _p, _p, _i, _p]),
     "mmvae_sqnorm_partials": (_l, [_l]),
@@ -76,6 +77,7 @@ PROTOTYPES = {
     "mmvae_adam_step": (_i, [_l, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _f, _p]),
     "mmvae_philox_keep_mask": (_i, [_l, _f, _p, _p, _u64, _i, _p]),
     "mmvae_philox_normal": (_i, [_l, _p, _p, _u64, _i, _p]),
+    "mmvae_philox_advance": (_i, [_p, _u64, _p]),
     "mmvae_axpby": (_i, [_l, _f, _p, _f, _p, _p]),
     "mmvae_scale_rows": (_i, [_i, _i, _p, _l, _p, _p, _l, _p]),
 }

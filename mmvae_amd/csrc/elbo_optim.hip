@@ -103,45 +103,54 @@ __global__ __launch_bounds__(256) void mse_rows_kernel(int B, int G, const float
     if (threadIdx.x == 0 && se_row) se_row[b] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// ---------------------------------------------------------------- ELBO finalisation, single workgroup
-__global__ __launch_bounds__(256) void elbo_finalize_kernel(int B, int K, int T, const float* __restrict__ se_part,
-                                                            const float* __restrict__ kl_row,
-                                                            const float* __restrict__ stat_row, int Z,
-                                                            const float* __restrict__ klw_dev, float klw_host,
-                                                            float* __restrict__ out6, float* __restrict__ w_out) {
+// ---------------------------------------------------------------- ELBO finalisation
+// Stage 1: one wavefront per cell.  Sums the cell's squared-error partials over the T column tiles (lanes stride over
+// tiles, then a butterfly: fixed order), applies the K-sample log-mean-exp, writes recon_row[b] and w[k, b].
+constexpr int ELBO_MAXK = 64;
+__global__ __launch_bounds__(256) void elbo_rows_kernel(int B, int K, int T, const float* __restrict__ se_part,
+                                                        float* __restrict__ recon_row, float* __restrict__ w_out) {
+    __shared__ float se_s[4][ELBO_MAXK];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wv;
+    if (b >= B) return;
+    const int64_t KB = (int64_t)K * B;
+    if (K == 1) {
+        float s = 0.f;
+        for (int t = lane; t < T; t += 64) s += se_part[(int64_t)t * KB + b];
+        s = wave_sum(s);
+        if (lane == 0) {
+            recon_row[b] = s;
+            if (w_out) w_out[b] = 1.f;
+        }
+        return;
+    }
+    for (int k = 0; k < K; ++k) {
+        float s = 0.f;
+        for (int t = lane; t < T; t += 64) s += se_part[(int64_t)t * KB + (int64_t)k * B + b];
+        s = wave_sum(s);
+        if (lane == 0) se_s[wv][k] = s;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // recon_b = -log(mean_k exp(-SE_bk)), max-subtracted; w_bk = softmax_k(-SE_b.)
+    float v = (lane < K) ? -se_s[wv][lane] : -INFINITY;
+    const float mx = wave_max(v);
+    const float ex = (lane < K) ? expf(v - mx) : 0.f;
+    const float lse = mx + logf(wave_sum(ex));
+    if (lane == 0) recon_row[b] = -(lse - logf((float)K));
+    if (w_out && lane < K) w_out[(int64_t)lane * B + b] = expf(v - lse);
+}
+
+// Stage 2: single workgroup, fp64 accumulation in a fixed order.
+__global__ __launch_bounds__(256) void elbo_reduce_kernel(int B, const float* __restrict__ recon_row,
+                                                          const float* __restrict__ kl_row,
+                                                          const float* __restrict__ stat_row, int Z,
+                                                          const float* __restrict__ klw_dev, float klw_host,
+                                                          float* __restrict__ out6) {
     __shared__ double red[4][256];
     const int tid = threadIdx.x;
-    const int64_t KB = (int64_t)K * B;
     double recon = 0.0, kl = 0.0, smu = 0.0, svar = 0.0;
     for (int b = tid; b < B; b += 256) {
-        if (K == 1) {
-            double se = 0.0;
-            for (int t = 0; t < T; ++t) se += (double)se_part[(int64_t)t * KB + b];
-            recon += se;
-            if (w_out) w_out[b] = 1.f;
-        } else {
-            // recon_b = -log( mean_k exp(-SE_bk) ), max-subtracted; w_bk = softmax_k(-SE_b.)
-            float mneg = -INFINITY;
-            for (int k = 0; k < K; ++k) {
-                float se = 0.f;
-                for (int t = 0; t < T; ++t) se += se_part[(int64_t)t * KB + (int64_t)k * B + b];
-                mneg = fmaxf(mneg, -se);
-            }
-            float sum = 0.f;
-            for (int k = 0; k < K; ++k) {
-                float se = 0.f;
-                for (int t = 0; t < T; ++t) se += se_part[(int64_t)t * KB + (int64_t)k * B + b];
-                sum += expf(-se - mneg);
-            }
-            const float lse = mneg + logf(sum);
-            recon += (double)(-(lse - logf((float)K)));
-            if (w_out)
-                for (int k = 0; k < K; ++k) {
-                    float se = 0.f;
-                    for (int t = 0; t < T; ++t) se += se_part[(int64_t)t * KB + (int64_t)k * B + b];
-                    w_out[(int64_t)k * B + b] = expf(-se - lse);
-                }
-        }
+        recon += (double)recon_row[b];
         if (kl_row) kl += (double)kl_row[b];
         if (stat_row) {
             smu += (double)stat_row[b];
@@ -457,10 +466,13 @@ extern "C" int mmvae_mse_sum_fwd_bwd(int B, int G, const float* xhat, int64_t ld
 
 extern "C" int mmvae_elbo_finalize(int B, int K, int T, const float* se_part, const float* kl_row,
                                    const float* stat_row, int Z, const float* kl_weight_dev, float kl_weight_host,
-                                   float* out6, float* w_out, mmvae_stream_t stream) {
-    if (B <= 0 || K < 1 || T < 1 || !se_part || !out6) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, K, T, se_part, kl_row,
-                       stat_row, Z, kl_weight_dev, kl_weight_host, out6, w_out);
+                                   float* out6, float* w_out, float* recon_row, mmvae_stream_t stream) {
+    if (B <= 0 || K < 1 || K > ELBO_MAXK || T < 1 || !se_part || !out6 || !recon_row) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(elbo_rows_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, K, T, se_part,
+                       recon_row, w_out);
+    MMVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(elbo_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, recon_row, kl_row, stat_row, Z,
+                       kl_weight_dev, kl_weight_host, out6);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }
@@ -540,6 +552,13 @@ extern "C" int mmvae_philox_normal(int64_t n, float* out, uint64_t* rng_state, u
                            (uint64_t)((n + 3) / 4));
         MMVAE_LAUNCH_CHECK();
     }
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_philox_advance(uint64_t* rng_state, uint64_t by, mmvae_stream_t stream) {
+    if (!rng_state) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(philox_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state, by);
+    MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }
 

@@ -4,19 +4,21 @@
 // Replaces (reference): nn.BatchNorm1d(momentum=0.01, eps=0.001) components.py:279, activation :282-286,
 // nn.Dropout :287-288, nn.LayerNorm(elementwise_affine=False) :281, and their autograd.
 //
-// These are HBM/L2-bound column reductions over the batch axis.  Layout: a workgroup owns a strip of 64 feature
-// columns (lane = column, so every row read is one coalesced 256-B wave access) and its 16 wavefronts stride
-// over the batch rows; per-column statistics are combined across the 16 waves through LDS in a fixed order
-// (bitwise reproducible, no atomics).  Statistics are two-pass (mean, then centred variance) like the
-// reference's batch_norm, re-reading z from L2 rather than holding the batch in registers, so any batch size
-// works.  The split-K partial slabs of the producing GEMM are summed here: no separate reduce pass exists.
+// These are HBM/L2-bound column reductions over the batch axis.  Layout: a 2-D grid of workgroups, each owning a
+// strip of 64 feature columns (lane = column, so every row access is one coalesced 256-B wave access) x a chunk of
+// 32 batch rows (4 wavefronts x 8 rows) -> (N/64) x (B/32) workgroups fill the chip even for the 256..1024-wide core
+// layers.  Column statistics are two-pass without atomics: pass 1 leaves per-chunk partials (mean + centred M2 for
+// BatchNorm, combined with Chan's formula; plain sums in backward) in a small workspace, pass 2 merges them in chunk
+// order (bitwise reproducible) and normalises.  The split-K partial slabs of the producing GEMM are summed on the
+// fly in pass 1: no separate reduce pass exists.
 #include "common.h"
 
 namespace {
 
-constexpr int CW = 64;  // columns per workgroup (one per lane)
-constexpr int NW = 16;  // wavefronts per workgroup
-constexpr int CT = CW * NW;
+constexpr int CW = 64;   // columns per workgroup (one per lane: every row access is one coalesced 256-B wave load)
+constexpr int RPC = 32;  // rows per workgroup ("row chunk"): 4 wavefronts x 8 rows
+constexpr int RPW = 8;
+constexpr int CT = 256;
 
 struct FwdArgs {
     const float* in;
@@ -38,61 +40,91 @@ struct FwdArgs {
     int64_t ld_out;
     float* save_mean;
     float* save_invstd;
-    int B, N;
+    float* ws;  // [2][RC][N] per-chunk (mean, M2)
+    int B, N, RC;
 };
 
-// Sum of `v` over the 16 waves for each of the 64 columns; result valid in every thread.
+// Sum of `v` over the 4 waves for each of the 64 columns; result valid in every thread.  Fixed order.
 __device__ __forceinline__ float block_colsum(float v, float (*red)[CW], int w, int lane) {
     __syncthreads();
     red[w][lane] = v;
     __syncthreads();
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) s += red[i][lane];
-    return s;
+    return (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
-template <bool HAS_BN>
-__global__ __launch_bounds__(CT) void fc_fwd_kernel(const FwdArgs a) {
-    __shared__ float red[NW][CW];
+__device__ __forceinline__ float fwd_z(const FwdArgs& a, int r, int c, float bias) {
+    float z = bias;
+    const float* p = a.in + (int64_t)r * a.ld_in + c;
+    for (int s = 0; s < a.n_slabs; ++s) z += p[(int64_t)s * a.slab_stride];
+    return z;
+}
+
+// Pass 1 of training BatchNorm: z = bias + sum of slabs (stored), per-chunk column mean and centred M2.
+__global__ __launch_bounds__(CT) void fc_fwd_stats_kernel(const FwdArgs a) {
+    __shared__ float red[4][CW];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * CW + lane;
+    const int chunk = blockIdx.y;
     const bool cv = c < a.N;
     const float bias = (cv && a.bias) ? a.bias[c] : 0.f;
-
-    auto zval = [&](int r) -> float {
-        float z = bias;
-        const float* p = a.in + (int64_t)r * a.ld_in + c;
-        for (int s = 0; s < a.n_slabs; ++s) z += p[(int64_t)s * a.slab_stride];
-        return z;
-    };
-
-    float mean = 0.f, invstd = 1.f, gam = 1.f, bet = 0.f;
-    bool z_saved = false;
-    if (HAS_BN) {
-        if (cv) {
-            gam = a.gamma ? a.gamma[c] : 1.f;
-            bet = a.beta ? a.beta[c] : 0.f;
+    const int r0 = chunk * RPC + w * RPW;
+    float zv[RPW];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = r0 + i;
+        zv[i] = 0.f;
+        if (cv && r < a.B) {
+            zv[i] = fwd_z(a, r, c, bias);
+            a.z_out[(int64_t)r * a.ld_out + c] = zv[i];
+            s += zv[i];
         }
-        if (a.training) {
-            float s = 0.f;
-            if (cv)
-                for (int r = w; r < a.B; r += NW) {
-                    const float z = zval(r);
-                    a.z_out[(int64_t)r * a.ld_out + c] = z;
-                    s += z;
-                }
-            z_saved = true;
-            mean = block_colsum(s, red, w, lane) / (float)a.B;
-            float s2 = 0.f;
-            if (cv)
-                for (int r = w; r < a.B; r += NW) {
-                    const float d = a.z_out[(int64_t)r * a.ld_out + c] - mean;
-                    s2 += d * d;
-                }
-            const float var = block_colsum(s2, red, w, lane) / (float)a.B;
+    }
+    const int nb = min(RPC, a.B - chunk * RPC);
+    const float mean = block_colsum(s, red, w, lane) / (float)nb;
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+        if (r0 + i < a.B) {
+            const float d = zv[i] - mean;
+            m2 += d * d;
+        }
+    m2 = block_colsum(m2, red, w, lane);
+    if (w == 0 && cv) {
+        a.ws[(int64_t)chunk * a.N + c] = mean;
+        a.ws[(int64_t)(a.RC + chunk) * a.N + c] = m2;
+    }
+}
+
+// Pass 2 (or the only pass without training BN): normalise / activate / drop this chunk's rows.
+template <bool HAS_BN>
+__global__ __launch_bounds__(CT) void fc_fwd_apply_kernel(const FwdArgs a) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * CW + lane;
+    const int chunk = blockIdx.y;
+    if (c >= a.N) return;
+    const float bias = a.bias ? a.bias[c] : 0.f;
+    float mean = 0.f, invstd = 1.f, gam = 1.f, bet = 0.f;
+    const bool stats = HAS_BN && a.training;
+    if (HAS_BN) {
+        gam = a.gamma ? a.gamma[c] : 1.f;
+        bet = a.beta ? a.beta[c] : 0.f;
+        if (stats) {
+            // Chan et al. pairwise merge of the per-chunk (n, mean, M2), in chunk order (bitwise reproducible)
+            float n = 0.f, M2 = 0.f;
+            for (int ch = 0; ch < a.RC; ++ch) {
+                const float nb = (float)min(RPC, a.B - ch * RPC);
+                const float mb = a.ws[(int64_t)ch * a.N + c];
+                const float m2b = a.ws[(int64_t)(a.RC + ch) * a.N + c];
+                const float delta = mb - mean;
+                const float nn = n + nb;
+                mean += delta * (nb / nn);
+                M2 += m2b + delta * delta * (n * nb / nn);
+                n = nn;
+            }
+            const float var = M2 / (float)a.B;
             invstd = 1.0f / sqrtf(var + a.eps);
-            if (w == 0 && cv) {
+            if (chunk == 0 && w == 0) {
                 if (a.save_mean) a.save_mean[c] = mean;
                 if (a.save_invstd) a.save_invstd[c] = invstd;
                 if (a.running_mean) a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
@@ -100,21 +132,24 @@ __global__ __launch_bounds__(CT) void fc_fwd_kernel(const FwdArgs a) {
                     const float unb = a.B > 1 ? var * ((float)a.B / (float)(a.B - 1)) : var;
                     a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unb;
                 }
+                if (blockIdx.x == 0 && lane == 0 && a.nbt) *a.nbt += 1;
             }
-            if (blockIdx.x == 0 && threadIdx.x == 0 && a.nbt) *a.nbt += 1;
-        } else if (cv) {
+        } else {
             mean = a.running_mean[c];
             invstd = 1.0f / sqrtf(a.running_var[c] + a.eps);
         }
     }
-    if (!cv) return;
-    for (int r = w; r < a.B; r += NW) {
+    const int r0 = chunk * RPC + w * RPW;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = r0 + i;
+        if (r >= a.B) break;
         const int64_t o = (int64_t)r * a.ld_out + c;
         float z;
-        if (z_saved) {
+        if (stats) {
             z = a.z_out[o];
         } else {
-            z = zval(r);
+            z = fwd_z(a, r, c, bias);
             if (a.z_out) a.z_out[o] = z;
         }
         float y = z;
@@ -148,73 +183,110 @@ struct BwdArgs {
     float* dbias;
     float* dgamma;
     float* dbeta;
-    int B, N;
+    float* ws;  // [3][RC][N] per-chunk column sums: dy, dy*xhat, xhat
+    int B, N, RC;
 };
 
+__device__ __forceinline__ float bwd_dy(const BwdArgs& a, int r, int c) {
+    const int64_t o = (int64_t)r * a.ld_in + c;
+    float g = 0.f;
+    for (int s = 0; s < a.n_slabs; ++s) g += a.din[(int64_t)s * a.slab_stride + o];
+    // addend / a / z / dz_out share the [B, ld_out] geometry of the layer's own activations
+    const int64_t oo = (int64_t)r * a.ld_out + c;
+    if (a.addend) g += a.addend[oo];
+    if (a.row_scale) g *= a.row_scale[r];
+    if (a.mask) g = a.mask[(int64_t)r * a.N + c] ? g * a.keep_scale : 0.f;
+    if (a.relu) g = (a.a[oo] > 0.f) ? g : 0.f;
+    return g;
+}
+
+// Pass 1: dy (through dropout / ReLU) stored to dz_out, per-chunk column sums to the workspace.
 template <bool HAS_BN>
-__global__ __launch_bounds__(CT) void fc_bwd_kernel(const BwdArgs a) {
-    __shared__ float red[NW][CW];
+__global__ __launch_bounds__(CT) void fc_bwd_stats_kernel(const BwdArgs a) {
+    __shared__ float red[4][CW];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * CW + lane;
+    const int chunk = blockIdx.y;
     const bool cv = c < a.N;
-
-    float mean = 0.f, invstd = 1.f, gam = 1.f;
+    float mean = 0.f, invstd = 1.f;
     if (HAS_BN && cv) {
         mean = a.save_mean[c];
         invstd = a.save_invstd[c];
-        gam = a.gamma ? a.gamma[c] : 1.f;
     }
-    auto dyval = [&](int r) -> float {
-        const int64_t o = (int64_t)r * a.ld_in + c;
-        float g = 0.f;
-        for (int s = 0; s < a.n_slabs; ++s) g += a.din[(int64_t)s * a.slab_stride + o];
-        // addend / a / z / dz_out share the [B, ld_out] geometry of the layer's own activations
-        const int64_t oo = (int64_t)r * a.ld_out + c;
-        if (a.addend) g += a.addend[oo];
-        if (a.row_scale) g *= a.row_scale[r];
-        if (a.mask) g = a.mask[(int64_t)r * a.N + c] ? g * a.keep_scale : 0.f;
-        if (a.relu) g = (a.a[oo] > 0.f) ? g : 0.f;
-        return g;
-    };
-
-    float s1 = 0.f, s2 = 0.f;
-    if (cv)
-        for (int r = w; r < a.B; r += NW) {
-            const float dy = dyval(r);
+    const int r0 = chunk * RPC + w * RPW;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = r0 + i;
+        if (cv && r < a.B) {
+            const float dy = bwd_dy(a, r, c);
             const int64_t oo = (int64_t)r * a.ld_out + c;
+            if (a.dz_out) a.dz_out[oo] = dy;
+            s1 += dy;
             if (HAS_BN) {
                 const float xh = (a.z[oo] - mean) * invstd;
                 s2 += dy * xh;
-                a.dz_out[oo] = dy;  // stash; finished in pass 2 by the same thread
-            } else if (a.dz_out) {
-                a.dz_out[oo] = dy;
+                s3 += xh;
             }
-            s1 += dy;
         }
+    }
+    if (!a.ws) return;  // block-uniform: no column sums requested
     s1 = block_colsum(s1, red, w, lane);
-    if (!HAS_BN) {
-        if (w == 0 && cv && a.dbias) a.dbias[c] = s1;
-        return;
+    if (HAS_BN) {
+        s2 = block_colsum(s2, red, w, lane);
+        s3 = block_colsum(s3, red, w, lane);
     }
-    s2 = block_colsum(s2, red, w, lane);
     if (w == 0 && cv) {
-        if (a.dbeta) a.dbeta[c] = s1;
-        if (a.dgamma) a.dgamma[c] = s2;
-    }
-    const float invB = 1.f / (float)a.B;
-    const float m1 = s1 * invB, m2 = s2 * invB;
-    float s3 = 0.f;
-    if (cv)
-        for (int r = w; r < a.B; r += NW) {
-            const int64_t oo = (int64_t)r * a.ld_out + c;
-            const float dy = a.dz_out[oo];
-            const float xh = (a.z[oo] - mean) * invstd;
-            const float dz = gam * invstd * (dy - m1 - xh * m2);
-            a.dz_out[oo] = dz;
-            s3 += dz;
+        a.ws[(int64_t)chunk * a.N + c] = s1;
+        if (HAS_BN) {
+            a.ws[(int64_t)(a.RC + chunk) * a.N + c] = s2;
+            a.ws[(int64_t)(2 * a.RC + chunk) * a.N + c] = s3;
         }
-    s3 = block_colsum(s3, red, w, lane);
-    if (w == 0 && cv && a.dbias) a.dbias[c] = s3;
+    }
+}
+
+// Pass 2 with BN: dz = gamma * invstd * (dy - mean(dy) - xhat * mean(dy * xhat)); dbeta, dgamma; the gradient of
+// the Linear bias ahead of a BatchNorm is zero in exact arithmetic: sum_b dz = -gamma*invstd*mean(dy*xhat)*sum_b xhat.
+__global__ __launch_bounds__(CT) void fc_bwd_apply_kernel(const BwdArgs a) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * CW + lane;
+    const int chunk = blockIdx.y;
+    if (c >= a.N) return;
+    float S1 = 0.f, S2 = 0.f, S3 = 0.f;
+    for (int ch = 0; ch < a.RC; ++ch) {
+        S1 += a.ws[(int64_t)ch * a.N + c];
+        S2 += a.ws[(int64_t)(a.RC + ch) * a.N + c];
+        S3 += a.ws[(int64_t)(2 * a.RC + ch) * a.N + c];
+    }
+    const float mean = a.save_mean[c], invstd = a.save_invstd[c];
+    const float gam = a.gamma ? a.gamma[c] : 1.f;
+    const float invB = 1.f / (float)a.B;
+    const float m1 = S1 * invB, m2 = S2 * invB;
+    if (chunk == 0 && w == 0) {
+        if (a.dbeta) a.dbeta[c] = S1;
+        if (a.dgamma) a.dgamma[c] = S2;
+        if (a.dbias) a.dbias[c] = -gam * invstd * m2 * S3;
+    }
+    const int r0 = chunk * RPC + w * RPW;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = r0 + i;
+        if (r >= a.B) break;
+        const int64_t oo = (int64_t)r * a.ld_out + c;
+        const float dy = a.dz_out[oo];
+        const float xh = (a.z[oo] - mean) * invstd;
+        a.dz_out[oo] = gam * invstd * (dy - m1 - xh * m2);
+    }
+}
+
+// Pass 2 without BN: dbias[c] = sum over chunks of the partial column sums (chunk order: reproducible).
+__global__ __launch_bounds__(256) void fc_colsum_finish_kernel(const float* __restrict__ ws, int RC, int N,
+                                                               float* __restrict__ dbias) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int ch = 0; ch < RC; ++ch) s += ws[(int64_t)ch * N + c];
+    dbias[c] = s;
 }
 
 // LayerNorm without affine: one wavefront per row.
@@ -264,15 +336,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int B, int N, const 
 
 }  // namespace
 
+extern "C" size_t mmvae_fc_workspace_bytes(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return (size_t)3 * (size_t)ceil_div_i(B, RPC) * (size_t)N * sizeof(float);
+}
+
 extern "C" int mmvae_fc_epilogue_fwd(int B, int N, const float* in, int64_t ld_in, int n_slabs, const float* bias,
                                      const mmvae_bn_params* bn, int training, int relu, const uint8_t* keep_mask,
                                      float dropout_p, float* z_out, float* a_out, float* d_out, int64_t ld_out,
-                                     float* save_mean, float* save_invstd, mmvae_stream_t stream) {
+                                     float* save_mean, float* save_invstd, float* workspace, size_t workspace_bytes,
+                                     mmvae_stream_t stream) {
     if (B <= 0 || N <= 0 || !in || n_slabs < 1 || ld_in < N || ld_out < N) return MMVAE_ERR_ARG;
     if (!a_out && !d_out) return MMVAE_ERR_ARG;
     if (keep_mask && (dropout_p < 0.f || dropout_p >= 1.f || !d_out)) return MMVAE_ERR_ARG;
     if (bn && training && (!z_out || !save_mean || !save_invstd)) return MMVAE_ERR_ARG;
     if (bn && !training && (!bn->running_mean || !bn->running_var)) return MMVAE_ERR_ARG;
+    const bool stats = bn && training;
+    if (stats && (!workspace || workspace_bytes < mmvae_fc_workspace_bytes(B, N))) return MMVAE_ERR_WORKSPACE;
     FwdArgs a = {};
     a.in = in;
     a.ld_in = ld_in;
@@ -298,13 +378,20 @@ extern "C" int mmvae_fc_epilogue_fwd(int B, int N, const float* in, int64_t ld_i
     a.ld_out = ld_out;
     a.save_mean = save_mean;
     a.save_invstd = save_invstd;
+    a.ws = workspace;
     a.B = B;
     a.N = N;
-    const int grid = ceil_div_i(N, CW);
+    a.RC = ceil_div_i(B, RPC);
+    const dim3 grid(ceil_div_i(N, CW), a.RC);
+    hipStream_t s = (hipStream_t)stream;
+    if (stats) {
+        hipLaunchKernelGGL(fc_fwd_stats_kernel, grid, dim3(CT), 0, s, a);
+        MMVAE_LAUNCH_CHECK();
+    }
     if (bn)
-        hipLaunchKernelGGL(fc_fwd_kernel<true>, dim3(grid), dim3(CT), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(fc_fwd_apply_kernel<true>, grid, dim3(CT), 0, s, a);
     else
-        hipLaunchKernelGGL(fc_fwd_kernel<false>, dim3(grid), dim3(CT), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(fc_fwd_apply_kernel<false>, grid, dim3(CT), 0, s, a);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }
@@ -313,12 +400,15 @@ extern "C" int mmvae_fc_epilogue_bwd(int B, int N, const float* din, int64_t ld_
                                      const float* row_scale, const uint8_t* keep_mask, float dropout_p, int relu,
                                      const float* a_act, const float* z, const float* gamma, const float* save_mean,
                                      const float* save_invstd, int has_bn, float* dz_out, int64_t ld_out, float* dbias,
-                                     float* dgamma, float* dbeta, mmvae_stream_t stream) {
+                                     float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes,
+                                     mmvae_stream_t stream) {
     if (B <= 0 || N <= 0 || !din || n_slabs < 1 || ld_in < N || ld_out < N) return MMVAE_ERR_ARG;
     if (relu && !a_act) return MMVAE_ERR_ARG;
     if (keep_mask && (dropout_p < 0.f || dropout_p >= 1.f)) return MMVAE_ERR_ARG;
     if (has_bn && (!z || !save_mean || !save_invstd || !dz_out)) return MMVAE_ERR_ARG;
     if (!dz_out && !dbias) return MMVAE_ERR_ARG;
+    const bool need_ws = has_bn || dbias;
+    if (need_ws && (!workspace || workspace_bytes < mmvae_fc_workspace_bytes(B, N))) return MMVAE_ERR_WORKSPACE;
     BwdArgs a = {};
     a.din = din;
     a.ld_in = ld_in;
@@ -339,13 +429,23 @@ extern "C" int mmvae_fc_epilogue_bwd(int B, int N, const float* din, int64_t ld_
     a.dbias = dbias;
     a.dgamma = dgamma;
     a.dbeta = dbeta;
+    a.ws = need_ws ? workspace : nullptr;
     a.B = B;
     a.N = N;
-    const int grid = ceil_div_i(N, CW);
-    if (has_bn)
-        hipLaunchKernelGGL(fc_bwd_kernel<true>, dim3(grid), dim3(CT), 0, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL(fc_bwd_kernel<false>, dim3(grid), dim3(CT), 0, (hipStream_t)stream, a);
+    a.RC = ceil_div_i(B, RPC);
+    const dim3 grid(ceil_div_i(N, CW), a.RC);
+    hipStream_t s = (hipStream_t)stream;
+    if (has_bn) {
+        hipLaunchKernelGGL(fc_bwd_stats_kernel<true>, grid, dim3(CT), 0, s, a);
+        MMVAE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(fc_bwd_apply_kernel, grid, dim3(CT), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(fc_bwd_stats_kernel<false>, grid, dim3(CT), 0, s, a);
+        MMVAE_LAUNCH_CHECK();
+        if (dbias)
+            hipLaunchKernelGGL(fc_colsum_finish_kernel, dim3(ceil_div_i(N, 256)), dim3(256), 0, s, workspace, a.RC, N,
+                               dbias);
+    }
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }

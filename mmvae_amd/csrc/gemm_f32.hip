@@ -25,17 +25,22 @@
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int KC_LD = BK + 4;  // floats per LDS row of a K-contiguous operand tile
-constexpr int NT = 256;        // threads per workgroup
+constexpr int NT = 256;  // threads per workgroup (4 wavefronts)
 
 enum { FORM_KC = 0, FORM_RC = 1 };
 enum { EPI_STD = 0, EPI_RECON = 1 };
 
-template <int FORM, int R>
+// LDS image of one operand tile with R rows/columns along the non-K axis and BK along K.
+//   KC ("K contiguous" in HBM):  [R][BK + 4]   (+4 floats: conflict-free ds_read_b128)
+//   RC ("row contiguous"):        [BK][R]
+template <int FORM, int R, int BK>
 struct Tile {
+    static constexpr int KC_LD = BK + 4;
     static constexpr int LDS_FLOATS = (FORM == FORM_KC) ? R * KC_LD : BK * R;
-    static constexpr int VECS = R / 32;  // float4 per thread per k-tile
+    static constexpr int NVEC = R * BK / 4;               // float4 per tile
+    static constexpr int VECS = (NVEC + NT - 1) / NT;     // float4 per thread
+    static constexpr bool EXACT = (NVEC % NT) == 0;
+    static constexpr int C4 = (FORM == FORM_KC) ? BK / 4 : R / 4;  // float4 per contiguous run
 };
 
 struct GemmArgs {
@@ -51,6 +56,7 @@ struct GemmArgs {
     int64_t slab_stride;   // elements between split-K slabs of C (0 when splitk == 1)
     float alpha;
     unsigned flags;
+    int aligned;           // A, B 16-byte aligned with leading dimensions % 4 == 0
     // recon epilogue
     const float* x;
     float* xhat;
@@ -61,41 +67,44 @@ struct GemmArgs {
 };
 
 // HBM -> registers.  r0: first row (KC) / column (RC) of this tile along the non-K axis, Rtot its extent.
-template <int FORM, int R, bool ALIGNED>
-__device__ __forceinline__ void load_tile(f32x4 (&reg)[R / 32], const float* __restrict__ P, int64_t ld, int r0,
-                                          int Rtot, int k0, int Kend, int tid) {
+// Branch-free: FAST (block-uniform: tile fully inside the matrix, 16-byte aligned rows) issues plain 16-byte loads
+// back to back; otherwise indices are clamped into the matrix and out-of-range values zeroed with selects.
+template <int FORM, int R, int BK, bool FAST, int NV>
+__device__ __forceinline__ void load_tile(f32x4 (&reg)[NV], const float* __restrict__ P, int64_t ld, int r0, int Rtot,
+                                          int k0, int Kend, int tid) {
+    static_assert(NV == Tile<FORM, R, BK>::VECS, "register tile size");
+    using T = Tile<FORM, R, BK>;
 #pragma unroll
-    for (int i = 0; i < R / 32; ++i) {
+    for (int i = 0; i < T::VECS; ++i) {
+        const int f = tid + NT * i;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (FORM == FORM_KC) {
-            const int c4 = tid & 7;
-            const int gr = r0 + (tid >> 3) + 32 * i;
-            const int gk = k0 + c4 * 4;
-            if (gr < Rtot && gk < Kend) {
-                const float* p = P + (int64_t)gr * ld + gk;
-                if (ALIGNED && gk + 3 < Kend) {
-                    v = *reinterpret_cast<const f32x4*>(p);
+        if (T::EXACT || f < T::NVEC) {
+            const int run = f / T::C4, c4 = f % T::C4;
+            if (FORM == FORM_KC) {
+                const int gr = r0 + run, gk = k0 + c4 * 4;
+                if (FAST) {
+                    v = *reinterpret_cast<const f32x4*>(P + (int64_t)gr * ld + gk);
                 } else {
-                    v.x = p[0];
-                    if (gk + 1 < Kend) v.y = p[1];
-                    if (gk + 2 < Kend) v.z = p[2];
-                    if (gk + 3 < Kend) v.w = p[3];
+                    const float* p = P + (int64_t)min(gr, Rtot - 1) * ld;
+                    const bool rv = gr < Rtot;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float t = p[min(gk + j, Kend - 1)];
+                        v[j] = (rv && gk + j < Kend) ? t : 0.f;
+                    }
                 }
-            }
-        } else {
-            constexpr int C4 = R / 4;  // float4 per k-row
-            const int c4 = tid % C4;
-            const int gk = k0 + tid / C4 + (NT / C4) * i;
-            const int gr = r0 + c4 * 4;
-            if (gk < Kend && gr < Rtot) {
-                const float* p = P + (int64_t)gk * ld + gr;
-                if (ALIGNED && gr + 3 < Rtot) {
-                    v = *reinterpret_cast<const f32x4*>(p);
+            } else {
+                const int gk = k0 + run, gr = r0 + c4 * 4;
+                if (FAST) {
+                    v = *reinterpret_cast<const f32x4*>(P + (int64_t)gk * ld + gr);
                 } else {
-                    v.x = p[0];
-                    if (gr + 1 < Rtot) v.y = p[1];
-                    if (gr + 2 < Rtot) v.z = p[2];
-                    if (gr + 3 < Rtot) v.w = p[3];
+                    const float* p = P + (int64_t)min(gk, Kend - 1) * ld;
+                    const bool kv = gk < Kend;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float t = p[min(gr + j, Rtot - 1)];
+                        v[j] = (kv && gr + j < Rtot) ? t : 0.f;
+                    }
                 }
             }
         }
@@ -104,29 +113,29 @@ __device__ __forceinline__ void load_tile(f32x4 (&reg)[R / 32], const float* __r
 }
 
 // registers -> LDS image
-template <int FORM, int R>
-__device__ __forceinline__ void store_tile(float* S, const f32x4 (&reg)[R / 32], int tid) {
+template <int FORM, int R, int BK, int NV>
+__device__ __forceinline__ void store_tile(float* S, const f32x4 (&reg)[NV], int tid) {
+    static_assert(NV == Tile<FORM, R, BK>::VECS, "register tile size");
+    using T = Tile<FORM, R, BK>;
 #pragma unroll
-    for (int i = 0; i < R / 32; ++i) {
-        if (FORM == FORM_KC) {
-            const int c4 = tid & 7;
-            const int r = (tid >> 3) + 32 * i;
-            *reinterpret_cast<f32x4*>(&S[r * KC_LD + c4 * 4]) = reg[i];
-        } else {
-            constexpr int C4 = R / 4;
-            const int c4 = tid % C4;
-            const int k = tid / C4 + (NT / C4) * i;
-            *reinterpret_cast<f32x4*>(&S[k * R + c4 * 4]) = reg[i];
+    for (int i = 0; i < T::VECS; ++i) {
+        const int f = tid + NT * i;
+        if (T::EXACT || f < T::NVEC) {
+            const int run = f / T::C4, c4 = f % T::C4;
+            if (FORM == FORM_KC)
+                *reinterpret_cast<f32x4*>(&S[run * T::KC_LD + c4 * 4]) = reg[i];
+            else
+                *reinterpret_cast<f32x4*>(&S[run * R + c4 * 4]) = reg[i];
         }
     }
 }
 
 // LDS -> MFMA operand fragment: element j of the result feeds MFMA step j of k-group kk and carries
 // k = 8*kk + 4*half + j for row/column `row` of the tile.
-template <int FORM, int R>
+template <int FORM, int R, int BK>
 __device__ __forceinline__ f32x4 load_frag(const float* S, int row, int kk, int half) {
     if (FORM == FORM_KC) {
-        return *reinterpret_cast<const f32x4*>(&S[row * KC_LD + kk * 8 + 4 * half]);
+        return *reinterpret_cast<const f32x4*>(&S[row * Tile<FORM, R, BK>::KC_LD + kk * 8 + 4 * half]);
     } else {
         const float* q = &S[(kk * 8 + 4 * half) * R + row];
         f32x4 f;
@@ -138,12 +147,17 @@ __device__ __forceinline__ f32x4 load_frag(const float* S, int row, int kk, int 
     }
 }
 
-template <int AFORM, int BFORM, int BM, int BN, bool ALIGNED, int EPI>
+// Block tile BM x BN, k-tile BK, 4 waves arranged WGM x WGN; each wave owns (BM/WGM) x (BN/WGN) as 32x32 MFMA blocks.
+template <int AFORM, int BFORM, int BM, int BN, int BK, int WGM, int WGN, int EPI>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
-    constexpr int TM = BM / 64;  // 32x32 MFMA blocks per wave along M (wave grid is 2x2)
-    constexpr int TN = BN / 64;
-    constexpr int A_FLOATS = Tile<AFORM, BM>::LDS_FLOATS;
-    constexpr int B_FLOATS = Tile<BFORM, BN>::LDS_FLOATS;
+    static_assert(WGM * WGN == 4, "4 wavefronts per workgroup");
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;  // wave tile
+    constexpr int TM = WTM / 32, TN = WTN / 32;    // 32x32 MFMA blocks per wave
+    static_assert(TM * 32 == WTM && TN * 32 == WTN && BK % 8 == 0, "tile shape");
+    using TA = Tile<AFORM, BM, BK>;
+    using TB = Tile<BFORM, BN, BK>;
+    constexpr int A_FLOATS = TA::LDS_FLOATS, B_FLOATS = TB::LDS_FLOATS;
+    constexpr int KK = BK / 8;
     __shared__ __attribute__((aligned(16))) float lds[2 * A_FLOATS + 2 * B_FLOATS];
     float* As = lds;
     float* Bs = lds + 2 * A_FLOATS;
@@ -151,7 +165,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, half = lane >> 5;
 
     // XCD-aware (bijective) remap of the workgroup id, then z (split-K slice) slowest, M fastest.
@@ -167,6 +181,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     int kt_end = kt_beg + g.ktiles_per_split;
     if (kt_end > g.ktiles) kt_end = g.ktiles;
     const int nkt = kt_end - kt_beg;
+    // block-uniform: may this block use the unguarded 16-byte loads (for k-tiles that lie fully inside K)?
+    const bool inner = g.aligned && (bm * BM + BM <= g.M) && (bn * BN + BN <= g.N);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -176,41 +192,56 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
 
-    f32x4 ra[BM / 32], rb[BN / 32];
+    f32x4 ra[TA::VECS], rb[TB::VECS];
+    auto load_ab = [&](int kt) {
+        const int k0 = kt * BK;
+        if (inner && k0 + BK <= g.K) {
+            load_tile<AFORM, BM, BK, true>(ra, g.A, g.lda, bm * BM, g.M, k0, g.K, tid);
+            load_tile<BFORM, BN, BK, true>(rb, g.B, g.ldb, bn * BN, g.N, k0, g.K, tid);
+        } else {
+            load_tile<AFORM, BM, BK, false>(ra, g.A, g.lda, bm * BM, g.M, k0, g.K, tid);
+            load_tile<BFORM, BN, BK, false>(rb, g.B, g.ldb, bn * BN, g.N, k0, g.K, tid);
+        }
+    };
     if (nkt > 0) {
-        load_tile<AFORM, BM, ALIGNED>(ra, g.A, g.lda, bm * BM, g.M, kt_beg * BK, g.K, tid);
-        load_tile<BFORM, BN, ALIGNED>(rb, g.B, g.ldb, bn * BN, g.N, kt_beg * BK, g.K, tid);
-        store_tile<AFORM, BM>(As, ra, tid);
-        store_tile<BFORM, BN>(Bs, rb, tid);
+        load_ab(kt_beg);
+        store_tile<AFORM, BM, BK>(As, ra, tid);
+        store_tile<BFORM, BN, BK>(Bs, rb, tid);
         __syncthreads();
         for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
             const bool more = (kt + 1 < nkt);
-            if (more) {
-                const int k0 = (kt_beg + kt + 1) * BK;
-                load_tile<AFORM, BM, ALIGNED>(ra, g.A, g.lda, bm * BM, g.M, k0, g.K, tid);
-                load_tile<BFORM, BN, ALIGNED>(rb, g.B, g.ldb, bn * BN, g.N, k0, g.K, tid);
-            }
+            if (more) load_ab(kt_beg + kt + 1);  // in flight during this k-tile's MFMAs
             const float* Ac = As + cur * A_FLOATS;
             const float* Bc = Bs + cur * B_FLOATS;
+            // fragments are fetched one k-group ahead of the MFMAs that consume them
+            f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
-            for (int kk = 0; kk < BK / 8; ++kk) {
-                f32x4 fa[TM], fb[TN];
+            for (int i = 0; i < TM; ++i) fa[0][i] = load_frag<AFORM, BM, BK>(Ac, wm * WTM + i * 32 + l31, 0, half);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = load_frag<AFORM, BM>(Ac, wm * (BM / 2) + i * 32 + l31, kk, half);
+            for (int n = 0; n < TN; ++n) fb[0][n] = load_frag<BFORM, BN, BK>(Bc, wn * WTN + n * 32 + l31, 0, half);
 #pragma unroll
-                for (int n = 0; n < TN; ++n) fb[n] = load_frag<BFORM, BN>(Bc, wn * (BN / 2) + n * 32 + l31, kk, half);
+            for (int kk = 0; kk < KK; ++kk) {
+                const int c = kk & 1, nx = c ^ 1;
+                if (kk + 1 < KK) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        fa[nx][i] = load_frag<AFORM, BM, BK>(Ac, wm * WTM + i * 32 + l31, kk + 1, half);
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        fb[nx][n] = load_frag<BFORM, BN, BK>(Bc, wn * WTN + n * 32 + l31, kk + 1, half);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int n = 0; n < TN; ++n)
-                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[n][j], acc[i][n], 0, 0, 0);
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][j], fb[c][n][j], acc[i][n], 0, 0, 0);
             }
             if (more) {
-                store_tile<AFORM, BM>(As + (cur ^ 1) * A_FLOATS, ra, tid);
-                store_tile<BFORM, BN>(Bs + (cur ^ 1) * B_FLOATS, rb, tid);
+                store_tile<AFORM, BM, BK>(As + (cur ^ 1) * A_FLOATS, ra, tid);
+                store_tile<BFORM, BN, BK>(Bs + (cur ^ 1) * B_FLOATS, rb, tid);
             }
             __syncthreads();
         }
@@ -220,44 +251,50 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     if (EPI == EPI_STD) {
         float* C = g.C + (int64_t)z * g.slab_stride;
         const bool raw = (g.flags & MMVAE_GEMM_RAW_SLABS) || g.slab_stride != 0;
+        const bool accum = !raw && (g.flags & MMVAE_GEMM_ACCUMULATE);
+        const bool relu = !raw && (g.flags & MMVAE_GEMM_RELU);
+        const float alpha = raw ? 1.f : g.alpha;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int n = 0; n < TN; ++n) {
-                const int col = bn * BN + wn * (BN / 2) + n * 32 + l31;
+                const int col = bn * BN + wn * WTN + n * 32 + l31;
                 if (col >= g.N) continue;
                 const float bv = (!raw && g.bias) ? g.bias[col] : 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int row = bm * BM + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    const int row = bm * BM + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
                     if (row >= g.M) continue;
                     float* cp = C + (int64_t)row * g.ldc + col;
-                    float v = acc[i][n][e];
-                    if (!raw) {
-                        v = v * g.alpha + bv;
-                        if (g.flags & MMVAE_GEMM_ACCUMULATE) v += *cp;
-                        if (g.flags & MMVAE_GEMM_RELU) v = fmaxf(v, 0.f);
-                    }
+                    float v = acc[i][n][e] * alpha + bv;
+                    if (accum) v += *cp;
+                    if (relu) v = fmaxf(v, 0.f);
                     *cp = v;
                 }
             }
     } else {
         // bias + ReLU + squared error + dP; per-cell SE reduced over the 32 lanes that share a row.
-        float* rowsum = lds;  // [2 (wn)][BM] scratch: the operand tiles are dead after the final barrier
+        float* rowsum = lds;  // [WGN][BM] scratch: the operand tiles are dead after the final barrier
+        float bv[TN];
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int col = bn * BN + wn * WTN + n * 32 + l31;
+            bv[n] = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int rloc = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                const int rloc = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
                 const int row = bm * BM + rloc;
                 float s = 0.f;
                 if (row < g.M) {
                     const int xr = row % g.x_rows;
 #pragma unroll
                     for (int n = 0; n < TN; ++n) {
-                        const int col = bn * BN + wn * (BN / 2) + n * 32 + l31;
+                        const int col = bn * BN + wn * WTN + n * 32 + l31;
                         if (col < g.N) {
-                            const float p = acc[i][n][e] + (g.bias ? g.bias[col] : 0.f);
+                            const float p = acc[i][n][e] + bv[n];
                             const float xh = fmaxf(p, 0.f);
                             const float d = xh - g.x[(int64_t)xr * g.ldx + col];
                             s += d * d;
@@ -273,7 +310,12 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
         __syncthreads();
         if (tid < BM) {
             const int row = bm * BM + tid;
-            if (row < g.M) g.se_part[(int64_t)bn * g.M + row] = rowsum[tid] + rowsum[BM + tid];
+            if (row < g.M) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < WGN; ++w) s += rowsum[w * BM + tid];
+                g.se_part[(int64_t)bn * g.M + row] = s;
+            }
         }
     }
 }
@@ -296,25 +338,68 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <int AFORM, int BFORM, int BM, int BN, int EPI>
-int launch_gemm(const GemmArgs& g, bool aligned, int nblocks, hipStream_t s) {
-    if (aligned)
-        hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, BM, BN, true, EPI>), dim3(nblocks), dim3(NT), 0, s, g);
-    else
-        hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, BM, BN, false, EPI>), dim3(nblocks), dim3(NT), 0, s, g);
+// ---------------------------------------------------------------------------------------------------- host side
+// Tile shapes.  id 0: 128x128 (2x2 waves), 1: 128x160 (4x1 waves; 20000 = 125 x 160 -> no ragged last wave of tiles),
+// 2: 64x64 (2x2 waves, the small core layers).  BK = 32 except NT 128x160 (BK = 16 keeps LDS at 46 KB so that two
+// workgroups stay resident per CU).
+struct TileShape {
+    int bm, bn, blocks_per_cu;
+};
+
+TileShape tile_shape(int layout, int id) {
+    if (id == 0) return {128, 128, 2};
+    if (id == 1) return {128, 160, 2};
+    return {64, 64, 4};
+}
+
+template <int AFORM, int BFORM, int EPI>
+int launch_gemm_forms(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) {
+    if (tile_id == 0)
+        hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, 128, 128, 32, 2, 2, EPI>), dim3(nblocks), dim3(NT), 0, s, g);
+    else if (tile_id == 1) {
+        if (AFORM == FORM_KC && BFORM == FORM_KC)
+            hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, 128, 160, 16, 4, 1, EPI>), dim3(nblocks), dim3(NT), 0, s,
+                               g);
+        else
+            hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, 128, 160, 32, 4, 1, EPI>), dim3(nblocks), dim3(NT), 0, s,
+                               g);
+    } else
+        hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, 64, 64, 32, 2, 2, EPI>), dim3(nblocks), dim3(NT), 0, s, g);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }
 
-void plan(int M, int N, int K, int* tile, int* splitk) {
-    const int kt = ceil_div_i(K, BK);
-    const int t128 = ceil_div_i(M, 128) * ceil_div_i(N, 128);
-    const int t64 = ceil_div_i(M, 64) * ceil_div_i(N, 64);
-    if (t128 >= 192) {
-        *tile = 128;
+int bk_of(int layout, int tile_id) { return (tile_id == 1 && layout == MMVAE_GEMM_NT) ? 16 : 32; }
+
+// Picks tile id and split-K.  Large outputs: the tile whose (rounds x tile area) is smallest, rounds = number of
+// times the chip's resident-workgroup slots are filled.  Few output tiles (K = G reductions): split-K.
+void plan(int layout, int M, int N, int K, int* tile_id, int* splitk) {
+    const int CUS = 256;
+    long best_cost = -1;
+    int best = 0;
+    for (int id = 0; id < (layout == MMVAE_GEMM_NT ? 2 : 1); ++id) {  // 128x160 measured slower on the RC images
+        const TileShape ts = tile_shape(layout, id);
+        const long tiles = (long)ceil_div_i(M, ts.bm) * ceil_div_i(N, ts.bn);
+        const long slots = (long)CUS * ts.blocks_per_cu;
+        const long rounds = (tiles + slots - 1) / slots;
+        // fractional fill of the last round still costs a full tile time per CU
+        const long per_cu = (tiles + CUS - 1) / CUS;
+        const long cost = (rounds > 1 ? per_cu : (tiles + CUS - 1) / CUS) * ts.bm * ts.bn;
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = id;
+        }
+    }
+    const TileShape tb = tile_shape(layout, best);
+    const int tbig = ceil_div_i(M, tb.bm) * ceil_div_i(N, tb.bn);
+    if (tbig >= 192) {
+        *tile_id = best;
         *splitk = 1;
         return;
     }
+    const int kt = ceil_div_i(K, 32);
+    const int t128 = ceil_div_i(M, 128) * ceil_div_i(N, 128);
+    const int t64 = ceil_div_i(M, 64) * ceil_div_i(N, 64);
     int sA = ceil_div_i(512, t128);
     if (sA > kt / 8) sA = kt / 8;
     if (sA < 1) sA = 1;
@@ -324,10 +409,10 @@ void plan(int M, int N, int K, int* tile, int* splitk) {
     if (sB < 1) sB = 1;
     if (sB > 64) sB = 64;
     if (t128 * sA >= 256 || t128 * sA >= t64 * sB) {
-        *tile = 128;
+        *tile_id = 0;
         *splitk = sA;
     } else {
-        *tile = 64;
+        *tile_id = 2;
         *splitk = sB;
     }
 }
@@ -337,7 +422,7 @@ void plan(int M, int N, int K, int* tile, int* splitk) {
 extern "C" int mmvae_gemm_plan(int layout, int M, int N, int K, int* tile_out, int* splitk_out) {
     if (layout < 0 || layout > 2 || M <= 0 || N <= 0 || K <= 0) return MMVAE_ERR_ARG;
     int tile, sk;
-    plan(M, N, K, &tile, &sk);
+    plan(layout, M, N, K, &tile, &sk);
     if (tile_out) *tile_out = tile;
     if (splitk_out) *splitk_out = sk;
     return MMVAE_OK;
@@ -362,10 +447,12 @@ extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, cons
     if (lda < a_inner || ldb < b_inner) return MMVAE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
 
-    int tile, sk_auto;
-    plan(M, N, K, &tile, &sk_auto);
+    int tile_id, sk_auto;
+    plan(layout, M, N, K, &tile_id, &sk_auto);
     if (splitk == 0) splitk = sk_auto;
-    const int ktiles = ceil_div_i(K, BK);
+    if (splitk > 1 && tile_id == 1) tile_id = 0;  // split-K slices use the square tiles
+    const TileShape ts = tile_shape(layout, tile_id);
+    const int ktiles = ceil_div_i(K, bk_of(layout, tile_id));
     const bool raw = (flags & MMVAE_GEMM_RAW_SLABS) != 0;
     if (!raw && splitk > ktiles) splitk = ktiles;
     if (raw && (flags & (MMVAE_GEMM_RELU | MMVAE_GEMM_ACCUMULATE))) return MMVAE_ERR_ARG;
@@ -380,14 +467,15 @@ extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, cons
     g.M = M;
     g.N = N;
     g.K = K;
-    g.mt = ceil_div_i(M, tile);
-    g.nt = ceil_div_i(N, tile);
+    g.mt = ceil_div_i(M, ts.bm);
+    g.nt = ceil_div_i(N, ts.bn);
     g.ktiles = ktiles;
     g.ktiles_per_split = ceil_div_i(ktiles, splitk);
     if (!raw) splitk = ceil_div_i(ktiles, g.ktiles_per_split);  // drop empty trailing slices (raw: caller sized the slabs)
     g.alpha = alpha;
     g.flags = flags;
     g.x_rows = 1;
+    g.aligned = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     if (raw) {
         g.C = C;
         g.ldc = ldc;
@@ -402,24 +490,14 @@ extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, cons
         g.ldc = ldc;
         g.slab_stride = 0;
     }
-    const bool aligned = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     const int nblocks = g.mt * g.nt * splitk;
     int rc;
-    if (tile == 128) {
-        if (layout == MMVAE_GEMM_NT)
-            rc = launch_gemm<FORM_KC, FORM_KC, 128, 128, EPI_STD>(g, aligned, nblocks, s);
-        else if (layout == MMVAE_GEMM_NN)
-            rc = launch_gemm<FORM_KC, FORM_RC, 128, 128, EPI_STD>(g, aligned, nblocks, s);
-        else
-            rc = launch_gemm<FORM_RC, FORM_RC, 128, 128, EPI_STD>(g, aligned, nblocks, s);
-    } else {
-        if (layout == MMVAE_GEMM_NT)
-            rc = launch_gemm<FORM_KC, FORM_KC, 64, 64, EPI_STD>(g, aligned, nblocks, s);
-        else if (layout == MMVAE_GEMM_NN)
-            rc = launch_gemm<FORM_KC, FORM_RC, 64, 64, EPI_STD>(g, aligned, nblocks, s);
-        else
-            rc = launch_gemm<FORM_RC, FORM_RC, 64, 64, EPI_STD>(g, aligned, nblocks, s);
-    }
+    if (layout == MMVAE_GEMM_NT)
+        rc = launch_gemm_forms<FORM_KC, FORM_KC, EPI_STD>(tile_id, g, nblocks, s);
+    else if (layout == MMVAE_GEMM_NN)
+        rc = launch_gemm_forms<FORM_KC, FORM_RC, EPI_STD>(tile_id, g, nblocks, s);
+    else
+        rc = launch_gemm_forms<FORM_RC, FORM_RC, EPI_STD>(tile_id, g, nblocks, s);
     if (rc != MMVAE_OK) return rc;
     if (!raw && splitk > 1) {
         const int64_t total = (int64_t)M * N;
@@ -432,7 +510,8 @@ extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, cons
     return MMVAE_OK;
 }
 
-extern "C" int mmvae_recon_tiles(int G) { return G > 0 ? ceil_div_i(G, 128) : 0; }
+// The fused decoder/recon kernel always uses the 128x160 tile: one se_part row per 160-gene column tile.
+extern "C" int mmvae_recon_tiles(int G) { return G > 0 ? ceil_div_i(G, 160) : 0; }
 
 extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, const float* h, int64_t ldh,
                                             const float* W, int64_t ldw, const float* bias, const float* x, int64_t ldx,
@@ -453,8 +532,8 @@ extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, 
     g.N = G;
     g.K = H;
     g.mt = ceil_div_i(rows, 128);
-    g.nt = ceil_div_i(G, 128);
-    g.ktiles = ceil_div_i(H, BK);
+    g.nt = ceil_div_i(G, 160);
+    g.ktiles = ceil_div_i(H, 16);
     g.ktiles_per_split = g.ktiles;
     g.alpha = 1.f;
     g.x = x;
@@ -465,8 +544,8 @@ extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, 
     g.ldxhat = ldxhat;
     g.lddp = lddp;
     g.x_rows = x_rows;
-    const bool aligned = aligned16(h) && aligned16(W) && (ldh % 4 == 0) && (ldw % 4 == 0);
-    return launch_gemm<FORM_KC, FORM_KC, 128, 128, EPI_RECON>(g, aligned, g.mt * g.nt, (hipStream_t)stream);
+    g.aligned = aligned16(h) && aligned16(W) && (ldh % 4 == 0) && (ldw % 4 == 0);
+    return launch_gemm_forms<FORM_KC, FORM_KC, EPI_RECON>(1, g, g.mt * g.nt, (hipStream_t)stream);
 }
 
 extern "C" int mmvae_decoder_recon_f32(int B, int G, int H, const float* h, int64_t ldh, const float* W, int64_t ldw,

@@ -1,7 +1,630 @@
-"""Graph-captured training-step engine (placeholder until the captured path lands; the module path is used)."""
+"""Graph-captured training-step engine: the measured hot path.
+
+One MMVAE training step (reference `CMMVAEModel.training_step`, models/cmmvae_model.py:138-217, with
+`gradient_reversal_domain_classifier` :103-136 and `BaseVAE.elbo` modules/vae.py:136-152) is compiled, per expert, into
+a FIXED program of libmmvae_hip.so launches over pre-allocated HBM buffers:
+
+    [Philox masks / eps] -> expert encoder (GEMM + fused BN/ReLU/dropout column kernels, split-K slabs summed in the
+    epilogue) -> VAE encoder -> mean/var heads -> fused reparameterise+KL -> VAE decoder -> expert decoder, last layer
+    fused with the squared-error / dP epilogue -> ELBO finalise -> [adversarial D phase: fwd, CE, bwd, clip+Adam;
+    G phase behind gradient reversal] -> backward GEMMs writing weight gradients STRAIGHT into the optimiser's flat
+    gradient arena -> fused global-norm clip + Adam over the arenas.
+
+The program is run eagerly once (a real step; loads the code objects), then captured into a hipGraph and replayed:
+no tracing compiler, no per-step allocation, no host read-back (loss scalars stay in a device metrics buffer).
+Per-step host values (KL weight) live in device scalars the kernels read, so the captured graph stays valid.
+Under data parallelism the program is cut at the gradient all-reduce points (RCCL over the flat arenas) into several
+graphs.  Configurations outside this shape (conditional layers, LayerNorm, non-ReLU activations) use the module path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, dist as mdist, rng
+from .constants import REGISTRY_KEYS as RK
+from .modules.base.components import Adversarial, FCBlock, _identity
+from .optim import HipAdam
+
+NT, NN, TN = _lib.GEMM_NT, _lib.GEMM_NN, _lib.GEMM_TN
+RAW = _lib.GEMM_RAW_SLABS
+ACC = _lib.GEMM_ACCUMULATE
+RELU = _lib.GEMM_RELU
+MAX_POINTER_PLANS = 8
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _LayerRef:
+    """One FCBlock layer bound to its parameter / gradient-arena tensors."""
+
+    def __init__(self, seq: nn.Sequential, grad_of, return_hidden: bool):
+        lin = seq.lin
+        self.n_in, self.n_out = lin.in_features, lin.out_features
+        self.W, self.b = lin.weight, lin.bias
+        self.gW, self.gb = grad_of(lin.weight), grad_of(lin.bias)
+        bn = getattr(seq, "bn", None)
+        self.bn = bn
+        if bn is not None:
+            self.ggamma, self.gbeta = grad_of(bn.weight), grad_of(bn.bias)
+        self.relu = isinstance(getattr(seq, "af", None), nn.ReLU)
+        dr = getattr(seq, "dr", None)
+        self.p = float(dr.p) if dr is not None else 0.0
+        self.return_hidden = return_hidden and hasattr(seq, "af")
+
+
+def _supported_block(block: FCBlock) -> bool:
+    for seq in block.fc_layers:
+        if hasattr(seq, "ln"):
+            return False
+        af = getattr(seq, "af", None)
+        if af is not None and not isinstance(af, nn.ReLU):
+            return False
+    return True
 
 
 class StepEngine:
     @staticmethod
-    def try_build(model):
-        return None
+    def try_build(model) -> Optional["StepEngine"]:
+        m = model.module
+        if getattr(m.vae, "conditionals", None) is not None:
+            return None
+        if m.vae.encoder.z_transformation is not _identity:
+            return None
+        blocks = [m.vae.encoder.fc, m.vae.decoder]
+        for e in m.experts.values():
+            blocks += [e.encoder, e.decoder]
+        for adv in m.adversarials:
+            blocks.append(adv.encoder)
+            for h in adv.heads.values():
+                if len(h.fc_layers) != 1 or len(list(h.fc_layers[0].children())) != 1:
+                    return None
+        if not all(_supported_block(b) for b in blocks):
+            return None
+        opts = model.optimizers()
+        if not all(isinstance(o, HipAdam) and o._hip for o in opts):
+            return None
+        return StepEngine(model)
+
+    def __init__(self, model):
+        self.model = model
+        self.lib = _lib.load()
+        self.device = next(model.parameters()).device
+        self.opts = model.get_optimizers()
+        self._grad_of: Dict[int, torch.Tensor] = {}
+        for opt in model.optimizers():
+            for i, p in enumerate(opt.arena.params):
+                self._grad_of[id(p)] = opt.arena.grad_view(i)
+        self._pool: Dict[tuple, torch.Tensor] = {}
+        self._plans: Dict[tuple, "_Plan"] = {}
+        self._ptr_seen: Dict[tuple, int] = {}
+        self.klw_dev = torch.ones(1, dtype=torch.float32, device=self.device)
+        self._klw_host = None
+        self.world = mdist.world_size()
+
+    # ------------------------------------------------------------------------------------------------ buffers
+    def buf(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
+        """Engine-level scratch pool: every plan of the same geometry shares its transient buffers (plans never
+        overlap in time on the stream)."""
+        key = (name, tuple(int(s) for s in shape), dtype)
+        t = self._pool.get(key)
+        if t is None:
+            t = torch.zeros(key[1], dtype=dtype, device=self.device)
+            self._pool[key] = t
+        return t
+
+    def grad_of(self, p: torch.Tensor) -> torch.Tensor:
+        return self._grad_of[id(p)]
+
+    # --------------------------------------------------------------------------------------------------- step
+    def training_step(self, x: torch.Tensor, metadata, expert_id: str) -> None:
+        model = self.model
+        if x.layout == torch.sparse_csr:
+            x = x.to_dense()
+        if x.dtype != torch.float32 or x.dim() != 2 or (x.shape[1] > 1 and x.stride(1) != 1):
+            x = x.float().contiguous()
+        enc_mod = model.module.vae.encoder
+        expert = model.module.experts[expert_id]
+        explicit = enc_mod.explicit_eps is not None or expert.encoder.explicit_masks is not None
+        K = int(enc_mod.n_samples)
+        if enc_mod.explicit_eps is not None and enc_mod.explicit_eps.dim() == 3:
+            K = enc_mod.explicit_eps.shape[0]
+        B = x.shape[0]
+        # plan selection: graphs are keyed by the input pointer once a pointer has been seen twice (resident
+        # batches); otherwise the batch is copied into a static buffer.
+        pkey = (expert_id, B, K, explicit, x.data_ptr(), x.stride(0))
+        seen = self._ptr_seen.get(pkey, 0)
+        self._ptr_seen[pkey] = seen + 1
+        n_ptr_plans = sum(1 for k in self._plans if k[4] != 0)
+        if pkey in self._plans or (seen >= 1 and n_ptr_plans < MAX_POINTER_PLANS):
+            key, x_in = pkey, x
+        else:
+            key = (expert_id, B, K, explicit, 0, 0)
+            x_in = self.buf(f"x_static.{expert_id}", (B, x.shape[1]))
+            x_in.copy_(x)
+            if len(self._ptr_seen) > 4096:
+                self._ptr_seen.clear()
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = _Plan(self, expert_id, B, K, explicit, x_in)
+            self._plans[key] = plan
+        # per-step host values -> device scalars
+        klw = float(model.kl_annealing_fn.kl_weight)
+        if klw != self._klw_host:
+            self.klw_dev.fill_(klw)
+            self._klw_host = klw
+        if explicit:
+            plan.load_explicit_noise(enc_mod, expert)
+        if plan.has_adv:
+            plan.load_labels(metadata)
+        plan.run()
+        model.kl_annealing_fn.step()
+        plan.log(model, expert_id)
+
+
+class _Plan:
+    def __init__(self, eng: StepEngine, eid: str, B: int, K: int, explicit: bool, x: torch.Tensor):
+        self.eng, self.eid, self.B, self.K, self.explicit = eng, eid, B, K, explicit
+        self.x = x
+        self.R = B * K
+        model = eng.model
+        m = model.module
+        self.lib = eng.lib
+        g = eng.grad_of
+        exp = m.experts[eid]
+
+        def refs(block: FCBlock):
+            return [_LayerRef(seq, g, block.config.return_hidden[i]) for i, seq in enumerate(block.fc_layers)]
+
+        self.enc_layers = refs(exp.encoder) + refs(m.vae.encoder.fc)
+        self.n_expert_enc = len(exp.encoder.fc_layers)
+        self.dec_layers = refs(m.vae.decoder) + refs(exp.decoder)
+        self.G = exp.decoder.config.layers[-1]
+        self.Z = m.vae.encoder.mean_encoder.out_features
+        self.var_eps = float(m.vae.encoder.var_eps)
+        self.hidden_z = bool(m.vae.encoder.hidden_z)
+        self.mean_enc, self.var_enc = m.vae.encoder.mean_encoder, m.vae.encoder.var_encoder
+        self.advs = list(m.adversarials)
+        self.has_adv = len(self.advs) > 0
+        self.adv_weight = float(model.adv_weight)
+        self.opt_vae = eng.opts["vae"]
+        self.opt_exp = eng.opts["experts"][eid]
+        self.opt_adv = list(eng.opts.get("adversarials", {}).values()) if self.has_adv else []
+        ac = model.autograd_config
+        self.clip_vae = float(ac.vae_gradient_clip.val) if ac.vae_gradient_clip and ac.vae_gradient_clip.val else 0.0
+        self.clip_exp = float(ac.expert_gradient_clip.val) if ac.expert_gradient_clip and ac.expert_gradient_clip.val else 0.0
+        self.clip_adv = (float(ac.adversarial_gradient_clip.val)
+                         if ac.adversarial_gradient_clip and ac.adversarial_gradient_clip.val else 0.0)
+        self.conditions = list(Adversarial.labels.keys()) if self.has_adv else []
+        self.metric_slots: Dict[str, int] = {}
+        self.segments: List = []  # list of closure lists, separated by ("allreduce", opt) markers
+        self._cur: List = []
+        self._ws_bytes = 0
+        self._slab_floats = 0
+        self._graphs: Optional[list] = None
+        self._runs = 0
+        self.metrics = eng.buf("metrics", (256,))
+        self.rng_state = rng.state(eng.device)
+        self._build()
+
+    # ------------------------------------------------------------------------------------------- program building
+    def _emit(self, fn, *args):
+        lib_fn = fn
+
+        def call():
+            rc = lib_fn(*args, _s())
+            if rc != 0:
+                raise _lib.HipLibraryError(f"{lib_fn.__name__} failed with code {rc}")
+
+        self._cur.append(call)
+
+    def _cut(self, marker):
+        self.segments.append(self._cur)
+        self.segments.append(marker)
+        self._cur = []
+
+    def slot(self, name: str) -> int:
+        if name not in self.metric_slots:
+            self.metric_slots[name] = 8 + len(self.metric_slots)
+            assert self.metric_slots[name] < 256
+        return self.metric_slots[name]
+
+    def mptr(self, name: str) -> int:
+        return self.metrics.data_ptr() + 4 * self.slot(name)
+
+    def _plan_gemm(self, layout, M, N, K):
+        tile, sk = C.c_int(0), C.c_int(0)
+        self.lib.mmvae_gemm_plan(layout, M, N, K, C.byref(tile), C.byref(sk))
+        return sk.value
+
+    def gemm(self, layout, M, N, K, A, lda, Bm, ldb, Cm, ldc, bias=None, flags=0, alpha=1.0):
+        """Complete GEMM (internal split-K reduce through the shared workspace when the plan asks for it)."""
+        sk = self._plan_gemm(layout, M, N, K)
+        nbytes = self.lib.mmvae_gemm_workspace_bytes(layout, M, N, K, sk)
+        self._ws_bytes = max(self._ws_bytes, nbytes)
+        self._emit_gemm(layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, sk, True)
+
+    def gemm_raw(self, layout, M, N, K, A, lda, Bm, ldb) -> int:
+        """Raw split-K slabs into the shared slab buffer; returns the slab count."""
+        sk = self._plan_gemm(layout, M, N, K)
+        self._slab_floats = max(self._slab_floats, sk * M * N)
+        self._emit_gemm(layout, M, N, K, 1.0, A, lda, Bm, ldb, None, N, None, RAW, sk, False)
+        return sk
+
+    def _emit_gemm(self, layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, sk, use_ws):
+        plan = self
+
+        def call():
+            ws = plan.ws
+            c_ptr = _p(Cm) if Cm is not None else plan.slab.data_ptr()
+            rc = plan.lib.mmvae_gemm_f32(layout, M, N, K, alpha, _p(A), lda, _p(Bm), ldb, c_ptr, ldc, _p(bias), flags, sk,
+                                         ws.data_ptr() if use_ws else None, ws.numel() * 4 if use_ws else 0, _s())
+            if rc != 0:
+                raise _lib.HipLibraryError(f"mmvae_gemm_f32 failed with code {rc} (layout {layout}, {M}x{N}x{K})")
+
+        self._cur.append(call)
+
+    # ---- one FCBlock layer forward: cur [rows, n_in] -> l.d
+    def fwd_layer(self, tag: str, l: _LayerRef, cur: torch.Tensor, ld_cur: int, rows: int, training: bool = True):
+        eng = self.eng
+        l.inp, l.ld_inp, l.rows = cur, ld_cur, rows
+        l.d = eng.buf(f"{tag}.d", (rows, l.n_out))
+        l.z = eng.buf(f"{tag}.z", (rows, l.n_out)) if l.bn is not None else None
+        l.mean = eng.buf(f"{tag}.mean", (l.n_out,)) if l.bn is not None else None
+        l.invstd = eng.buf(f"{tag}.invstd", (l.n_out,)) if l.bn is not None else None
+        l.mask = eng.buf(f"{tag}.mask", (rows, l.n_out), torch.uint8) if l.p > 0 else None
+        l.a = eng.buf(f"{tag}.a", (rows, l.n_out)) if (l.p > 0 and l.return_hidden) else None
+        l.dz = eng.buf(f"{tag}.dz", (rows, l.n_out))
+        self._fcws_bytes = max(getattr(self, "_fcws_bytes", 0), self.lib.mmvae_fc_workspace_bytes(rows, l.n_out))
+        sk = self._plan_gemm(NT, rows, l.n_out, l.n_in)
+        if l.bn is None and l.p == 0 and sk == 1:
+            self.gemm(NT, rows, l.n_out, l.n_in, cur, ld_cur, l.W, l.n_in, l.d, l.n_out, bias=l.b,
+                      flags=RELU if l.relu else 0)
+            return l.d
+        S = self.gemm_raw(NT, rows, l.n_out, l.n_in, cur, ld_cur, l.W, l.n_in)
+        bnp = None
+        if l.bn is not None:
+            bn = l.bn
+            bnp = _lib.BnParams(_p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
+                                _p(bn.num_batches_tracked), float(bn.momentum), float(bn.eps))
+            l._bnp = bnp  # keep the struct alive for the lifetime of the plan
+        plan = self
+
+        def call():
+            rc = plan.lib.mmvae_fc_epilogue_fwd(rows, l.n_out, plan.slab.data_ptr(), l.n_out, S, _p(l.b),
+                                                C.byref(bnp) if bnp is not None else None, 1, int(l.relu), _p(l.mask),
+                                                l.p, _p(l.z), _p(l.a), _p(l.d), l.n_out, _p(l.mean), _p(l.invstd),
+                                                plan.fcws.data_ptr(), plan.fcws.numel() * 4, _s())
+            if rc != 0:
+                raise _lib.HipLibraryError(f"mmvae_fc_epilogue_fwd failed with code {rc}")
+
+        self._cur.append(call)
+        return l.d
+
+    # ---- one layer backward.  din: tensor [rows, n_out] or None (= shared slab buffer holding S_in raw slabs)
+    def bwd_layer(self, l: _LayerRef, din, S_in: int, addend=None, need_dx: str = "raw", dx_out=None, dx_flags=0,
+                  dx_alpha=1.0):
+        rows = l.rows
+        plan = self
+        relu_src = l.a if l.a is not None else l.d
+        has_bn = l.bn is not None
+
+        def call():
+            din_ptr = _p(din) if din is not None else plan.slab.data_ptr()
+            rc = plan.lib.mmvae_fc_epilogue_bwd(
+                rows, l.n_out, din_ptr, l.n_out, S_in, _p(addend), None, _p(l.mask), l.p, int(l.relu),
+                _p(relu_src) if l.relu else None, _p(l.z), _p(l.bn.weight) if has_bn else None, _p(l.mean),
+                _p(l.invstd), int(has_bn), _p(l.dz), l.n_out, _p(l.gb), _p(l.ggamma) if has_bn else None,
+                _p(l.gbeta) if has_bn else None, plan.fcws.data_ptr(), plan.fcws.numel() * 4, _s())
+            if rc != 0:
+                raise _lib.HipLibraryError(f"mmvae_fc_epilogue_bwd failed with code {rc}")
+
+        self._cur.append(call)
+        # dW[n_out, n_in] = dz^T[n_out, rows] . inp[rows, n_in]  -> straight into the gradient arena
+        self.gemm(TN, l.n_out, l.n_in, rows, l.dz, l.n_out, l.inp, l.ld_inp, l.gW, l.n_in)
+        if need_dx == "raw":
+            return self.gemm_raw(NN, rows, l.n_in, l.n_out, l.dz, l.n_out, l.W, l.n_in)
+        if need_dx == "full":
+            self.gemm(NN, rows, l.n_in, l.n_out, l.dz, l.n_out, l.W, l.n_in, dx_out, l.n_in, flags=dx_flags,
+                      alpha=dx_alpha)
+        return 0
+
+    def _emit_fc_bwd(self, rows, N, din, addend, row_scale, dz_out, dbias):
+        """Plain (no BN / ReLU / mask) column pass: dz = row_scale * (din + addend) (optional), dbias = column sums."""
+        plan = self
+        self._fcws_bytes = max(getattr(self, "_fcws_bytes", 0), self.lib.mmvae_fc_workspace_bytes(rows, N))
+
+        def call():
+            rc = plan.lib.mmvae_fc_epilogue_bwd(rows, N, _p(din), N, 1, _p(addend), _p(row_scale), None, 0.0, 0, None, None,
+                                                None, None, None, 0, _p(dz_out), N, _p(dbias), None, None,
+                                                plan.fcws.data_ptr(), plan.fcws.numel() * 4, _s())
+            if rc != 0:
+                raise _lib.HipLibraryError(f"mmvae_fc_epilogue_bwd (column sum) failed with code {rc}")
+
+        self._cur.append(call)
+
+    def optimizer(self, opt: HipAdam, max_norm: float, advance: bool = True, step: bool = True):
+        a = opt.arena
+        g = opt.param_groups[0]
+        b1, b2 = g["betas"]
+        gs = 1.0 / self.eng.world
+        npart = self.lib.mmvae_sqnorm_partials(a.numel)
+        if self.eng.world > 1:
+            self._cut(("allreduce", opt))
+        self._emit(self.lib.mmvae_grad_sqnorm, a.numel, _p(a.grad), _p(opt.partials))
+        flags = _lib.PREPARE_NORM | (_lib.PREPARE_ADVANCE if (advance and step) else 0)
+        self._emit(self.lib.mmvae_adam_prepare, npart, _p(opt.partials), max_norm, gs, b1, b2, _p(opt.state_dev), flags)
+        if step:
+            self._emit(self.lib.mmvae_adam_step, a.numel, _p(a.data), _p(a.grad), _p(a.exp_avg), _p(a.exp_avg_sq),
+                       _p(opt.state_dev), g["lr"], b1, b2, g["eps"], g["weight_decay"], gs)
+
+    def copy_scalar(self, src_ptr: int, dst_name: str):
+        self._emit(self.lib.mmvae_axpby, 1, 1.0, src_ptr, 0.0, self.mptr(dst_name))
+
+    # ---------------------------------------------------------------------------------------------------- build
+    def _build(self):
+        eng, lib = self.eng, self.lib
+        B, K, R, Z, G = self.B, self.K, self.R, self.Z, self.G
+        x, ldx = self.x, self.x.stride(0) if self.x.shape[0] > 1 else self.x.shape[1]
+        self.eps = eng.buf("eps", (K, B, Z))
+
+        # ---- forward, encoder side
+        cur, ld = x, ldx
+        for i, l in enumerate(self.enc_layers):
+            cur = self.fwd_layer(f"{self.eid}.enc{i}" if i < self.n_expert_enc else f"vae.enc{i}", l, cur, ld, B)
+            ld = l.n_out
+        q, HV = cur, self.enc_layers[-1].n_out
+        # ---- heads + reparameterisation
+        self.mu = eng.buf("mu", (B, Z))
+        self.a_raw = eng.buf("a_raw", (B, Z))
+        self.std = eng.buf("std", (B, Z))
+        self.z = eng.buf("z", (K, B, Z))
+        self.kl_row = eng.buf("kl_row", (B,))
+        self.stat = eng.buf("stat", (2, B))
+        self.gemm(NT, B, Z, HV, q, HV, self.mean_enc.weight, HV, self.mu, Z, bias=self.mean_enc.bias)
+        self.gemm(NT, B, Z, HV, q, HV, self.var_enc.weight, HV, self.a_raw, Z, bias=self.var_enc.bias)
+        self._emit(lib.mmvae_reparam_kl_fwd, B, Z, K, _p(self.mu), _p(self.a_raw), _p(self.eps), self.var_eps,
+                   _p(self.std), _p(self.z), _p(self.kl_row), _p(self.stat))
+        # ---- forward, decoder side (rows R = K*B)
+        cur, ld = self.z, Z
+        for i, l in enumerate(self.dec_layers[:-1]):
+            cur = self.fwd_layer(f"{self.eid}.dec{i}.K{K}", l, cur, ld, R)
+            ld = l.n_out
+        last = self.dec_layers[-1]
+        fused_last = last.relu and last.bn is None and last.p == 0
+        if not fused_last:
+            raise _lib.HipLibraryError("engine: the last decoder layer must be Linear+ReLU (fused recon epilogue)")
+        last.inp, last.ld_inp, last.rows = cur, ld, R
+        T = lib.mmvae_recon_tiles(G)
+        self.dP = eng.buf(f"dP.{G}", (R, G))
+        self.se_part = eng.buf(f"se_part.{G}", (T, R))
+        self.w = eng.buf("w", (R,))
+        self._emit(lib.mmvae_decoder_recon_rows_f32, R, B, G, last.n_in, _p(cur), ld, _p(last.W), last.n_in,
+                   _p(last.b), _p(x), ldx, None, 0, _p(self.dP), G, _p(self.se_part))
+        self.recon_row = eng.buf("recon_row", (B,))
+        self._emit(lib.mmvae_elbo_finalize, B, K, T, _p(self.se_part), _p(self.kl_row), _p(self.stat), Z,
+                   _p(eng.klw_dev), 1.0, _p(self.metrics), _p(self.w), _p(self.recon_row))
+        # total loss slot starts as the ELBO loss
+        self._emit(lib.mmvae_axpby, 1, 1.0, _p(self.metrics), 0.0, self.mptr("total_loss"))
+
+        # ---- adversarial phases
+        hidden = [l.a if l.a is not None else l.d for l in self.enc_layers if l.return_hidden]
+        if self.hidden_z:
+            hidden.append(self.z)  # first sample (rows 0..B-1)
+        self.adv_grad_into: Dict[int, torch.Tensor] = {}
+        self.dz_lat = eng.buf("dz_lat", (R, Z))
+        if self.has_adv:
+            self._build_adversaries(hidden)
+
+        # ---- backward, decoder side
+        if K > 1:
+            # dP <- diag(w) dP in place (w = softmax weights of the K-sample bound), dbias = column sums
+            self._emit_fc_bwd(R, G, self.dP, None, self.w, self.dP, last.gb)
+        else:
+            self._emit_fc_bwd(R, G, self.dP, None, None, None, last.gb)
+        self.gemm(TN, G, last.n_in, R, self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in)
+        S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
+        rest = self.dec_layers[:-1]
+        for j in range(len(rest) - 1, -1, -1):
+            l = rest[j]
+            if j > 0:
+                S = self.bwd_layer(l, None, S, need_dx="raw")
+            else:
+                self.bwd_layer(l, None, S, need_dx="full", dx_out=self.dz_lat)
+        if not rest:
+            raise _lib.HipLibraryError("engine: decoder needs at least two layers")
+        # gradient-reversed adversary gradient on z (first sample) joins here
+        zi = self.adv_grad_into.get(id(self.z))
+        if zi is not None:
+            self._emit(lib.mmvae_axpby, B * Z, 1.0, _p(zi), 1.0, _p(self.dz_lat))
+        # ---- reparameterisation + heads backward
+        self.dmu = eng.buf("dmu", (B, Z))
+        self.da = eng.buf("da", (B, Z))
+        self.dq = eng.buf("dq", (B, HV))
+        self._emit(lib.mmvae_reparam_kl_bwd, B, Z, K, _p(self.mu), _p(self.std), _p(self.eps), _p(self.dz_lat), None,
+                   None, None, _p(eng.klw_dev), 1.0 / B, self.var_eps, _p(self.dmu), _p(self.da))
+        for dy, lin in ((self.dmu, self.mean_enc), (self.da, self.var_enc)):
+            self._emit_fc_bwd(B, Z, dy, None, None, None, eng.grad_of(lin.bias))
+            self.gemm(TN, Z, HV, B, dy, Z, q, HV, eng.grad_of(lin.weight), HV)
+        self.gemm(NN, B, HV, Z, self.dmu, Z, self.mean_enc.weight, HV, self.dq, HV)
+        self.gemm(NN, B, HV, Z, self.da, Z, self.var_enc.weight, HV, self.dq, HV, flags=ACC)
+        # ---- backward, encoder side
+        din, S = self.dq, 1
+        for j in range(len(self.enc_layers) - 1, -1, -1):
+            l = self.enc_layers[j]
+            hid = l.a if l.a is not None else l.d
+            addend = self.adv_grad_into.get(id(hid)) if l.return_hidden else None
+            S_next = self.bwd_layer(l, din, S, addend=addend, need_dx="raw" if j > 0 else "none")
+            din, S = None, S_next
+        # ---- clip + Adam (reference order: clip vae, clip expert, step vae, step expert)
+        self.optimizer(self.opt_vae, self.clip_vae)
+        self.optimizer(self.opt_exp, self.clip_exp)
+        self.segments.append(self._cur)
+        self._cur = []
+        # noise: Philox fills (production) or explicit buffers (parity mode), at the head of the program
+        if not self.explicit:
+            n_max = K * B * Z
+            for i, l in enumerate(self.enc_layers + self.dec_layers[:-1]):
+                if l.mask is not None:
+                    n_max = max(n_max, l.mask.numel())
+                    self._emit(lib.mmvae_philox_keep_mask, l.mask.numel(), l.p, _p(l.mask), _p(self.rng_state),
+                               rng.STREAM_DROPOUT + i, 0)
+            self._emit(lib.mmvae_philox_normal, K * B * Z, _p(self.eps), _p(self.rng_state), rng.STREAM_NORMAL, 0)
+            self._emit(lib.mmvae_philox_advance, _p(self.rng_state), (n_max + 3) // 4)
+            self.segments[0] = self._cur + self.segments[0]
+            self._cur = []
+        self.fcws = eng.buf("fc_ws", (max(getattr(self, "_fcws_bytes", 0) // 4, 1),))
+        for key, t in eng._pool.items():
+            if key[0] == "fc_ws" and t.numel() > self.fcws.numel():
+                self.fcws = t
+        self.ws = eng.buf("gemm_ws", (max(self._ws_bytes // 4, 1),))
+        self.slab = eng.buf("gemm_slabs", (max(self._slab_floats, 1),))
+        # a shared buffer may have been re-allocated larger by a later plan: always take the biggest one
+        for key, t in eng._pool.items():
+            if key[0] == "gemm_ws" and t.numel() > self.ws.numel():
+                self.ws = t
+            if key[0] == "gemm_slabs" and t.numel() > self.slab.numel():
+                self.slab = t
+
+    def _build_adversaries(self, hidden):
+        eng, lib, B = self.eng, self.lib, self.B
+        self.labels_dev = {c: eng.buf(f"labels.{c}", (B,), torch.int64) for c in self.conditions}
+        self.n_adv = min(len(hidden), len(self.advs))
+        for i, (h, adv) in enumerate(zip(hidden, self.advs), start=1):
+            g = eng.grad_of
+            layers = [_LayerRef(seq, g, False) for seq in adv.encoder.fc_layers]
+            n_e = layers[-1].n_out
+            heads = {c: adv.heads[c].fc_layers[0].lin for c in self.conditions}
+            logits = {c: eng.buf(f"adv{i}.logits.{c}", (B, heads[c].out_features)) for c in self.conditions}
+            dlogits = {c: eng.buf(f"adv{i}.dlogits.{c}", (B, heads[c].out_features)) for c in self.conditions}
+            rows = eng.buf(f"adv{i}.ce_rows", (B,))
+            de = eng.buf(f"adv{i}.de", (B, n_e))
+            gh = eng.buf(f"adv{i}.gh", (B, layers[0].n_in))
+            opt = self.opt_adv[i - 1]
+            for phase in ("discriminator", "generator"):
+                gen = phase == "generator"
+                cur, ld = h, layers[0].n_in
+                for j, l in enumerate(layers):
+                    cur = self.fwd_layer(f"adv{i}.enc{j}", l, cur, ld, B)
+                    ld = l.n_out
+                e = cur
+                gscale = self.adv_weight if gen else 1.0
+                for ci, c in enumerate(self.conditions):
+                    lin = heads[c]
+                    Cn = lin.out_features
+                    self.gemm(NT, B, Cn, n_e, e, n_e, lin.weight, n_e, logits[c], Cn, bias=lin.bias)
+                    self._emit(lib.mmvae_cross_entropy_sum, B, Cn, _p(logits[c]), Cn, _p(self.labels_dev[c]), _p(rows),
+                               _p(dlogits[c]), Cn, None, gscale)
+                    self._emit(lib.mmvae_sum_f32, B, _p(rows), self.mptr(f"{phase}_{i}/{c}"), 0)
+                    self._emit(lib.mmvae_axpby, 1, 1.0, self.mptr(f"{phase}_{i}/{c}"), 1.0 if ci > 0 else 0.0,
+                               self.mptr(f"{phase}_{i}/summed"))
+                    # head backward
+                    self._emit_fc_bwd(B, Cn, dlogits[c], None, None, None, g(lin.bias))
+                    self.gemm(TN, Cn, n_e, B, dlogits[c], Cn, e, n_e, g(lin.weight), n_e)
+                    self.gemm(NN, B, n_e, Cn, dlogits[c], Cn, lin.weight, n_e, de, n_e, flags=ACC if ci > 0 else 0)
+                din, S = de, 1
+                for j in range(len(layers) - 1, -1, -1):
+                    l = layers[j]
+                    if j > 0:
+                        S = self.bwd_layer(l, din, S, need_dx="raw")
+                        din = None
+                    elif gen:
+                        # gradient reversal (components.py:889-899): d h = -alpha * d(adv loss)/d h, alpha = 1
+                        self.bwd_layer(l, din, S, need_dx="full", dx_out=gh, dx_alpha=-1.0)
+                    else:
+                        self.bwd_layer(l, din, S, need_dx="none")
+                if gen:
+                    self._emit(lib.mmvae_axpby, 1, self.adv_weight, self.mptr(f"generator_{i}/summed"), 1.0,
+                               self.mptr("total_loss"))
+                    self.optimizer(opt, 0.0, step=False)  # norm of the (never applied) generator-phase gradients
+                    self.copy_scalar(opt.state_dev.data_ptr() + 4, f"grad_norms/generator_{i}")
+                    self.adv_grad_into[id(h)] = gh
+                else:
+                    self.optimizer(opt, self.clip_adv)
+                    self.copy_scalar(opt.state_dev.data_ptr() + 4, f"grad_norms/discriminator_{i}")
+
+    # ------------------------------------------------------------------------------------------------ execution
+    def load_explicit_noise(self, enc_mod, expert):
+        eps = enc_mod.explicit_eps
+        if eps is not None:
+            self.eps.copy_(eps.reshape(self.eps.shape))
+        masks = expert.encoder.explicit_masks or {}
+        for i, l in enumerate(self.enc_layers[: self.n_expert_enc]):
+            if l.mask is not None:
+                if i not in masks:
+                    raise KeyError(f"explicit noise mode: no keep mask for encoder layer {i}")
+                l.mask.copy_(masks[i])
+
+    def load_labels(self, metadata):
+        cache = metadata.attrs.get("_mmvae_labels") if hasattr(metadata, "attrs") else None
+        if cache is None:
+            cache = {c: torch.tensor([Adversarial.labels[c][v] for v in metadata[c].values], dtype=torch.int64).pin_memory()
+                     for c in self.conditions}
+            try:
+                metadata.attrs["_mmvae_labels"] = cache
+            except Exception:  # noqa: BLE001
+                pass
+        for c in self.conditions:
+            self.labels_dev[c].copy_(cache[c], non_blocking=True)
+
+    def _run_segments_eager(self):
+        for seg in self.segments:
+            if isinstance(seg, tuple):
+                self._collective(seg)
+            else:
+                for call in seg:
+                    call()
+
+    def _collective(self, marker):
+        kind, opt = marker
+        if opt.reducer is not None:
+            opt.reducer.launch(opt.arena.grad)
+            opt.reducer.wait()
+
+    def run(self):
+        self._runs += 1
+        if self._runs == 1:
+            self._run_segments_eager()  # a real step; also loads every code object before capture
+            return
+        if self._graphs is None:
+            torch.cuda.synchronize()
+            graphs = []
+            for seg in self.segments:
+                if isinstance(seg, tuple):
+                    graphs.append(seg)
+                    continue
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for call in seg:
+                        call()
+                graphs.append(g)
+            self._graphs = graphs
+        for g in self._graphs:
+            if isinstance(g, tuple):
+                self._collective(g)
+            else:
+                g.replay()
+
+    def log(self, model, eid: str):
+        m = self.metrics.clone()  # one small D2D copy; logged scalars are views of it (no host sync)
+        stage = model.stage_name
+        main = {RK.LOSS: m[self.slot("total_loss")], RK.RECON_LOSS: m[1], RK.KL_LOSS: m[2], RK.KL_WEIGHT: m[3],
+                "Mean": m[4], "Variance": m[5]}
+        for i in range(1, getattr(self, "n_adv", 0) + 1):
+            for phase in ("discriminator", "generator"):
+                tags = [f"{phase}_{i}", stage, eid, RK.ADV_LOSS]
+                for c in self.conditions + ["summed"]:
+                    model.auto_log({c: m[self.slot(f"{phase}_{i}/{c}")]}, tags=tags, key_pos="last")
+                model.log(f"grad_norms/{phase}_{i}", m[self.slot(f"grad_norms/{phase}_{i}")])
+        model.log("grad_norms/vae", self.opt_vae.state_dev[1].clone())
+        model.log(f"grad_norms/expert_{eid}", self.opt_exp.state_dev[1].clone())
+        model.auto_log(main, tags=[stage, eid])

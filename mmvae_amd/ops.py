@@ -50,9 +50,9 @@ def _mat(t: torch.Tensor, name: str) -> Tuple[int, int, int]:
     return t.shape[0], t.shape[1], ld
 
 
-def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only per-device scratch arena (split-K slabs).  Stream-ordered use only."""
-    key = (torch.device(device).index, _stream())
+def workspace(nbytes: int, device, kind: str = "gemm") -> torch.Tensor:
+    """Grow-only per-device scratch arena (split-K slabs / column partials).  Stream-ordered use only."""
+    key = (kind, torch.device(device).index, _stream())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty(max(nbytes // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
@@ -223,9 +223,12 @@ def fc_epilogue_fwd(
         )
     if has_drop and (tuple(keep_mask.shape) != (B, N) or not keep_mask.is_contiguous()):
         raise ValueError("keep_mask must be contiguous [B,N] uint8")
+    nws = lib.mmvae_fc_workspace_bytes(B, N)
+    ws = workspace(nws, dev, "fc")
     rc = lib.mmvae_fc_epilogue_fwd(
         B, N, _ptr(inp), N, S, _ptr(bias), C.byref(bnp) if bnp is not None else None, int(training), int(relu),
-        _ptr(keep_mask), float(dropout_p), _ptr(z), _ptr(a), _ptr(d), N, _ptr(mean), _ptr(invstd), _stream(),
+        _ptr(keep_mask), float(dropout_p), _ptr(z), _ptr(a), _ptr(d), N, _ptr(mean), _ptr(invstd), _ptr(ws), nws,
+        _stream(),
     )
     _lib.check(rc, "mmvae_fc_epilogue_fwd")
     return {"z": z, "a": a if a is not None else d, "d": d, "mean": mean, "invstd": invstd}
@@ -271,10 +274,12 @@ def fc_epilogue_bwd(
     if has_bn:
         dgamma = dgamma_out if dgamma_out is not None else torch.empty(N, dtype=torch.float32, device=dev)
         dbeta = dbeta_out if dbeta_out is not None else torch.empty(N, dtype=torch.float32, device=dev)
+    nws = lib.mmvae_fc_workspace_bytes(B, N)
+    ws = workspace(nws, dev, "fc")
     rc = lib.mmvae_fc_epilogue_bwd(
         B, N, _ptr(din), N, S, _ptr(addend), _ptr(row_scale), _ptr(keep_mask), float(dropout_p), int(relu), _ptr(a),
         _ptr(z), _ptr(gamma), _ptr(mean), _ptr(invstd), int(has_bn), _ptr(dz), N, _ptr(dbias), _ptr(dgamma),
-        _ptr(dbeta), _stream(),
+        _ptr(dbeta), _ptr(ws), nws, _stream(),
     )
     _lib.check(rc, "mmvae_fc_epilogue_bwd")
     return dz, dbias, dgamma, dbeta
@@ -376,8 +381,9 @@ def elbo_finalize(se_part: torch.Tensor, kl_row, stat_row, *, B: int, K: int = 1
     T = se_part.shape[0]
     out = torch.empty(6, dtype=torch.float32, device=se_part.device)
     w = torch.empty(K * B, dtype=torch.float32, device=se_part.device) if want_w else None
+    recon_row = torch.empty(B, dtype=torch.float32, device=se_part.device)
     rc = lib.mmvae_elbo_finalize(B, K, T, _ptr(se_part), _ptr(kl_row), _ptr(stat_row), Z, _ptr(kl_weight_dev),
-                                 float(kl_weight), _ptr(out), _ptr(w), _stream())
+                                 float(kl_weight), _ptr(out), _ptr(w), _ptr(recon_row), _stream())
     _lib.check(rc, "mmvae_elbo_finalize")
     return out, w
 
