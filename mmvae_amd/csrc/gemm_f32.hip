@@ -56,7 +56,7 @@ struct GemmArgs {
     int64_t slab_stride;   // elements between split-K slabs of C (0 when splitk == 1)
     float alpha;
     unsigned flags;
-    int aligned;           // A, B 16-byte aligned with leading dimensions % 4 == 0
+    int aligned;           // 1: A, B 16-byte aligned with leading dimensions % 4 == 0; 2: and M, N, K % 4 == 0
     // recon epilogue
     const float* x;
     float* xhat;
@@ -67,54 +67,51 @@ struct GemmArgs {
 };
 
 // HBM -> registers.  r0: first row (KC) / column (RC) of this tile along the non-K axis, Rtot its extent.
-// Branch-free: FAST (block-uniform: tile fully inside the matrix, 16-byte aligned rows) issues plain 16-byte loads
-// back to back; otherwise indices are clamped into the matrix and out-of-range values zeroed with selects.
-template <int FORM, int R, int BK, bool FAST, int NV>
-__device__ __forceinline__ void load_tile(f32x4 (&reg)[NV], const float* __restrict__ P, int64_t ld, int r0, int Rtot,
-                                          int k0, int Kend, int tid) {
-    static_assert(NV == Tile<FORM, R, BK>::VECS, "register tile size");
+// One code path, no branches: every 16-byte group is loaded from a clamped (always valid) address and a validity
+// mask is kept beside it; store_tile zeroes the out-of-matrix elements on the way to LDS.  Loads therefore issue back
+// to back and stay in flight across the k-tile's MFMAs (an exec-masked load per element, or a control-flow join
+// between loads and consumers, makes the compiler drain them one by one).
+//   VEC = true   A, B 16-byte aligned, leading dimensions and M, N, K multiples of 4: a group never straddles an edge
+//   VEC = false  anything else (e.g. 60530 / 52437-gene matrices): clamped element loads
+template <int FORM, int R, int BK, bool VEC, int NV>
+__device__ __forceinline__ void load_tile(f32x4 (&reg)[NV], unsigned (&valid)[NV], const float* __restrict__ P,
+                                          int64_t ld, int r0, int Rtot, int k0, int Kend, int tid) {
     using T = Tile<FORM, R, BK>;
+    static_assert(NV == T::VECS, "register tile size");
 #pragma unroll
     for (int i = 0; i < T::VECS; ++i) {
         const int f = tid + NT * i;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        unsigned vm = 0u;
         if (T::EXACT || f < T::NVEC) {
             const int run = f / T::C4, c4 = f % T::C4;
-            if (FORM == FORM_KC) {
-                const int gr = r0 + run, gk = k0 + c4 * 4;
-                if (FAST) {
-                    v = *reinterpret_cast<const f32x4*>(P + (int64_t)gr * ld + gk);
-                } else {
-                    const float* p = P + (int64_t)min(gr, Rtot - 1) * ld;
-                    const bool rv = gr < Rtot;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float t = p[min(gk + j, Kend - 1)];
-                        v[j] = (rv && gk + j < Kend) ? t : 0.f;
-                    }
-                }
+            // (o, x): index along the strided (outer) axis and along the contiguous axis, with their extents
+            const int o = (FORM == FORM_KC) ? r0 + run : k0 + run;
+            const int x = (FORM == FORM_KC) ? k0 + c4 * 4 : r0 + c4 * 4;
+            const int olim = (FORM == FORM_KC) ? Rtot : Kend;
+            const int xlim = (FORM == FORM_KC) ? Kend : Rtot;
+            const bool ov = o < olim;
+            const float* p = P + (int64_t)(ov ? o : olim - 1) * ld;
+            if (VEC) {
+                const bool full = ov && (x + 3 < xlim);
+                v = *reinterpret_cast<const f32x4*>(p + (full ? x : 0));
+                vm = full ? 0xFu : 0u;
             } else {
-                const int gk = k0 + run, gr = r0 + c4 * 4;
-                if (FAST) {
-                    v = *reinterpret_cast<const f32x4*>(P + (int64_t)gk * ld + gr);
-                } else {
-                    const float* p = P + (int64_t)min(gk, Kend - 1) * ld;
-                    const bool kv = gk < Kend;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float t = p[min(gr + j, Rtot - 1)];
-                        v[j] = (kv && gr + j < Rtot) ? t : 0.f;
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = p[min(x + j, xlim - 1)];
+                    vm |= (ov && x + j < xlim) ? (1u << j) : 0u;
                 }
             }
         }
         reg[i] = v;
+        valid[i] = vm;
     }
 }
 
-// registers -> LDS image
+// registers -> LDS image (zeroing out-of-matrix elements for the guarded modes)
 template <int FORM, int R, int BK, int NV>
-__device__ __forceinline__ void store_tile(float* S, const f32x4 (&reg)[NV], int tid) {
+__device__ __forceinline__ void store_tile(float* S, const f32x4 (&reg)[NV], const unsigned (&valid)[NV], int tid) {
     static_assert(NV == Tile<FORM, R, BK>::VECS, "register tile size");
     using T = Tile<FORM, R, BK>;
 #pragma unroll
@@ -122,10 +119,13 @@ __device__ __forceinline__ void store_tile(float* S, const f32x4 (&reg)[NV], int
         const int f = tid + NT * i;
         if (T::EXACT || f < T::NVEC) {
             const int run = f / T::C4, c4 = f % T::C4;
+            f32x4 v = reg[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ((valid[i] >> j) & 1u) ? v[j] : 0.f;
             if (FORM == FORM_KC)
-                *reinterpret_cast<f32x4*>(&S[run * T::KC_LD + c4 * 4]) = reg[i];
+                *reinterpret_cast<f32x4*>(&S[run * T::KC_LD + c4 * 4]) = v;
             else
-                *reinterpret_cast<f32x4*>(&S[run * R + c4 * 4]) = reg[i];
+                *reinterpret_cast<f32x4*>(&S[run * R + c4 * 4]) = v;
         }
     }
 }
@@ -148,7 +148,7 @@ __device__ __forceinline__ f32x4 load_frag(const float* S, int row, int kk, int 
 }
 
 // Block tile BM x BN, k-tile BK, 4 waves arranged WGM x WGN; each wave owns (BM/WGM) x (BN/WGN) as 32x32 MFMA blocks.
-template <int AFORM, int BFORM, int BM, int BN, int BK, int WGM, int WGN, int EPI>
+template <int AFORM, int BFORM, int BM, int BN, int BK, int WGM, int WGN, bool VEC, int EPI>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     static_assert(WGM * WGN == 4, "4 wavefronts per workgroup");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;  // wave tile
@@ -181,8 +181,6 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     int kt_end = kt_beg + g.ktiles_per_split;
     if (kt_end > g.ktiles) kt_end = g.ktiles;
     const int nkt = kt_end - kt_beg;
-    // block-uniform: may this block use the unguarded 16-byte loads (for k-tiles that lie fully inside K)?
-    const bool inner = g.aligned && (bm * BM + BM <= g.M) && (bn * BN + BN <= g.N);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -193,55 +191,41 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
             for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
 
     f32x4 ra[TA::VECS], rb[TB::VECS];
-    auto load_ab = [&](int kt) {
-        const int k0 = kt * BK;
-        if (inner && k0 + BK <= g.K) {
-            load_tile<AFORM, BM, BK, true>(ra, g.A, g.lda, bm * BM, g.M, k0, g.K, tid);
-            load_tile<BFORM, BN, BK, true>(rb, g.B, g.ldb, bn * BN, g.N, k0, g.K, tid);
-        } else {
-            load_tile<AFORM, BM, BK, false>(ra, g.A, g.lda, bm * BM, g.M, k0, g.K, tid);
-            load_tile<BFORM, BN, BK, false>(rb, g.B, g.ldb, bn * BN, g.N, k0, g.K, tid);
-        }
-    };
+    unsigned va[TA::VECS], vb[TB::VECS];
     if (nkt > 0) {
-        load_ab(kt_beg);
-        store_tile<AFORM, BM, BK>(As, ra, tid);
-        store_tile<BFORM, BN, BK>(Bs, rb, tid);
+        load_tile<AFORM, BM, BK, VEC>(ra, va, g.A, g.lda, bm * BM, g.M, kt_beg * BK, g.K, tid);
+        load_tile<BFORM, BN, BK, VEC>(rb, vb, g.B, g.ldb, bn * BN, g.N, kt_beg * BK, g.K, tid);
+        store_tile<AFORM, BM, BK>(As, ra, va, tid);
+        store_tile<BFORM, BN, BK>(Bs, rb, vb, tid);
         __syncthreads();
         for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
             const bool more = (kt + 1 < nkt);
-            if (more) load_ab(kt_beg + kt + 1);  // in flight during this k-tile's MFMAs
+            if (more) {  // next tile's loads: in flight during this k-tile's MFMAs
+                const int k0 = (kt_beg + kt + 1) * BK;
+                load_tile<AFORM, BM, BK, VEC>(ra, va, g.A, g.lda, bm * BM, g.M, k0, g.K, tid);
+                load_tile<BFORM, BN, BK, VEC>(rb, vb, g.B, g.ldb, bn * BN, g.N, k0, g.K, tid);
+            }
             const float* Ac = As + cur * A_FLOATS;
             const float* Bc = Bs + cur * B_FLOATS;
-            // fragments are fetched one k-group ahead of the MFMAs that consume them
-            f32x4 fa[2][TM], fb[2][TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[0][i] = load_frag<AFORM, BM, BK>(Ac, wm * WTM + i * 32 + l31, 0, half);
-#pragma unroll
-            for (int n = 0; n < TN; ++n) fb[0][n] = load_frag<BFORM, BN, BK>(Bc, wn * WTN + n * 32 + l31, 0, half);
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
-                const int c = kk & 1, nx = c ^ 1;
-                if (kk + 1 < KK) {
+                f32x4 fa[TM], fb[TN];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        fa[nx][i] = load_frag<AFORM, BM, BK>(Ac, wm * WTM + i * 32 + l31, kk + 1, half);
+                for (int i = 0; i < TM; ++i) fa[i] = load_frag<AFORM, BM, BK>(Ac, wm * WTM + i * 32 + l31, kk, half);
 #pragma unroll
-                    for (int n = 0; n < TN; ++n)
-                        fb[nx][n] = load_frag<BFORM, BN, BK>(Bc, wn * WTN + n * 32 + l31, kk + 1, half);
-                }
+                for (int n = 0; n < TN; ++n) fb[n] = load_frag<BFORM, BN, BK>(Bc, wn * WTN + n * 32 + l31, kk, half);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int n = 0; n < TN; ++n)
-                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][j], fb[c][n][j], acc[i][n], 0, 0, 0);
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[n][j], acc[i][n], 0, 0, 0);
             }
             if (more) {
-                store_tile<AFORM, BM, BK>(As + (cur ^ 1) * A_FLOATS, ra, tid);
-                store_tile<BFORM, BN, BK>(Bs + (cur ^ 1) * B_FLOATS, rb, tid);
+                store_tile<AFORM, BM, BK>(As + (cur ^ 1) * A_FLOATS, ra, va, tid);
+                store_tile<BFORM, BN, BK>(Bs + (cur ^ 1) * B_FLOATS, rb, vb, tid);
             }
             __syncthreads();
         }
@@ -352,21 +336,25 @@ TileShape tile_shape(int layout, int id) {
     return {64, 64, 4};
 }
 
-template <int AFORM, int BFORM, int EPI>
-int launch_gemm_forms(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) {
+template <int AFORM, int BFORM, bool VEC, int EPI>
+int launch_gemm_vec(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) {
     if (tile_id == 0)
-        hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, 128, 128, 32, 2, 2, EPI>), dim3(nblocks), dim3(NT), 0, s, g);
-    else if (tile_id == 1) {
-        if (AFORM == FORM_KC && BFORM == FORM_KC)
-            hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, 128, 160, 16, 4, 1, EPI>), dim3(nblocks), dim3(NT), 0, s,
-                               g);
-        else
-            hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, 128, 160, 32, 4, 1, EPI>), dim3(nblocks), dim3(NT), 0, s,
-                               g);
-    } else
-        hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, 64, 64, 32, 2, 2, EPI>), dim3(nblocks), dim3(NT), 0, s, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, 128, 128, 32, 2, 2, VEC, EPI>), dim3(nblocks), dim3(NT), 0, s,
+                           g);
+    else if (tile_id == 1)  // NT only (plan): BK = 16 keeps two workgroups resident per CU
+        hipLaunchKernelGGL((gemm_f32_kernel<FORM_KC, FORM_KC, 128, 160, 16, 4, 1, VEC, EPI>), dim3(nblocks), dim3(NT), 0,
+                           s, g);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, 64, 64, 32, 2, 2, VEC, EPI>), dim3(nblocks), dim3(NT), 0, s,
+                           g);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
+}
+
+template <int AFORM, int BFORM, int EPI>
+int launch_gemm_forms(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) {
+    return g.aligned == 2 ? launch_gemm_vec<AFORM, BFORM, true, EPI>(tile_id, g, nblocks, s)
+                          : launch_gemm_vec<AFORM, BFORM, false, EPI>(tile_id, g, nblocks, s);
 }
 
 int bk_of(int layout, int tile_id) { return (tile_id == 1 && layout == MMVAE_GEMM_NT) ? 16 : 32; }
@@ -476,6 +464,7 @@ extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, cons
     g.flags = flags;
     g.x_rows = 1;
     g.aligned = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+    if (g.aligned && M % 4 == 0 && N % 4 == 0 && K % 4 == 0) g.aligned = 2;
     if (raw) {
         g.C = C;
         g.ldc = ldc;
@@ -545,6 +534,7 @@ extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, 
     g.lddp = lddp;
     g.x_rows = x_rows;
     g.aligned = aligned16(h) && aligned16(W) && (ldh % 4 == 0) && (ldw % 4 == 0);
+    if (g.aligned && rows % 4 == 0 && G % 4 == 0 && H % 4 == 0) g.aligned = 2;
     return launch_gemm_forms<FORM_KC, FORM_KC, EPI_RECON>(1, g, g.mt * g.nt, (hipStream_t)stream);
 }
 
