@@ -1,0 +1,121 @@
+"""Data-parallel path on CPU with the gloo backend, world_size 2 (the N > 1 logic of bench.py / mmvae_amd.dist):
+bucketed all-reduce of the flat gradient arenas, gradient averaging folded into the optimiser, identical parameters
+on every rank, and equality with a hand-computed average of the per-shard gradients."""
+import os
+import socket
+import tempfile
+
+import pandas as pd
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import helpers as H
+from tests import mirror_utils as MU
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(case, tmpdir):
+    from mmvae_amd import backend
+
+    with backend.cpu_plumbing():
+        torch.manual_seed(0)
+        model = MU.build_mirror(case, "cpu", tmpdir)
+        model.train()
+        model.trainer.set_stage("training")
+        model.optimizers()
+    return model
+
+
+def _step(model, x, eps, mask, eid):
+    from mmvae_amd import backend
+
+    with backend.cpu_plumbing():
+        model.module.vae.encoder.explicit_eps = eps
+        model.module.experts[eid].encoder.explicit_masks = mask
+        model.training_step((x, pd.DataFrame({"dummy": [0] * x.shape[0]}), eid), 0)
+
+
+def _flat_params(model, case):
+    """All parameters except Linear biases that feed a BatchNorm (zero true gradient -> chaotic under Adam, and the
+    workers run single-threaded matmuls with a different rounding than the 8-thread main process)."""
+    skip = H.bn_fed_biases(H.spec_from_case(case))
+    return torch.cat([p.detach().flatten() for n, p in model.module.named_parameters() if n not in skip])
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from mmvae_amd import backend, dist as mdist
+
+    assert mdist.init_from_env("gloo") == world
+    case, z = H.load_case("c1_small")
+    x, eps, masks, _ = H.step_inputs(z, 0)
+    B = x.shape[0] // world
+    rows = slice(rank * B, (rank + 1) * B)
+    mask = {int(k.split(".")[4]): m[rows] for k, m in masks.items()}
+    with tempfile.TemporaryDirectory() as d:
+        model = _build(case, d)
+        MU.load_state(model, z, "sd0/")
+        mdist.broadcast_parameters(model)
+        red = mdist.attach(model, mdist.GradAllReducer(bucket_bytes=4096, side_stream=False))
+        assert all(abs(o.grad_scale - 1.0 / world) < 1e-12 and o.reducer is red for o in model.optimizers())
+        _step(model, x[rows], eps[rows], mask, "human")
+        flat = _flat_params(model, case)
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], g) for g in gathered), "ranks diverged"
+        if rank == 0:
+            torch.save(flat, os.path.join(out_dir, "dp.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_matches_manual_average(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    dp = torch.load(os.path.join(tmp_path, "dp.pt"))
+    # reference computation in one process: per-shard gradients, averaged, then the same clip + Adam
+    case, z = H.load_case("c1_small")
+    x, eps, masks, _ = H.step_inputs(z, 0)
+    B = x.shape[0] // world
+    with tempfile.TemporaryDirectory() as d:
+        from mmvae_amd import backend
+
+        shard_grads = []
+        for r in range(world):
+            m = _build(case, d)
+            MU.load_state(m, z, "sd0/")
+            rows = slice(r * B, (r + 1) * B)
+            mask = {int(k.split(".")[4]): v[rows] for k, v in masks.items()}
+            for o in m.optimizers():
+                o.step = lambda closure=None: None  # gradients only
+            _step(m, x[rows], eps[rows], mask, "human")
+            shard_grads.append([o.arena.grad.clone() for o in m.optimizers()])
+        m = _build(case, d)
+        MU.load_state(m, z, "sd0/")
+        with backend.cpu_plumbing():
+            for i, o in enumerate(m.optimizers()):
+                o.arena.grad.copy_(sum(g[i] for g in shard_grads))
+                o.grad_scale = 1.0 / world
+                o.set_clip(10.0)
+                o.arena.gather_grads = lambda: None
+                if i in (m.optimizer_map["vae"], m.optimizer_map["experts"]["human"]):
+                    o.step()
+        ref = _flat_params(m, case)
+    assert H.rel_l2(dp, ref) < 1e-5
+
+
+def test_bucket_ranges_cover_the_arena_exactly():
+    from mmvae_amd.dist import bucket_ranges
+
+    for n, bb in ((10, 16), (1000, 4096), (4097, 4096), (1, 4)):
+        rs = bucket_ranges(n, bb)
+        assert rs[0].start == 0 and rs[-1].stop == n
+        assert all(a.stop == b.start for a, b in zip(rs, rs[1:]))
+        assert all(len(r) <= max(bb // 4, 1) for r in rs)

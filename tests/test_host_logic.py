@@ -1,0 +1,190 @@
+"""Host-logic tests (no GPU): config validation mirrors the reference's tests/test_components.py behaviours, YAML
+instantiation with the reference's schema, the trainer loop on CPU plumbing (BASELINE config C1), KL annealing,
+log-key tagging, and the C-ABI surface (every symbol the header declares is exported and bound)."""
+import os
+import re
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+import torch.nn as nn
+
+from mmvae_amd import backend
+from mmvae_amd.modules.base import Encoder, Expert, Experts, FCBlock, FCBlockConfig
+from mmvae_amd.modules.base.components import ConditionalLayer, collect_species_files, is_iterable
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- FCBlockConfig / FCBlock (reference tests/test_components.py:22-93)
+def test_is_iterable():
+    assert is_iterable([1]) and is_iterable("s") and is_iterable({"k": 1})
+    assert not is_iterable(123) and not is_iterable(None)
+
+
+def test_fcblock_config_broadcast_and_shapes():
+    cfg = FCBlockConfig(layers=[10, 20, 30], dropout_rate=0.5)
+    block = FCBlock(cfg)
+    assert cfg.n_layers == 2 and block.input_dim == 10 and block.output_dim == 30
+    assert cfg.dropout_rate == [0.5, 0.5]
+    with backend.cpu_plumbing():
+        assert block(torch.randn(5, 10)).shape == (5, 30)
+    assert FCBlock(FCBlockConfig(layers=[10, 20, 30])).can_bypass
+    assert not FCBlock(FCBlockConfig(layers=[10, 20, 30], return_hidden=True)).can_bypass
+    assert FCBlockConfig(layers=[10]).layers == [10, 10] and FCBlockConfig(layers=[10]).n_layers == 1
+    cfg = FCBlockConfig(layers=[10, 20], activation_fn=nn.ReLU)
+    assert all(issubclass(a, nn.ReLU) for a in cfg.activation_fn)
+
+
+@pytest.mark.parametrize("kwargs", [dict(layers=[-10, 20]), dict(layers=[10, 20, 30], dropout_rate=[0.5]),
+                                    dict(layers=(10, 20)), dict(layers=[10, 20], dropout_rate=1),
+                                    dict(layers=[10, 20], use_batch_norm="yes")])
+def test_fcblock_config_rejects_bad_input(kwargs):
+    with pytest.raises(ValueError):
+        FCBlockConfig(**kwargs)
+
+
+def test_encoder_expert_surface():
+    with backend.cpu_plumbing():
+        enc = Encoder(latent_dim=5, fc_block_config=FCBlockConfig(layers=[10]))
+        assert enc.n_layers == 1 and enc.var_eps == 1e-4
+        q_m, q_v, latent, hidden = enc(torch.randn(5, 10))  # 4-tuple when return_dist is False
+        assert q_m.shape == q_v.shape == latent.shape == (5, 5) and isinstance(hidden, list)
+        ex = Expert("e1", FCBlockConfig(layers=[10], return_hidden=[True]), FCBlockConfig(layers=[10]))
+        encoded, hid = ex.encode(torch.randn(5, 10))
+        assert encoded.shape == (5, 10) and ex.decode(encoded).shape == (5, 10)
+        with pytest.raises(NotImplementedError):
+            ex(torch.randn(5, 10))
+    cfg = FCBlockConfig(layers=[10, 20])
+    exps = Experts([Expert("a", cfg, cfg), Expert("b", cfg, cfg)])
+    assert len(exps) == 2 and exps.labels == {"a": 0, "b": 1}
+
+
+def test_conditional_layer_and_species_files(tmp_path):
+    csv = tmp_path / "unique_expression_assay.csv"
+    pd.Series(["10x 3' v3", "microwell-seq", "a.b"]).to_csv(csv, header=False, index=False)
+    layer = ConditionalLayer("assay", str(csv), FCBlockConfig(layers=[6]))
+    assert len(layer.conditions) == 3 and "a_b" in layer.conditions
+    x = torch.randn(4, 6)
+    with backend.cpu_plumbing():
+        out = layer(x, pd.DataFrame({"assay": ["microwell-seq", "a.b", "10x 3' v3", "microwell-seq"]}))
+    assert out.shape == x.shape
+    (tmp_path / "shared").mkdir()
+    (tmp_path / "human").mkdir()
+    (tmp_path / "shared" / "unique_expression_assay.csv").write_text("x\n")
+    (tmp_path / "human" / "unique_expression_assay.csv").write_text("x\n")
+    (tmp_path / "human" / "unique_expression_sex.csv").write_text("x\n")
+    files = collect_species_files(str(tmp_path), ["assay", "sex"])
+    assert set(files["shared"]) == {"assay"} and set(files["human"]) == {"sex"}
+
+
+# ---- log keys (reference tests/test_tag_log_dict.py)
+def test_tag_log_dict():
+    from mmvae_amd.models import tag_log_dict
+
+    d = {"loss": 1}
+    assert tag_log_dict(d, ["training", "human"]) == {"loss/training/human": 1}
+    assert tag_log_dict(d, ["a", "b"], key_pos="last") == {"a/b/loss": 1}
+    assert tag_log_dict(d, [], sep="-") == {"loss": 1}
+    with pytest.raises(ValueError):
+        tag_log_dict(d, ["a"], key_pos="middle")
+
+
+def test_linear_kl_annealing_matches_reference(golden_dir):
+    import json
+    from mmvae_amd.modules.base import KLAnnealingFn, LinearKLAnnealingFn
+
+    z = np.load(os.path.join(golden_dir, "annealing.npz"))
+    for i in range(2):
+        fn = LinearKLAnnealingFn(**json.loads(str(z[f"linear{i}/kwargs"])))
+        vals = [fn.kl_weight]
+        for _ in range(20):
+            fn.step()
+            vals.append(fn.kl_weight)
+        np.testing.assert_allclose(vals, z[f"linear{i}/values"], rtol=1e-12)
+    c = KLAnnealingFn(0.25)
+    c.step()
+    assert c.kl_weight == 0.25
+
+
+# ---- YAML schema + trainer loop on CPU plumbing (BASELINE config C1)
+def test_yaml_instantiation_and_c1_fit_on_cpu_plumbing():
+    from mmvae_amd import instantiate, synthetic
+    from mmvae_amd.models import CMMVAEModel
+    from mmvae_amd.trainer import MultiModalBatches, Trainer
+
+    torch.manual_seed(0)
+    model = instantiate.load_yaml(os.path.join(ROOT, "configs", "model", "c1_core_vae.yaml"))
+    assert isinstance(model, CMMVAEModel) and len(model.module.adversarials) == 0
+    assert model.autograd_config.vae_gradient_clip.val == 10
+    keys = model.state_dict().keys()
+    assert "module.experts.human.encoder.fc_layers.0.lin.weight" in keys
+    assert "module.vae.encoder.mean_encoder.bias" in keys
+    assert model.module.experts["human"].encoder.fc_layers[0].lin.weight.shape == (1024, 2000)
+    w0 = model.module.vae.encoder.mean_encoder.weight.detach().clone()
+    trainer = Trainer.from_yaml(os.path.join(ROOT, "configs", "trainer", "config.yaml"))
+    x = synthetic.synthetic_counts(128 * 4, 2000)
+    batches = [(x[i * 128:(i + 1) * 128], pd.DataFrame({"dummy": [0] * 128}), "human") for i in range(4)]
+    with backend.cpu_plumbing():
+        hist = trainer.fit(model, MultiModalBatches({"human": batches}, seed=1), val_batches=batches[:2])
+        preds = trainer.predict(model, batches[:1])
+    train = [h for h in hist if h["stage"] == "training"]
+    assert len(train) == 2 and trainer.global_step == 8
+    assert all(np.isfinite(h["loss/training/human"]) and h["kl_weight/training/human"] == 1.0 for h in train)
+    assert not torch.equal(w0, model.module.vae.encoder.mean_encoder.weight.detach())  # Adam stepped
+    assert any("loss/validation/human" in h for h in hist)
+    z, meta = preds[0]["z"]
+    assert z.shape == (128, 128) and (meta["species"] == "human").all()
+
+
+def test_instantiate_reference_style_adversarial_yaml(tmp_path):
+    """The reference's human_only.yaml layout: adversarials as Adversarial objects, activation as dotted string."""
+    import yaml
+    from mmvae_amd import instantiate, synthetic
+
+    labels = synthetic.write_label_dir(str(tmp_path), {"assay": 3, "sex": 2})
+    node = {"class_path": "cmmvae.modules.base.Adversarial", "init_args": {
+        "encoder": {"class_path": "cmmvae.modules.base.FCBlockConfig",
+                    "init_args": {"layers": [16, 8], "activation_fn": "torch.nn.ReLU"}},
+        "heads": {"class_path": "cmmvae.modules.base.FCBlockConfig", "init_args": {"layers": [8], "activation_fn": None}},
+        "conditions": ["assay", "sex"], "labels_dir": labels}}
+    from mmvae_amd.modules.base import Adversarial
+
+    Adversarial.labels.clear()
+    adv = instantiate.build(yaml.safe_load(yaml.safe_dump(node)))
+    assert isinstance(adv, Adversarial)
+    assert adv.heads["assay"].fc_layers[0].lin.weight.shape == (3, 8)
+    assert Adversarial.labels["sex"] == {"sex_0": 0, "sex_1": 1}
+
+
+# ---- C-ABI surface
+def test_abi_header_symbols_are_exported_and_bound():
+    import ctypes
+    from mmvae_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "mmvae_hip.h")).read()
+    declared = set(re.findall(r"\b(mmvae_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mmvae_bn_params"}
+    lib = _lib.load()  # loads on a GPU-less host too (no compute call is made)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, f"declared in the header but not exported: {missing}"
+    unbound = sorted(declared - set(_lib.PROTOTYPES))
+    assert not unbound, f"declared in the header but not bound in _lib.PROTOTYPES: {unbound}"
+    extra = sorted(set(_lib.PROTOTYPES) - declared)
+    assert not extra, f"bound but not declared in the header: {extra}"
+    assert lib.mmvae_abi_version() == 1 and lib.mmvae_build_arch() == b"gfx950"
+    # pure host helpers may be called without a GPU
+    t, s = ctypes.c_int(), ctypes.c_int()
+    assert lib.mmvae_gemm_plan(0, 512, 1024, 20000, ctypes.byref(t), ctypes.byref(s)) == 0 and s.value >= 8
+    assert lib.mmvae_gemm_plan(9, 1, 1, 1, None, None) == _lib.ERR_ARG
+    assert lib.mmvae_recon_tiles(20000) == 125 and lib.mmvae_sqnorm_partials(1 << 20) == 16
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "mmvae_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
