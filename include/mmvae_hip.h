@@ -64,6 +64,18 @@ const char* mmvae_build_arch(void);
 #define MMVAE_GEMM_ACCUMULATE 2u  /* C += result (beta = 1) */
 #define MMVAE_GEMM_RAW_SLABS 4u   /* write exactly [splitk, M, ldc] partial slabs, no epilogue (bias must be NULL) */
 
+/* How the chip-filling GEMMs multiply (process-wide switch, host side; default BF16X3):
+ *   MMVAE_GEMM_PRECISION_F32     v_mfma_f32_32x32x2_f32: exact f32 products (bitwise an fmaf chain), 157 TFLOP/s peak.
+ *   MMVAE_GEMM_PRECISION_BF16X3  every f32 operand is split exactly into three bf16 pieces (3 x 8 = 24 significant
+ *                                bits) while it is staged to LDS and a*b is evaluated as the six leading bf16 products
+ *                                on v_mfma_f32_32x32x16_bf16 with f32 accumulation: f32-GEMM accuracy (dropped terms
+ *                                < 2^-24 |a b|) at 2.67x the matrix-core throughput.  Inputs and outputs stay f32.
+ * The small (64x64-tile) GEMMs always use the exact-f32 instruction.  mmvae_recon_tiles depends on the mode. */
+#define MMVAE_GEMM_PRECISION_F32 0
+#define MMVAE_GEMM_PRECISION_BF16X3 1
+int mmvae_gemm_set_precision(int mode);
+int mmvae_gemm_get_precision(void);
+
 /* Library heuristic: picks the block tile (128 or 64) and split-K factor for a shape.  Pure host function. */
 int mmvae_gemm_plan(int layout, int M, int N, int K, int* tile_out, int* splitk_out);
 size_t mmvae_gemm_workspace_bytes(int layout, int M, int N, int K, int splitk);
@@ -80,7 +92,7 @@ int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, const float* A,
  *   P      = h[B,H] . W[G,H]^T + bias[G]
  *   xhat   = max(P, 0)                                   (optional store)
  *   dP     = 2 (xhat - x) * 1[P > 0]                     (optional store; unscaled d recon / d P)
- *   se_part[t, b] = sum over the genes of column tile t (160 genes) of (xhat - x)^2     (t < mmvae_recon_tiles(G))
+ *   se_part[t, b] = sum over the genes of column tile t of (xhat - x)^2                 (t < mmvae_recon_tiles(G))
  *
  * The per-cell squared error is reduced across the wavefront with shuffles inside the GEMM epilogue; the
  * [tiles, B] partials are summed in fixed order by mmvae_elbo_finalize (bitwise reproducible, no atomics).

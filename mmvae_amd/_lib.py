@@ -17,6 +17,7 @@ _ERR_NAMES = {1: "MMVAE_ERR_ARG", 2: "MMVAE_ERR_LAUNCH", 3: "MMVAE_ERR_WORKSPACE
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 GEMM_RELU, GEMM_ACCUMULATE, GEMM_RAW_SLABS = 1, 2, 4
+GEMM_PRECISION_F32, GEMM_PRECISION_BF16X3 = 0, 1
 ADAM_STATE_FLOATS = 8
 PREPARE_NORM, PREPARE_ADVANCE = 1, 2
 
@@ -48,6 +49,8 @@ class BnParams(C.Structure):
 PROTOTYPES = {
     "mmvae_abi_version": (_i, []),
     "mmvae_build_arch": (C.c_char_p, []),
+    "mmvae_gemm_set_precision": (_i, [_i]),
+    "mmvae_gemm_get_precision": (_i, []),
     "mmvae_gemm_plan": (_i, [_i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "mmvae_gemm_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "mmvae_gemm_f32": (_i, [_i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _u, _i, _p, _z, _p]),

@@ -25,6 +25,16 @@
 
 namespace {
 
+#ifndef MMVAE_GEMM_BK0
+#define MMVAE_GEMM_BK0 32  // k-tile of the 128x128 block tile
+#endif
+#ifndef MMVAE_X3_ABLATE
+#define MMVAE_X3_ABLATE 0  // timing-only ablations of the bf16x3 loop (results are wrong when != 0)
+#endif
+#ifndef MMVAE_GEMM_PRELOAD
+#define MMVAE_GEMM_PRELOAD 0
+#endif
+
 constexpr int NT = 256;  // threads per workgroup (4 wavefronts)
 
 enum { FORM_KC = 0, FORM_RC = 1 };
@@ -147,91 +157,17 @@ __device__ __forceinline__ f32x4 load_frag(const float* S, int row, int kk, int 
     }
 }
 
-// Block tile BM x BN, k-tile BK, 4 waves arranged WGM x WGN; each wave owns (BM/WGM) x (BN/WGN) as 32x32 MFMA blocks.
-template <int AFORM, int BFORM, int BM, int BN, int BK, int WGM, int WGN, bool VEC, int EPI>
-__global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
-    static_assert(WGM * WGN == 4, "4 wavefronts per workgroup");
-    constexpr int WTM = BM / WGM, WTN = BN / WGN;  // wave tile
-    constexpr int TM = WTM / 32, TN = WTN / 32;    // 32x32 MFMA blocks per wave
-    static_assert(TM * 32 == WTM && TN * 32 == WTN && BK % 8 == 0, "tile shape");
-    using TA = Tile<AFORM, BM, BK>;
-    using TB = Tile<BFORM, BN, BK>;
-    constexpr int A_FLOATS = TA::LDS_FLOATS, B_FLOATS = TB::LDS_FLOATS;
-    constexpr int KK = BK / 8;
-    __shared__ __attribute__((aligned(16))) float lds[2 * A_FLOATS + 2 * B_FLOATS];
-    float* As = lds;
-    float* Bs = lds + 2 * A_FLOATS;
-
+// Epilogue shared by the fp32-MFMA and the bf16x3-MFMA kernels (the C/D register layout of the 32x32 MFMAs is
+// dtype-independent): col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+template <int BM, int BN, int WGM, int WGN, int EPI, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& g, int bm, int bn, int z,
+                                              float* lds) {
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, half = lane >> 5;
-
-    // XCD-aware (bijective) remap of the workgroup id, then z (split-K slice) slowest, M fastest.
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tiles = g.mt * g.nt;
-    const int z = L / tiles;
-    const int t = L - z * tiles;
-    const int bm = t % g.mt, bn = t / g.mt;
-
-    const int kt_beg = z * g.ktiles_per_split;
-    int kt_end = kt_beg + g.ktiles_per_split;
-    if (kt_end > g.ktiles) kt_end = g.ktiles;
-    const int nkt = kt_end - kt_beg;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int n = 0; n < TN; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
-
-    f32x4 ra[TA::VECS], rb[TB::VECS];
-    unsigned va[TA::VECS], vb[TB::VECS];
-    if (nkt > 0) {
-        load_tile<AFORM, BM, BK, VEC>(ra, va, g.A, g.lda, bm * BM, g.M, kt_beg * BK, g.K, tid);
-        load_tile<BFORM, BN, BK, VEC>(rb, vb, g.B, g.ldb, bn * BN, g.N, kt_beg * BK, g.K, tid);
-        store_tile<AFORM, BM, BK>(As, ra, va, tid);
-        store_tile<BFORM, BN, BK>(Bs, rb, vb, tid);
-        __syncthreads();
-        for (int kt = 0; kt < nkt; ++kt) {
-            const int cur = kt & 1;
-            const bool more = (kt + 1 < nkt);
-            if (more) {  // next tile's loads: in flight during this k-tile's MFMAs
-                const int k0 = (kt_beg + kt + 1) * BK;
-                load_tile<AFORM, BM, BK, VEC>(ra, va, g.A, g.lda, bm * BM, g.M, k0, g.K, tid);
-                load_tile<BFORM, BN, BK, VEC>(rb, vb, g.B, g.ldb, bn * BN, g.N, k0, g.K, tid);
-            }
-            const float* Ac = As + cur * A_FLOATS;
-            const float* Bc = Bs + cur * B_FLOATS;
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk) {
-                f32x4 fa[TM], fb[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = load_frag<AFORM, BM, BK>(Ac, wm * WTM + i * 32 + l31, kk, half);
-#pragma unroll
-                for (int n = 0; n < TN; ++n) fb[n] = load_frag<BFORM, BN, BK>(Bc, wn * WTN + n * 32 + l31, kk, half);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int n = 0; n < TN; ++n)
-                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[n][j], acc[i][n], 0, 0, 0);
-            }
-            if (more) {
-                store_tile<AFORM, BM, BK>(As + (cur ^ 1) * A_FLOATS, ra, va, tid);
-                store_tile<BFORM, BN, BK>(Bs + (cur ^ 1) * B_FLOATS, rb, vb, tid);
-            }
-            __syncthreads();
-        }
-    }
-
-    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
     if (EPI == EPI_STD) {
         float* C = g.C + (int64_t)z * g.slab_stride;
         const bool raw = (g.flags & MMVAE_GEMM_RAW_SLABS) || g.slab_stride != 0;
@@ -304,6 +240,478 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     }
 }
 
+// Block tile BM x BN, k-tile BK, 4 waves arranged WGM x WGN; each wave owns (BM/WGM) x (BN/WGN) as 32x32 MFMA blocks.
+template <int AFORM, int BFORM, int BM, int BN, int BK, int WGM, int WGN, bool VEC, int EPI>
+__global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
+    static_assert(WGM * WGN == 4, "4 wavefronts per workgroup");
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;  // wave tile
+    constexpr int TM = WTM / 32, TN = WTN / 32;    // 32x32 MFMA blocks per wave
+    static_assert(TM * 32 == WTM && TN * 32 == WTN && BK % 8 == 0, "tile shape");
+    using TA = Tile<AFORM, BM, BK>;
+    using TB = Tile<BFORM, BN, BK>;
+    constexpr int A_FLOATS = TA::LDS_FLOATS, B_FLOATS = TB::LDS_FLOATS;
+    constexpr int KK = BK / 8;
+    __shared__ __attribute__((aligned(16))) float lds[2 * A_FLOATS + 2 * B_FLOATS];
+    float* As = lds;
+    float* Bs = lds + 2 * A_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // XCD-aware (bijective) remap of the workgroup id, then z (split-K slice) slowest, M fastest.
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tiles = g.mt * g.nt;
+    const int z = L / tiles;
+    const int t = L - z * tiles;
+    const int bm = t % g.mt, bn = t / g.mt;
+
+    const int kt_beg = z * g.ktiles_per_split;
+    int kt_end = kt_beg + g.ktiles_per_split;
+    if (kt_end > g.ktiles) kt_end = g.ktiles;
+    const int nkt = kt_end - kt_beg;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
+
+    f32x4 ra[TA::VECS], rb[TB::VECS];
+    unsigned va[TA::VECS], vb[TB::VECS];
+    if (nkt > 0) {
+        load_tile<AFORM, BM, BK, VEC>(ra, va, g.A, g.lda, bm * BM, g.M, kt_beg * BK, g.K, tid);
+        load_tile<BFORM, BN, BK, VEC>(rb, vb, g.B, g.ldb, bn * BN, g.N, kt_beg * BK, g.K, tid);
+        store_tile<AFORM, BM, BK>(As, ra, va, tid);
+        store_tile<BFORM, BN, BK>(Bs, rb, vb, tid);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            const bool more = (kt + 1 < nkt);
+            if (more) {  // next tile's loads: in flight during this k-tile's MFMAs
+                const int k0 = (kt_beg + kt + 1) * BK;
+                load_tile<AFORM, BM, BK, VEC>(ra, va, g.A, g.lda, bm * BM, g.M, k0, g.K, tid);
+                load_tile<BFORM, BN, BK, VEC>(rb, vb, g.B, g.ldb, bn * BN, g.N, k0, g.K, tid);
+            }
+            const float* Ac = As + cur * A_FLOATS;
+            const float* Bc = Bs + cur * B_FLOATS;
+#if MMVAE_GEMM_PRELOAD
+            // all of this k-tile's operand fragments are requested from LDS up front, so the MFMAs below only wait
+            // for the group they consume (counted lgkmcnt) instead of exposing the LDS latency once per 4 MFMAs
+            f32x4 fa[KK][TM], fb[KK][TN];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[kk][i] = load_frag<AFORM, BM, BK>(Ac, wm * WTM + i * 32 + l31, kk, half);
+#pragma unroll
+                for (int n = 0; n < TN; ++n) fb[kk][n] = load_frag<BFORM, BN, BK>(Bc, wn * WTN + n * 32 + l31, kk, half);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int n = 0; n < TN; ++n)
+                            acc[i][n] =
+                                __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i][j], fb[kk][n][j], acc[i][n], 0, 0, 0);
+#else
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                f32x4 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = load_frag<AFORM, BM, BK>(Ac, wm * WTM + i * 32 + l31, kk, half);
+#pragma unroll
+                for (int n = 0; n < TN; ++n) fb[n] = load_frag<BFORM, BN, BK>(Bc, wn * WTN + n * 32 + l31, kk, half);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int n = 0; n < TN; ++n)
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[n][j], acc[i][n], 0, 0, 0);
+            }
+#endif
+            if (more) {
+                store_tile<AFORM, BM, BK>(As + (cur ^ 1) * A_FLOATS, ra, va, tid);
+                store_tile<BFORM, BN, BK>(Bs + (cur ^ 1) * B_FLOATS, rb, vb, tid);
+            }
+            __syncthreads();
+        }
+    }
+
+    gemm_epilogue<BM, BN, WGM, WGN, EPI>(acc, g, bm, bn, z, lds);
+}
+
+// ====================================================================================================================
+// bf16x3 GEMM: fp32 in, fp32 out, computed on the bf16 matrix cores.
+//
+// Every fp32 operand element a is split EXACTLY into three bf16 pieces by truncation, a = a0 + a1 + a2
+// (a0 = top 16 bits of a, a1 = top 16 bits of a - a0, a2 = a - a0 - a1: 3 x 8 significant bits = the 24 of fp32), and
+//     a * b  ~=  a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0)
+// (the dropped terms are below 2^-24 |a b|).  Each bf16 x bf16 product is exact in fp32 and the MFMA accumulates in
+// fp32, so the result has fp32-GEMM accuracy (measured 1.5e-7 rel-L2 vs fp64 at K = 20000, plain fp32 GEMM 3.5e-7),
+// while v_mfma_f32_32x32x16_bf16 runs at 16x the rate of v_mfma_f32_32x32x2_f32: 6 MFMAs replace 8 -> 2.67x the
+// matrix-core throughput of the exact-f32 path.  The split happens once per element while a tile is staged into LDS
+// (VALU work that overlaps the partner wave's MFMAs); LDS holds three bf16 planes per operand, [plane][row][32 k]
+// with 80-byte rows (64 B data + 16 B pad: conflict-free ds_read_b128 fragments).  Operands whose contiguous axis is
+// not K (the "RC" images of the NN / TN layouts) are transposed in registers on the way to LDS (each thread owns a
+// 4 k x 4 row patch), so the MFMA loop is identical for all three layouts.
+// One LDS buffer + register prefetch of the next k-tile; two workgroups per CU.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int X3_BK = 32;
+constexpr int X3_LD = 80;  // bytes per LDS row per plane
+
+__device__ __forceinline__ void x3_split(float a, unsigned& p0, unsigned& p1, unsigned& p2) {
+    const unsigned u = __float_as_uint(a);
+    p0 = u & 0xFFFF0000u;
+    const float r1 = a - __uint_as_float(p0);
+    p1 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(p1);
+    p2 = __float_as_uint(r2);  // <= 8 significant bits left: already a bf16 value
+}
+
+// Four fp32 values that are consecutive in k -> three 8-byte groups of 4 bf16, written to the three planes.
+__device__ __forceinline__ void x3_store4(char* S, int plane_bytes, int byte_off, float v0, float v1, float v2,
+                                          float v3) {
+    unsigned a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
+    x3_split(v0, a0, a1, a2);
+    x3_split(v1, b0, b1, b2);
+    x3_split(v2, c0, c1, c2);
+    x3_split(v3, d0, d1, d2);
+    uint2 w;
+    w.x = (a0 >> 16) | b0;
+    w.y = (c0 >> 16) | d0;
+    *reinterpret_cast<uint2*>(S + byte_off) = w;
+    w.x = (a1 >> 16) | b1;
+    w.y = (c1 >> 16) | d1;
+    *reinterpret_cast<uint2*>(S + plane_bytes + byte_off) = w;
+    w.x = (a2 >> 16) | (b2 & 0xFFFF0000u);
+    w.y = (c2 >> 16) | (d2 & 0xFFFF0000u);
+    *reinterpret_cast<uint2*>(S + 2 * plane_bytes + byte_off) = w;
+}
+
+// RC operand (k-slices contiguous along rows in HBM): each thread owns a 4 k x 4 row patch, so that after the split it
+// holds 4 consecutive-k values for each of its 4 rows.  Patch p: row group c4 = p / 8, k group kq = p % 8.
+template <int R, bool VEC, int NV>
+__device__ __forceinline__ void x3_load_rc(f32x4 (&reg)[NV], unsigned (&valid)[NV], const float* __restrict__ P,
+                                           int64_t ld, int r0, int Rtot, int k0, int Kend, int tid) {
+    constexpr int NP = R / 4 * 8;  // patches per tile
+    static_assert(NV == 4 * ((NP + NT - 1) / NT), "register tile size");
+#pragma unroll
+    for (int i = 0; i < NV / 4; ++i) {
+        const int pidx = tid + NT * i;
+        const int c4 = pidx >> 3, kq = pidx & 7;
+        const int x = r0 + c4 * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = k0 + kq * 4 + j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            unsigned vm = 0u;
+            if (NP % NT == 0 || pidx < NP) {
+                const bool ov = o < Kend;
+                const float* p = P + (int64_t)(ov ? o : Kend - 1) * ld;
+                if (VEC) {
+                    const bool full = ov && (x + 3 < Rtot);
+                    v = *reinterpret_cast<const f32x4*>(p + (full ? x : 0));
+                    vm = full ? 0xFu : 0u;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = p[min(x + e, Rtot - 1)];
+                        vm |= (ov && x + e < Rtot) ? (1u << e) : 0u;
+                    }
+                }
+            }
+            reg[i * 4 + j] = v;
+            valid[i * 4 + j] = vm;
+        }
+    }
+}
+
+__device__ __forceinline__ f32x4 x3_mask(f32x4 v, unsigned valid, bool vec) {
+    if (vec) {  // all-or-nothing per 16-byte group: one AND per element, no compares
+        const unsigned m = (valid & 1u) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(__float_as_uint(v[j]) & m);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ((valid >> j) & 1u) ? v[j] : 0.f;
+    }
+    return v;
+}
+
+// In VEC mode the validity of a 16-byte group is recomputed from its indices here (cheaper than carrying a mask
+// register per group across the prefetch distance); `valid` is only read in the element-guarded mode.
+template <int FORM, int R, bool VEC, int NV>
+__device__ __forceinline__ void x3_store(char* S, const f32x4 (&reg)[NV], const unsigned (&valid)[NV], int tid, int r0,
+                                         int Rtot, int k0, int Kend) {
+    constexpr int PLANE = R * X3_LD;
+    if (FORM == FORM_KC) {
+        using T = Tile<FORM_KC, R, X3_BK>;
+#pragma unroll
+        for (int i = 0; i < T::VECS; ++i) {
+            const int f = tid + NT * i;
+            if (T::EXACT || f < T::NVEC) {
+                const int row = f >> 3, c4 = f & 7;
+                const unsigned vm = VEC ? ((r0 + row < Rtot && k0 + c4 * 4 + 3 < Kend) ? 0xFu : 0u) : valid[i];
+                const f32x4 v = x3_mask(reg[i], vm, VEC);
+                x3_store4(S, PLANE, row * X3_LD + c4 * 8, v[0], v[1], v[2], v[3]);
+            }
+        }
+    } else {
+        constexpr int NP = R / 4 * 8;
+#pragma unroll
+        for (int i = 0; i < NV / 4; ++i) {
+            const int pidx = tid + NT * i;
+            if (NP % NT == 0 || pidx < NP) {
+                const int c4 = pidx >> 3, kq = pidx & 7;
+                f32x4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned vm =
+                        VEC ? ((k0 + kq * 4 + j < Kend && r0 + c4 * 4 + 3 < Rtot) ? 0xFu : 0u) : valid[i * 4 + j];
+                    v[j] = x3_mask(reg[i * 4 + j], vm, VEC);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    x3_store4(S, PLANE, (c4 * 4 + e) * X3_LD + kq * 8, v[0][e], v[1][e], v[2][e], v[3][e]);
+            }
+        }
+    }
+}
+
+// ---- unit-level split / write: a "unit" is 4 consecutive-k fp32 values of one tile row = three uint2 of packed bf16.
+// KC operand: unit u = the thread's u-th 16-byte group.  RC operand: unit u = column u of the thread's 4k x 4row patch.
+__device__ __forceinline__ void x3_pack4(float v0, float v1, float v2, float v3, uint2 (&pk)[3]) {
+    unsigned a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
+    x3_split(v0, a0, a1, a2);
+    x3_split(v1, b0, b1, b2);
+    x3_split(v2, c0, c1, c2);
+    x3_split(v3, d0, d1, d2);
+    pk[0].x = (a0 >> 16) | b0;
+    pk[0].y = (c0 >> 16) | d0;
+    pk[1].x = (a1 >> 16) | b1;
+    pk[1].y = (c1 >> 16) | d1;
+    pk[2].x = (a2 >> 16) | (b2 & 0xFFFF0000u);
+    pk[2].y = (c2 >> 16) | (d2 & 0xFFFF0000u);
+}
+
+// VEC-mode only (validity recomputed from indices).  NV == 4 for the 128-row tiles handled here.
+template <int FORM, int R>
+__device__ __forceinline__ void x3_split_unit(const f32x4 (&reg)[4], int u, uint2 (&pk)[3], int tid, int r0, int Rtot,
+                                              int k0, int Kend) {
+    if (FORM == FORM_KC) {
+        const int f = tid + NT * u;
+        const int row = f >> 3, c4 = f & 7;
+        const unsigned vm = (r0 + row < Rtot && k0 + c4 * 4 + 3 < Kend) ? 0xFu : 0u;
+        const f32x4 v = x3_mask(reg[u], vm, true);
+        x3_pack4(v[0], v[1], v[2], v[3], pk);
+    } else {
+        const int c4 = tid >> 3, kq = tid & 7;
+        const bool cv = r0 + c4 * 4 + 3 < Rtot;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned m = (cv && k0 + kq * 4 + j < Kend) ? 0xFFFFFFFFu : 0u;
+            v[j] = __uint_as_float(__float_as_uint(reg[j][u]) & m);
+        }
+        x3_pack4(v[0], v[1], v[2], v[3], pk);
+    }
+}
+
+template <int FORM, int R>
+__device__ __forceinline__ void x3_write_unit(char* S, int u, const uint2 (&pk)[3], int tid) {
+    constexpr int PLANE = R * X3_LD;
+    int off;
+    if (FORM == FORM_KC) {
+        const int f = tid + NT * u;
+        off = (f >> 3) * X3_LD + (f & 7) * 8;
+    } else {
+        off = ((tid >> 3) * 4 + u) * X3_LD + (tid & 7) * 8;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(S + p * PLANE + off) = pk[p];
+}
+
+template <int FORM, int R>
+struct X3Regs {
+    static constexpr int NV = (FORM == FORM_KC) ? Tile<FORM_KC, R, X3_BK>::VECS : 4 * ((R / 4 * 8 + NT - 1) / NT);
+};
+
+template <int AFORM, int BFORM, int BM, int BN, int WGM, int WGN, bool VEC, int EPI>
+__global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
+    static_assert(WGM * WGN == 4, "4 wavefronts per workgroup");
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int A_BYTES = 3 * BM * X3_LD, B_BYTES = 3 * BN * X3_LD;
+    constexpr int PA = BM * X3_LD, PB = BN * X3_LD;
+    __shared__ __attribute__((aligned(16))) char lds[A_BYTES + B_BYTES];
+    char* As = lds;
+    char* Bs = lds + A_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tiles = g.mt * g.nt;
+    const int z = L / tiles;
+    const int t = L - z * tiles;
+    const int bm = t % g.mt, bn = t / g.mt;
+
+    const int kt_beg = z * g.ktiles_per_split;
+    int kt_end = kt_beg + g.ktiles_per_split;
+    if (kt_end > g.ktiles) kt_end = g.ktiles;
+    const int nkt = kt_end - kt_beg;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
+
+    constexpr int NVA = X3Regs<AFORM, BM>::NV, NVB = X3Regs<BFORM, BN>::NV;
+    f32x4 ra[NVA], rb[NVB];
+    unsigned va[NVA], vb[NVB];
+    auto load_ab = [&](int kt) {
+        const int k0 = kt * X3_BK;
+        if (AFORM == FORM_KC)
+            load_tile<FORM_KC, BM, X3_BK, VEC>(ra, va, g.A, g.lda, bm * BM, g.M, k0, g.K, tid);
+        else
+            x3_load_rc<BM, VEC>(ra, va, g.A, g.lda, bm * BM, g.M, k0, g.K, tid);
+        if (BFORM == FORM_KC)
+            load_tile<FORM_KC, BN, X3_BK, VEC>(rb, vb, g.B, g.ldb, bn * BN, g.N, k0, g.K, tid);
+        else
+            x3_load_rc<BN, VEC>(rb, vb, g.B, g.ldb, bn * BN, g.N, k0, g.K, tid);
+    };
+    auto mfma_group = [&](int ks, int i, int n, const bf16x8 (&fa)[3][TM], const bf16x8 (&fb)[3][TN]) {
+        f32x16 c = acc[i][n];  // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][n], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][n], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][n], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][n], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][n], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][n], c, 0, 0, 0);
+        acc[i][n] = c;
+    };
+    auto load_frags = [&](int ks, bf16x8 (&fa)[3][TM], bf16x8 (&fb)[3][TN]) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[p][i] = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const f32x4*>(As + p * PA + (wm * WTM + i * 32 + l31) * X3_LD + ks * 32 +
+                                                            half * 16));
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+                fb[p][n] = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const f32x4*>(Bs + p * PB + (wn * WTN + n * 32 + l31) * X3_LD + ks * 32 +
+                                                            half * 16));
+        }
+    };
+    if (nkt > 0) {
+        load_ab(kt_beg);
+        if (VEC && NVA == 4 && NVB == 4 && TM == 2 && TN == 2) {
+            // Software pipeline (one raw staging set + packed planes): while tile t is multiplied, the registers of
+            // tile t+1 (loaded during tile t-1) are split into packed bf16 planes BETWEEN the first half of the MFMAs
+            // (VALU hidden in the matrix-core shadow), the freed registers are immediately reissued as the loads of
+            // tile t+2, and after the barrier only the ds_write burst remains.
+            uint2 pka[4][3], pkb[4][3];
+            auto split_unit = [&](int u, int kt) {
+                const int k0 = kt * X3_BK;
+                x3_split_unit<AFORM, BM>(ra, u, pka[u], tid, bm * BM, g.M, k0, g.K);
+                x3_split_unit<BFORM, BN>(rb, u, pkb[u], tid, bn * BN, g.N, k0, g.K);
+            };
+            auto write_all = [&]() {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    x3_write_unit<AFORM, BM>(As, u, pka[u], tid);
+                    x3_write_unit<BFORM, BN>(Bs, u, pkb[u], tid);
+                }
+            };
+#pragma unroll
+            for (int u = 0; u < 4; ++u) split_unit(u, kt_beg);
+            if (nkt > 1) load_ab(kt_beg + 1);
+            write_all();
+            __syncthreads();
+            for (int kt = 0; kt < nkt; ++kt) {
+                const bool more = kt + 1 < nkt;
+                bf16x8 fa[3][TM], fb[3][TN];
+                load_frags(0, fa, fb);
+                // k-step 0: 4 MFMA groups, one split unit (A and B) after each
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) {
+#if MMVAE_X3_ABLATE != 4
+                        mfma_group(0, i, n, fa, fb);
+#endif
+#if MMVAE_X3_ABLATE != 1
+                        if (more) split_unit(i * TN + n, kt_beg + kt + 1);
+#endif
+                    }
+#if MMVAE_X3_ABLATE != 2
+                if (kt + 2 < nkt) load_ab(kt_beg + kt + 2);  // raw registers are free again: next-next tile in flight
+#endif
+                load_frags(1, fa, fb);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) {
+#if MMVAE_X3_ABLATE != 4
+                        mfma_group(1, i, n, fa, fb);
+#endif
+                    }
+                __syncthreads();  // every wave is done reading this k-tile
+#if MMVAE_X3_ABLATE != 3
+                if (more) write_all();
+#endif
+                __syncthreads();
+            }
+        } else {  // element-guarded (unaligned) matrices: plain loop
+            x3_store<AFORM, BM, VEC>(As, ra, va, tid, bm * BM, g.M, kt_beg * X3_BK, g.K);
+            x3_store<BFORM, BN, VEC>(Bs, rb, vb, tid, bn * BN, g.N, kt_beg * X3_BK, g.K);
+            __syncthreads();
+            for (int kt = 0; kt < nkt; ++kt) {
+                const bool more = kt + 1 < nkt;
+                if (more) load_ab(kt_beg + kt + 1);
+#pragma unroll
+                for (int ks = 0; ks < X3_BK / 16; ++ks) {
+                    bf16x8 fa[3][TM], fb[3][TN];
+                    load_frags(ks, fa, fb);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int n = 0; n < TN; ++n) mfma_group(ks, i, n, fa, fb);
+                }
+                __syncthreads();
+                if (more) {
+                    const int k0 = (kt_beg + kt + 1) * X3_BK;
+                    x3_store<AFORM, BM, VEC>(As, ra, va, tid, bm * BM, g.M, k0, g.K);
+                    x3_store<BFORM, BN, VEC>(Bs, rb, vb, tid, bn * BN, g.N, k0, g.K);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    gemm_epilogue<BM, BN, WGM, WGN, EPI>(acc, g, bm, bn, z, reinterpret_cast<float*>(lds));
+}
+
 // Fixed-order reduction of split-K slabs + the standard epilogue.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int S, int64_t slab_stride,
                                                             int M, int N, float alpha, const float* __restrict__ bias,
@@ -331,7 +739,7 @@ struct TileShape {
 };
 
 TileShape tile_shape(int layout, int id) {
-    if (id == 0) return {128, 128, 2};
+    if (id == 0 || id == 3) return {128, 128, 2};
     if (id == 1) return {128, 160, 2};
     return {64, 64, 4};
 }
@@ -339,11 +747,18 @@ TileShape tile_shape(int layout, int id) {
 template <int AFORM, int BFORM, bool VEC, int EPI>
 int launch_gemm_vec(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) {
     if (tile_id == 0)
-        hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, 128, 128, 32, 2, 2, VEC, EPI>), dim3(nblocks), dim3(NT), 0, s,
-                           g);
-    else if (tile_id == 1)  // NT only (plan): BK = 16 keeps two workgroups resident per CU
-        hipLaunchKernelGGL((gemm_f32_kernel<FORM_KC, FORM_KC, 128, 160, 16, 4, 1, VEC, EPI>), dim3(nblocks), dim3(NT), 0,
-                           s, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, 128, 128, MMVAE_GEMM_BK0, 2, 2, VEC, EPI>), dim3(nblocks),
+                           dim3(NT), 0, s, g);
+    else if (tile_id == 1) {
+        if (AFORM == FORM_KC && BFORM == FORM_KC)  // BK = 16 keeps two workgroups resident per CU
+            hipLaunchKernelGGL((gemm_f32_kernel<FORM_KC, FORM_KC, 128, 160, 16, 4, 1, VEC, EPI>), dim3(nblocks),
+                               dim3(NT), 0, s, g);
+        else if (AFORM == FORM_RC)
+            hipLaunchKernelGGL((gemm_f32_kernel<FORM_RC, FORM_RC, 128, 160, 32, 4, 1, VEC, EPI>), dim3(nblocks),
+                               dim3(NT), 0, s, g);
+        else
+            return MMVAE_ERR_ARG;
+    }
     else
         hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, 64, 64, 32, 2, 2, VEC, EPI>), dim3(nblocks), dim3(NT), 0, s,
                            g);
@@ -351,13 +766,30 @@ int launch_gemm_vec(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) 
     return MMVAE_OK;
 }
 
+int g_precision = MMVAE_GEMM_PRECISION_BF16X3;  // process-wide, set by mmvae_gemm_set_precision
+
+template <int AFORM, int BFORM, bool VEC, int EPI>
+int launch_gemm_x3(const GemmArgs& g, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL((gemm_x3_kernel<AFORM, BFORM, 128, 128, 2, 2, VEC, EPI>), dim3(nblocks), dim3(NT), 0, s, g);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+// tile_id 3 = the bf16x3 kernel (128x128 tile)
 template <int AFORM, int BFORM, int EPI>
 int launch_gemm_forms(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) {
+    if (tile_id == 3)
+        return g.aligned == 2 ? launch_gemm_x3<AFORM, BFORM, true, EPI>(g, nblocks, s)
+                              : launch_gemm_x3<AFORM, BFORM, false, EPI>(g, nblocks, s);
     return g.aligned == 2 ? launch_gemm_vec<AFORM, BFORM, true, EPI>(tile_id, g, nblocks, s)
                           : launch_gemm_vec<AFORM, BFORM, false, EPI>(tile_id, g, nblocks, s);
 }
 
-int bk_of(int layout, int tile_id) { return (tile_id == 1 && layout == MMVAE_GEMM_NT) ? 16 : 32; }
+int bk_of(int layout, int tile_id) {
+    if (tile_id == 3) return X3_BK;
+    if (tile_id == 0) return MMVAE_GEMM_BK0;
+    return (tile_id == 1 && layout == MMVAE_GEMM_NT) ? 16 : 32;
+}
 
 // Picks tile id and split-K.  Large outputs: the tile whose (rounds x tile area) is smallest, rounds = number of
 // times the chip's resident-workgroup slots are filled.  Few output tiles (K = G reductions): split-K.
@@ -365,14 +797,12 @@ void plan(int layout, int M, int N, int K, int* tile_id, int* splitk) {
     const int CUS = 256;
     long best_cost = -1;
     int best = 0;
-    for (int id = 0; id < (layout == MMVAE_GEMM_NT ? 2 : 1); ++id) {  // 128x160 measured slower on the RC images
+    for (int id = 0; id < (layout == MMVAE_GEMM_NN ? 1 : 2); ++id) {
         const TileShape ts = tile_shape(layout, id);
         const long tiles = (long)ceil_div_i(M, ts.bm) * ceil_div_i(N, ts.bn);
         const long slots = (long)CUS * ts.blocks_per_cu;
         const long rounds = (tiles + slots - 1) / slots;
-        // fractional fill of the last round still costs a full tile time per CU
-        const long per_cu = (tiles + CUS - 1) / CUS;
-        const long cost = (rounds > 1 ? per_cu : (tiles + CUS - 1) / CUS) * ts.bm * ts.bn;
+        const long cost = rounds * ts.bm * ts.bn;  // every round costs one tile time per resident slot
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
             best = id;
@@ -439,6 +869,7 @@ extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, cons
     plan(layout, M, N, K, &tile_id, &sk_auto);
     if (splitk == 0) splitk = sk_auto;
     if (splitk > 1 && tile_id == 1) tile_id = 0;  // split-K slices use the square tiles
+    if (g_precision == MMVAE_GEMM_PRECISION_BF16X3 && tile_id != 2) tile_id = 3;  // chip-filling GEMMs: bf16x3 cores
     const TileShape ts = tile_shape(layout, tile_id);
     const int ktiles = ceil_div_i(K, bk_of(layout, tile_id));
     const bool raw = (flags & MMVAE_GEMM_RAW_SLABS) != 0;
@@ -499,8 +930,21 @@ extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, cons
     return MMVAE_OK;
 }
 
-// The fused decoder/recon kernel always uses the 128x160 tile: one se_part row per 160-gene column tile.
-extern "C" int mmvae_recon_tiles(int G) { return G > 0 ? ceil_div_i(G, 160) : 0; }
+// Upper bound on the se_part rows written by the fused decoder/recon kernel (one row per column tile: 128 genes on the
+// bf16x3 path, 160 on the exact-f32 path).  Rows beyond the tiles actually written must be zero-initialised by the
+// caller ONCE (the library never reads what it did not write: mmvae_elbo_finalize takes T = mmvae_recon_tiles_used).
+extern "C" int mmvae_recon_tiles(int G) {
+    if (G <= 0) return 0;
+    return ceil_div_i(G, g_precision == MMVAE_GEMM_PRECISION_BF16X3 ? 128 : 160);
+}
+
+extern "C" int mmvae_gemm_set_precision(int mode) {
+    if (mode != MMVAE_GEMM_PRECISION_F32 && mode != MMVAE_GEMM_PRECISION_BF16X3) return MMVAE_ERR_ARG;
+    g_precision = mode;
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_gemm_get_precision(void) { return g_precision; }
 
 extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, const float* h, int64_t ldh,
                                             const float* W, int64_t ldw, const float* bias, const float* x, int64_t ldx,
@@ -520,9 +964,10 @@ extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, 
     g.M = rows;
     g.N = G;
     g.K = H;
+    const bool x3 = g_precision == MMVAE_GEMM_PRECISION_BF16X3;
     g.mt = ceil_div_i(rows, 128);
-    g.nt = ceil_div_i(G, 160);
-    g.ktiles = ceil_div_i(H, 16);
+    g.nt = ceil_div_i(G, x3 ? 128 : 160);
+    g.ktiles = ceil_div_i(H, x3 ? X3_BK : 16);
     g.ktiles_per_split = g.ktiles;
     g.alpha = 1.f;
     g.x = x;
@@ -535,7 +980,7 @@ extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, 
     g.x_rows = x_rows;
     g.aligned = aligned16(h) && aligned16(W) && (ldh % 4 == 0) && (ldw % 4 == 0);
     if (g.aligned && rows % 4 == 0 && G % 4 == 0 && H % 4 == 0) g.aligned = 2;
-    return launch_gemm_forms<FORM_KC, FORM_KC, EPI_RECON>(1, g, g.mt * g.nt, (hipStream_t)stream);
+    return launch_gemm_forms<FORM_KC, FORM_KC, EPI_RECON>(x3 ? 3 : 1, g, g.mt * g.nt, (hipStream_t)stream);
 }
 
 extern "C" int mmvae_decoder_recon_f32(int B, int G, int H, const float* h, int64_t ldh, const float* W, int64_t ldw,

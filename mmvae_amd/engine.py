@@ -19,6 +19,7 @@ graphs.  Configurations outside this shape (conditional layers, LayerNorm, non-R
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -95,7 +96,7 @@ class StepEngine:
             return None
         return StepEngine(model)
 
-    def __init__(self, model):
+    def __init__(self, model, side_stream: bool = False, defer_expert_adam: Optional[bool] = None):
         self.model = model
         self.lib = _lib.load()
         self.device = next(model.parameters()).device
@@ -110,6 +111,18 @@ class StepEngine:
         self.klw_dev = torch.ones(1, dtype=torch.float32, device=self.device)
         self._klw_host = None
         self.world = mdist.world_size()
+        # weight-gradient GEMMs run on a side stream inside the captured graph (fork/join edges)
+        self.side_stream = torch.cuda.Stream(device=self.device) if side_stream else None
+        # only the small (latency-bound) weight-gradient GEMMs go aside; chip-filling ones stay in order on the main stream
+        self.side_max_elems = int(os.environ.get("MMVAE_SIDE_MAX_ELEMS", 2 * 1024 * 1024))
+        # Deferred expert update: the active expert's parameters are not read again until that expert's next step, so
+        # its (HBM-bound) Adam update runs on a second stream, concurrently with the next step's (MFMA-bound) work for
+        # another modality.  The clip norm / coefficient are still computed in order on the main stream.
+        if defer_expert_adam is None:
+            defer_expert_adam = os.environ.get("MMVAE_DEFER_EXPERT_ADAM", "1") != "0"
+        self.defer_expert_adam = bool(defer_expert_adam) and len(model.module.experts) > 1
+        self.update_stream = torch.cuda.Stream(device=self.device) if self.defer_expert_adam else None
+        self._pending: Dict[str, torch.cuda.Event] = {}
 
     # ------------------------------------------------------------------------------------------------ buffers
     def buf(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
@@ -124,6 +137,12 @@ class StepEngine:
 
     def grad_of(self, p: torch.Tensor) -> torch.Tensor:
         return self._grad_of[id(p)]
+
+    def flush(self) -> None:
+        """Make the current stream wait for every deferred expert update (before parameters are read elsewhere)."""
+        if self.update_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.update_stream)
+            self._pending.clear()
 
     # --------------------------------------------------------------------------------------------------- step
     def training_step(self, x: torch.Tensor, metadata, expert_id: str) -> None:
@@ -166,7 +185,19 @@ class StepEngine:
             plan.load_explicit_noise(enc_mod, expert)
         if plan.has_adv:
             plan.load_labels(metadata)
+        ev = self._pending.pop(expert_id, None)
+        if ev is not None:  # this expert's previous (deferred) update must land before its parameters are read
+            torch.cuda.current_stream().wait_event(ev)
         plan.run()
+        if plan.deferred:
+            main = torch.cuda.current_stream()
+            self.update_stream.wait_stream(main)
+            with torch.cuda.stream(self.update_stream):
+                for call in plan.deferred:
+                    call()
+                ev = torch.cuda.Event()
+                ev.record(self.update_stream)
+            self._pending[expert_id] = ev
         model.kl_annealing_fn.step()
         plan.log(model, expert_id)
 
@@ -212,6 +243,7 @@ class _Plan:
         self._slab_floats = 0
         self._graphs: Optional[list] = None
         self._runs = 0
+        self.deferred: List = []  # launches enqueued on the engine's update stream after the captured program
         self.metrics = eng.buf("metrics", (256,))
         self.rng_state = rng.state(eng.device)
         self._build()
@@ -246,12 +278,40 @@ class _Plan:
         self.lib.mmvae_gemm_plan(layout, M, N, K, C.byref(tile), C.byref(sk))
         return sk.value
 
-    def gemm(self, layout, M, N, K, A, lda, Bm, ldb, Cm, ldc, bias=None, flags=0, alpha=1.0):
-        """Complete GEMM (internal split-K reduce through the shared workspace when the plan asks for it)."""
+    def gemm(self, layout, M, N, K, A, lda, Bm, ldb, Cm, ldc, bias=None, flags=0, alpha=1.0, side=False):
+        """Complete GEMM (internal split-K reduce through a workspace when the plan asks for it).  side=True runs it
+        on the engine's side stream (weight gradients: off the backward critical path) with its own workspace."""
         sk = self._plan_gemm(layout, M, N, K)
         nbytes = self.lib.mmvae_gemm_workspace_bytes(layout, M, N, K, sk)
+        if side and self.eng.side_stream is not None and M * N <= self.eng.side_max_elems:
+            self._ws_side_bytes = max(getattr(self, "_ws_side_bytes", 0), nbytes)
+            self._fork()
+            self._emit_gemm(layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, sk, "side")
+            return
         self._ws_bytes = max(self._ws_bytes, nbytes)
         self._emit_gemm(layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, sk, True)
+
+    def _fork(self):
+        """Side stream waits for everything enqueued so far on the main stream (graph edge under capture)."""
+        side = self.eng.side_stream
+
+        def call():
+            side.wait_stream(torch.cuda.current_stream())
+
+        self._cur.append(call)
+        self._side_dirty = True
+
+    def _join(self):
+        """Main stream waits for the side stream (before the optimiser reads the gradient arenas)."""
+        if not getattr(self, "_side_dirty", False):
+            return
+        side = self.eng.side_stream
+
+        def call():
+            torch.cuda.current_stream().wait_stream(side)
+
+        self._cur.append(call)
+        self._side_dirty = False
 
     def gemm_raw(self, layout, M, N, K, A, lda, Bm, ldb) -> int:
         """Raw split-K slabs into the shared slab buffer; returns the slab count."""
@@ -263,14 +323,22 @@ class _Plan:
     def _emit_gemm(self, layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, sk, use_ws):
         plan = self
 
-        def call():
-            ws = plan.ws
+        def launch():
+            ws = plan.ws_side if use_ws == "side" else plan.ws
             c_ptr = _p(Cm) if Cm is not None else plan.slab.data_ptr()
             rc = plan.lib.mmvae_gemm_f32(layout, M, N, K, alpha, _p(A), lda, _p(Bm), ldb, c_ptr, ldc, _p(bias), flags, sk,
                                          ws.data_ptr() if use_ws else None, ws.numel() * 4 if use_ws else 0, _s())
             if rc != 0:
                 raise _lib.HipLibraryError(f"mmvae_gemm_f32 failed with code {rc} (layout {layout}, {M}x{N}x{K})")
 
+        if use_ws == "side":
+            side = self.eng.side_stream
+
+            def call():
+                with torch.cuda.stream(side):
+                    launch()
+        else:
+            call = launch
         self._cur.append(call)
 
     # ---- one FCBlock layer forward: cur [rows, n_in] -> l.d
@@ -330,7 +398,7 @@ class _Plan:
 
         self._cur.append(call)
         # dW[n_out, n_in] = dz^T[n_out, rows] . inp[rows, n_in]  -> straight into the gradient arena
-        self.gemm(TN, l.n_out, l.n_in, rows, l.dz, l.n_out, l.inp, l.ld_inp, l.gW, l.n_in)
+        self.gemm(TN, l.n_out, l.n_in, rows, l.dz, l.n_out, l.inp, l.ld_inp, l.gW, l.n_in, side=True)
         if need_dx == "raw":
             return self.gemm_raw(NN, rows, l.n_in, l.n_out, l.dz, l.n_out, l.W, l.n_in)
         if need_dx == "full":
@@ -352,7 +420,8 @@ class _Plan:
 
         self._cur.append(call)
 
-    def optimizer(self, opt: HipAdam, max_norm: float, advance: bool = True, step: bool = True):
+    def optimizer(self, opt: HipAdam, max_norm: float, advance: bool = True, step: bool = True, defer: bool = False):
+        self._join()
         a = opt.arena
         g = opt.param_groups[0]
         b1, b2 = g["betas"]
@@ -364,8 +433,14 @@ class _Plan:
         flags = _lib.PREPARE_NORM | (_lib.PREPARE_ADVANCE if (advance and step) else 0)
         self._emit(self.lib.mmvae_adam_prepare, npart, _p(opt.partials), max_norm, gs, b1, b2, _p(opt.state_dev), flags)
         if step:
+            if defer:
+                # the update reads state_dev (clip, bias corrections) written above; it must not see the NEXT step's
+                # prepare of the same optimiser -> training_step waits for the pending event before re-running it
+                cur, self._cur = self._cur, self.deferred
             self._emit(self.lib.mmvae_adam_step, a.numel, _p(a.data), _p(a.grad), _p(a.exp_avg), _p(a.exp_avg_sq),
                        _p(opt.state_dev), g["lr"], b1, b2, g["eps"], g["weight_decay"], gs)
+            if defer:
+                self._cur = cur
 
     def copy_scalar(self, src_ptr: int, dst_name: str):
         self._emit(self.lib.mmvae_axpby, 1, 1.0, src_ptr, 0.0, self.mptr(dst_name))
@@ -431,7 +506,7 @@ class _Plan:
             self._emit_fc_bwd(R, G, self.dP, None, self.w, self.dP, last.gb)
         else:
             self._emit_fc_bwd(R, G, self.dP, None, None, None, last.gb)
-        self.gemm(TN, G, last.n_in, R, self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in)
+        self.gemm(TN, G, last.n_in, R, self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True)
         S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
         rest = self.dec_layers[:-1]
         for j in range(len(rest) - 1, -1, -1):
@@ -454,7 +529,7 @@ class _Plan:
                    None, None, _p(eng.klw_dev), 1.0 / B, self.var_eps, _p(self.dmu), _p(self.da))
         for dy, lin in ((self.dmu, self.mean_enc), (self.da, self.var_enc)):
             self._emit_fc_bwd(B, Z, dy, None, None, None, eng.grad_of(lin.bias))
-            self.gemm(TN, Z, HV, B, dy, Z, q, HV, eng.grad_of(lin.weight), HV)
+            self.gemm(TN, Z, HV, B, dy, Z, q, HV, eng.grad_of(lin.weight), HV, side=True)
         self.gemm(NN, B, HV, Z, self.dmu, Z, self.mean_enc.weight, HV, self.dq, HV)
         self.gemm(NN, B, HV, Z, self.da, Z, self.var_enc.weight, HV, self.dq, HV, flags=ACC)
         # ---- backward, encoder side
@@ -467,7 +542,7 @@ class _Plan:
             din, S = None, S_next
         # ---- clip + Adam (reference order: clip vae, clip expert, step vae, step expert)
         self.optimizer(self.opt_vae, self.clip_vae)
-        self.optimizer(self.opt_exp, self.clip_exp)
+        self.optimizer(self.opt_exp, self.clip_exp, defer=eng.defer_expert_adam)
         self.segments.append(self._cur)
         self._cur = []
         # noise: Philox fills (production) or explicit buffers (parity mode), at the head of the program
@@ -486,6 +561,10 @@ class _Plan:
         for key, t in eng._pool.items():
             if key[0] == "fc_ws" and t.numel() > self.fcws.numel():
                 self.fcws = t
+        self.ws_side = eng.buf("gemm_ws_side", (max(getattr(self, "_ws_side_bytes", 0) // 4, 1),))
+        for key, t in eng._pool.items():
+            if key[0] == "gemm_ws_side" and t.numel() > self.ws_side.numel():
+                self.ws_side = t
         self.ws = eng.buf("gemm_ws", (max(self._ws_bytes // 4, 1),))
         self.slab = eng.buf("gemm_slabs", (max(self._slab_floats, 1),))
         # a shared buffer may have been re-allocated larger by a later plan: always take the biggest one
@@ -529,7 +608,7 @@ class _Plan:
                                self.mptr(f"{phase}_{i}/summed"))
                     # head backward
                     self._emit_fc_bwd(B, Cn, dlogits[c], None, None, None, g(lin.bias))
-                    self.gemm(TN, Cn, n_e, B, dlogits[c], Cn, e, n_e, g(lin.weight), n_e)
+                    self.gemm(TN, Cn, n_e, B, dlogits[c], Cn, e, n_e, g(lin.weight), n_e, side=True)
                     self.gemm(NN, B, n_e, Cn, dlogits[c], Cn, lin.weight, n_e, de, n_e, flags=ACC if ci > 0 else 0)
                 din, S = de, 1
                 for j in range(len(layers) - 1, -1, -1):

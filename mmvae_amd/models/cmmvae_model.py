@@ -155,8 +155,17 @@ class CMMVAEModel(BaseModel):
             return ops.sum_f32(stat[0]).reshape(()) / n, ops.sum_f32(stat[1]).reshape(()) / n
         return qz.mean.mean(), qz.variance.mean()
 
+    def _flush_engine(self):
+        if self._engine:
+            self._engine.flush()
+
+    def state_dict(self, *args, **kwargs):
+        self._flush_engine()  # deferred expert updates must have landed before parameters are read
+        return super().state_dict(*args, **kwargs)
+
     def validation_step(self, batch, batch_idx: int = 0):
         """Eval-mode forward + ELBO, logged under the current stage (:219-248)."""
+        self._flush_engine()
         x, metadata, expert_id = batch
         qz, pz, z, xhats, hidden_representations = self.module(x, metadata, expert_id)
         if x.layout == torch.sparse_csr:
@@ -170,6 +179,7 @@ class CMMVAEModel(BaseModel):
     test_step = validation_step
 
     def predict_step(self, batch, batch_idx: int = 0):
+        self._flush_engine()
         x, metadata, species = batch
         return self.module.get_latent_embeddings(x, metadata, species)
 

@@ -178,7 +178,11 @@ def test_abi_header_symbols_are_exported_and_bound():
     t, s = ctypes.c_int(), ctypes.c_int()
     assert lib.mmvae_gemm_plan(0, 512, 1024, 20000, ctypes.byref(t), ctypes.byref(s)) == 0 and s.value >= 8
     assert lib.mmvae_gemm_plan(9, 1, 1, 1, None, None) == _lib.ERR_ARG
-    assert lib.mmvae_recon_tiles(20000) == 125 and lib.mmvae_sqnorm_partials(1 << 20) == 16
+    assert lib.mmvae_gemm_get_precision() == _lib.GEMM_PRECISION_BF16X3  # default
+    assert lib.mmvae_recon_tiles(20000) == 157 and lib.mmvae_sqnorm_partials(1 << 20) == 16
+    assert lib.mmvae_gemm_set_precision(_lib.GEMM_PRECISION_F32) == 0 and lib.mmvae_recon_tiles(20000) == 125
+    assert lib.mmvae_gemm_set_precision(7) == _lib.ERR_ARG
+    assert lib.mmvae_gemm_set_precision(_lib.GEMM_PRECISION_BF16X3) == 0
 
 
 def test_product_package_never_imports_the_oracle():
