@@ -405,6 +405,20 @@ __global__ __launch_bounds__(256) void axpby_kernel(int64_t n, float alpha, cons
         y[i] = alpha * x[i] + (beta != 0.f ? beta * y[i] : 0.f);
 }
 
+// 16-byte variant (n % 4 == 0, both pointers 16-byte aligned); beta == 0 never reads y (plain copy / scaled copy).
+__global__ __launch_bounds__(256) void axpby4_kernel(int64_t n4, float alpha, const float4* __restrict__ x, float beta,
+                                                     float4* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = x[i];
+        float4 r = make_float4(alpha * a.x, alpha * a.y, alpha * a.z, alpha * a.w);
+        if (beta != 0.f) {
+            const float4 b = y[i];
+            r.x += beta * b.x, r.y += beta * b.y, r.z += beta * b.z, r.w += beta * b.w;
+        }
+        y[i] = r;
+    }
+}
+
 __global__ __launch_bounds__(256) void scale_rows_kernel(int B, int N, const float* __restrict__ x, int64_t ldx,
                                                          const float* __restrict__ rs, float* __restrict__ y,
                                                          int64_t ldy) {
@@ -564,8 +578,12 @@ extern "C" int mmvae_philox_advance(uint64_t* rng_state, uint64_t by, mmvae_stre
 
 extern "C" int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, float* y, mmvae_stream_t stream) {
     if (n <= 0 || !x || !y) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, n, alpha, x, beta,
-                       y);
+    if (n % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
+        hipLaunchKernelGGL(axpby4_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, n / 4,
+                           alpha, reinterpret_cast<const float4*>(x), beta, reinterpret_cast<float4*>(y));
+    else
+        hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, n, alpha, x,
+                           beta, y);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }

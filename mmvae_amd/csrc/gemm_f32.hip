@@ -505,27 +505,59 @@ __device__ __forceinline__ void x3_pack4(float v0, float v1, float v2, float v3,
     pk[2].y = (c2 >> 16) | (d2 & 0xFFFF0000u);
 }
 
-// VEC-mode only (validity recomputed from indices).  NV == 4 for the 128-row tiles handled here.
+// Lean split for the pipelined loop: 4.5 VALU instructions per element (VALU and MFMA instructions of one SIMD do not
+// overlap on gfx950 -- tools/ubench/overlap.hip -- so every instruction here is paid for in matrix-core time):
+// 2 ANDs + 2 halves of a packed subtract per element, one v_perm_b32 per bf16 pair and plane.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 x3_top16(f32x2 v) {
+    f32x2 h;
+    h[0] = __uint_as_float(__float_as_uint(v[0]) & 0xFFFF0000u);
+    h[1] = __uint_as_float(__float_as_uint(v[1]) & 0xFFFF0000u);
+    return h;
+}
+// dword = [bf16(hi) : bf16(lo)] = the top halves of two fp32 (v_perm_b32: selector bytes 0-3 address the 2nd source)
+__device__ __forceinline__ unsigned x3_pair(f32x2 v) {
+    return __builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u);
+}
+__device__ __forceinline__ void x3_pack4_lean(f32x2 lo, f32x2 hi, uint2 (&pk)[3]) {
+    pk[0].x = x3_pair(lo);
+    pk[0].y = x3_pair(hi);
+    const f32x2 r1lo = lo - x3_top16(lo), r1hi = hi - x3_top16(hi);
+    pk[1].x = x3_pair(r1lo);
+    pk[1].y = x3_pair(r1hi);
+    const f32x2 r2lo = r1lo - x3_top16(r1lo), r2hi = r1hi - x3_top16(r1hi);
+    pk[2].x = x3_pair(r2lo);  // <= 8 significant bits left: the top half IS the value
+    pk[2].y = x3_pair(r2hi);
+}
+
+// VEC-mode only.  NV == 4 for the 128-row tiles handled here.  Rows/columns beyond the matrix hold clamped (finite,
+// in-matrix) data: they only reach accumulators the epilogue never stores.  Only the K tail must be zeroed, and only
+// in the last k-tile (a wave-uniform branch).
 template <int FORM, int R>
 __device__ __forceinline__ void x3_split_unit(const f32x4 (&reg)[4], int u, uint2 (&pk)[3], int tid, int r0, int Rtot,
                                               int k0, int Kend) {
+    float v[4];
     if (FORM == FORM_KC) {
-        const int f = tid + NT * u;
-        const int row = f >> 3, c4 = f & 7;
-        const unsigned vm = (r0 + row < Rtot && k0 + c4 * 4 + 3 < Kend) ? 0xFu : 0u;
-        const f32x4 v = x3_mask(reg[u], vm, true);
-        x3_pack4(v[0], v[1], v[2], v[3], pk);
-    } else {
-        const int c4 = tid >> 3, kq = tid & 7;
-        const bool cv = r0 + c4 * 4 + 3 < Rtot;
-        float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned m = (cv && k0 + kq * 4 + j < Kend) ? 0xFFFFFFFFu : 0u;
-            v[j] = __uint_as_float(__float_as_uint(reg[j][u]) & m);
-        }
-        x3_pack4(v[0], v[1], v[2], v[3], pk);
+        for (int j = 0; j < 4; ++j) v[j] = reg[u][j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = reg[j][u];
     }
+    if (k0 + X3_BK > Kend) {
+        if (FORM == FORM_KC) {
+            const int c4 = (tid + NT * u) & 7;
+            const unsigned m = (k0 + c4 * 4 + 3 < Kend) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(__float_as_uint(v[j]) & m);
+        } else {
+            const int kq = tid & 7;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (k0 + kq * 4 + j < Kend) ? v[j] : 0.f;
+        }
+    }
+    f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+    x3_pack4_lean(lo, hi, pk);
 }
 
 template <int FORM, int R>

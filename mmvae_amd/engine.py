@@ -119,7 +119,7 @@ class StepEngine:
         # its (HBM-bound) Adam update runs on a second stream, concurrently with the next step's (MFMA-bound) work for
         # another modality.  The clip norm / coefficient are still computed in order on the main stream.
         if defer_expert_adam is None:
-            defer_expert_adam = os.environ.get("MMVAE_DEFER_EXPERT_ADAM", "1") != "0"
+            defer_expert_adam = os.environ.get("MMVAE_DEFER_EXPERT_ADAM", "0") != "0"  # measured slower on C2
         self.defer_expert_adam = bool(defer_expert_adam) and len(model.module.experts) > 1
         self.update_stream = torch.cuda.Stream(device=self.device) if self.defer_expert_adam else None
         self._pending: Dict[str, torch.cuda.Event] = {}
@@ -169,7 +169,12 @@ class StepEngine:
         else:
             key = (expert_id, B, K, explicit, 0, 0)
             x_in = self.buf(f"x_static.{expert_id}", (B, x.shape[1]))
-            x_in.copy_(x)
+            if x.is_contiguous():  # own 16-byte copy kernel: the runtime's blit kernel reaches < 1 TB/s here
+                from . import ops
+
+                ops.axpby(1.0, x, 0.0, x_in)
+            else:
+                x_in.copy_(x)
             if len(self._ptr_seen) > 4096:
                 self._ptr_seen.clear()
         plan = self._plans.get(key)
