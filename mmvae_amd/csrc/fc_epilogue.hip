@@ -52,11 +52,33 @@ __device__ __forceinline__ float block_colsum(float v, float (*red)[CW], int w, 
     return (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
-__device__ __forceinline__ float fwd_z(const FwdArgs& a, int r, int c, float bias) {
-    float z = bias;
-    const float* p = a.in + (int64_t)r * a.ld_in + c;
-    for (int s = 0; s < a.n_slabs; ++s) z += p[(int64_t)s * a.slab_stride];
-    return z;
+// acc[i] += sum over the split-K slabs of element (row r0 + i, column c), accumulated in slab order (bitwise the plain
+// loop) but with the loads of 4 slabs x RPW rows issued together: at 4 wavefronts per CU a dependent load per slab is
+// pure latency (16 slabs of the G-wide GEMMs took 34 us for a 2 MB matrix).  Rows >= B are clamped (callers mask).
+__device__ __forceinline__ void slab_sum_rows(float (&acc)[RPW], const float* __restrict__ in, int64_t ld,
+                                              int64_t slab_stride, int n_slabs, int r0, int B, int c) {
+    const float* p[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) p[i] = in + (int64_t)min(r0 + i, B - 1) * ld + c;
+    int s = 0;
+    for (; s + 4 <= n_slabs; s += 4) {
+        float t[4][RPW];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) t[u][i] = p[i][(int64_t)(s + u) * slab_stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) acc[i] += t[u][i];
+    }
+    for (; s < n_slabs; ++s) {
+        float t[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) t[i] = p[i][(int64_t)s * slab_stride];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) acc[i] += t[i];
+    }
 }
 
 // Pass 1 of training BatchNorm: z = bias + sum of slabs (stored), per-chunk column mean and centred M2.
@@ -71,13 +93,16 @@ __global__ __launch_bounds__(CT) void fc_fwd_stats_kernel(const FwdArgs a) {
     float zv[RPW];
     float s = 0.f;
 #pragma unroll
+    for (int i = 0; i < RPW; ++i) zv[i] = bias;
+    slab_sum_rows(zv, a.in, a.ld_in, a.slab_stride, a.n_slabs, r0, a.B, cv ? c : a.N - 1);
+#pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int r = r0 + i;
-        zv[i] = 0.f;
         if (cv && r < a.B) {
-            zv[i] = fwd_z(a, r, c, bias);
             a.z_out[(int64_t)r * a.ld_out + c] = zv[i];
             s += zv[i];
+        } else {
+            zv[i] = 0.f;
         }
     }
     const int nb = min(RPC, a.B - chunk * RPC);
@@ -140,6 +165,12 @@ __global__ __launch_bounds__(CT) void fc_fwd_apply_kernel(const FwdArgs a) {
         }
     }
     const int r0 = chunk * RPC + w * RPW;
+    float zs[RPW];
+    if (!stats) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) zs[i] = bias;
+        slab_sum_rows(zs, a.in, a.ld_in, a.slab_stride, a.n_slabs, r0, a.B, c);
+    }
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int r = r0 + i;
@@ -149,7 +180,7 @@ __global__ __launch_bounds__(CT) void fc_fwd_apply_kernel(const FwdArgs a) {
         if (stats) {
             z = a.z_out[o];
         } else {
-            z = fwd_z(a, r, c, bias);
+            z = zs[i];
             if (a.z_out) a.z_out[o] = z;
         }
         float y = z;
@@ -187,10 +218,7 @@ struct BwdArgs {
     int B, N, RC;
 };
 
-__device__ __forceinline__ float bwd_dy(const BwdArgs& a, int r, int c) {
-    const int64_t o = (int64_t)r * a.ld_in + c;
-    float g = 0.f;
-    for (int s = 0; s < a.n_slabs; ++s) g += a.din[(int64_t)s * a.slab_stride + o];
+__device__ __forceinline__ float bwd_dy(const BwdArgs& a, int r, int c, float g) {
     // addend / a / z / dz_out share the [B, ld_out] geometry of the layer's own activations
     const int64_t oo = (int64_t)r * a.ld_out + c;
     if (a.addend) g += a.addend[oo];
@@ -215,11 +243,15 @@ __global__ __launch_bounds__(CT) void fc_bwd_stats_kernel(const BwdArgs a) {
     }
     const int r0 = chunk * RPC + w * RPW;
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float gs[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) gs[i] = 0.f;
+    slab_sum_rows(gs, a.din, a.ld_in, a.slab_stride, a.n_slabs, r0, a.B, cv ? c : a.N - 1);
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int r = r0 + i;
         if (cv && r < a.B) {
-            const float dy = bwd_dy(a, r, c);
+            const float dy = bwd_dy(a, r, c, gs[i]);
             const int64_t oo = (int64_t)r * a.ld_out + c;
             if (a.dz_out) a.dz_out[oo] = dy;
             s1 += dy;

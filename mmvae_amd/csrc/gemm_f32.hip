@@ -28,6 +28,9 @@ namespace {
 #ifndef MMVAE_GEMM_BK0
 #define MMVAE_GEMM_BK0 32  // k-tile of the 128x128 block tile
 #endif
+#ifndef MMVAE_X3_STAMPS
+#define MMVAE_X3_STAMPS 0  // diagnostic build: per-phase cycle sums of the bf16x3 loop (block 0, one lane per wave)
+#endif
 #ifndef MMVAE_X3_ABLATE
 #define MMVAE_X3_ABLATE 0  // timing-only ablations of the bf16x3 loop (results are wrong when != 0)
 #endif
@@ -73,7 +76,8 @@ struct GemmArgs {
     float* dP;
     float* se_part;
     int64_t ldx, ldxhat, lddp;
-    int x_rows;  // x row = output row % x_rows (K-sample decode stacks K copies of the batch)
+    int x_rows;    // x row = output row % x_rows (K-sample decode stacks K copies of the batch)
+    int se_tiles;  // rows of se_part the caller reads (>= nt); the last column tile zeroes rows nt .. se_tiles-1
 };
 
 // HBM -> registers.  r0: first row (KC) / column (RC) of this tile along the non-K axis, Rtot its extent.
@@ -235,6 +239,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
 #pragma unroll
                 for (int w = 0; w < WGN; ++w) s += rowsum[w * BM + tid];
                 g.se_part[(int64_t)bn * g.M + row] = s;
+                if (bn == g.nt - 1)
+                    for (int tz = g.nt; tz < g.se_tiles; ++tz) g.se_part[(int64_t)tz * g.M + row] = 0.f;
             }
         }
     }
@@ -367,6 +373,9 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
 // 4 k x 4 row patch), so the MFMA loop is identical for all three layouts.
 // One LDS buffer + register prefetch of the next k-tile; two workgroups per CU.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#if MMVAE_X3_STAMPS
+__device__ long long g_x3_stamps[32];
+#endif
 constexpr int X3_BK = 32;
 constexpr int X3_LD = 80;  // bytes per LDS row per plane
 
@@ -519,41 +528,111 @@ __device__ __forceinline__ f32x2 x3_top16(f32x2 v) {
 __device__ __forceinline__ unsigned x3_pair(f32x2 v) {
     return __builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u);
 }
+// Scalar subtracts on purpose: v_pk_add_f32 beside MFMAs costs more than two v_sub_f32 (MI355X_MICROARCH.md, "price of
+// one filler beside MFMAs"); the asm keeps the SLP vectoriser from re-packing them.
+__device__ __forceinline__ float x3_sub(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 x3_resid(f32x2 v) {
+    const f32x2 h = x3_top16(v);
+    f32x2 r;
+    r[0] = x3_sub(v[0], h[0]);
+    r[1] = x3_sub(v[1], h[1]);
+    return r;
+}
 __device__ __forceinline__ void x3_pack4_lean(f32x2 lo, f32x2 hi, uint2 (&pk)[3]) {
     pk[0].x = x3_pair(lo);
     pk[0].y = x3_pair(hi);
-    const f32x2 r1lo = lo - x3_top16(lo), r1hi = hi - x3_top16(hi);
+    const f32x2 r1lo = x3_resid(lo), r1hi = x3_resid(hi);
     pk[1].x = x3_pair(r1lo);
     pk[1].y = x3_pair(r1hi);
-    const f32x2 r2lo = r1lo - x3_top16(r1lo), r2hi = r1hi - x3_top16(r1hi);
+    const f32x2 r2lo = x3_resid(r1lo), r2hi = x3_resid(r1hi);
     pk[2].x = x3_pair(r2lo);  // <= 8 significant bits left: the top half IS the value
     pk[2].y = x3_pair(r2hi);
 }
 
-// VEC-mode only.  NV == 4 for the 128-row tiles handled here.  Rows/columns beyond the matrix hold clamped (finite,
-// in-matrix) data: they only reach accumulators the epilogue never stores.  Only the K tail must be zeroed, and only
-// in the last k-tile (a wave-uniform branch).
+// ---- pipelined (VEC-mode) staging of one operand tile of R rows x 32 k; R = 128 or 160, R / 32 "units" per thread.
+// A unit = 4 consecutive-k fp32 values of one tile row = three uint2 of packed bf16 (one per plane).
+//   KC operand (K contiguous in HBM): unit u = 16-byte group f = tid + 256 u: row f >> 3, k = 4 (f & 7).
+//   RC operand (rows contiguous):     rows 0..127: each thread owns a 4 k x 4 row patch (row group c4 = tid >> 3,
+//                                     k group kq = tid & 7), loaded as 4 row-vectors; unit u (< 4) = patch row u, its
+//                                     4 k values are component u of the 4 loads (a register-name transpose).
+//                                     rows 128..159 (R = 160): one row-vector per thread at k = 4 (tid >> 5) + (tid & 3),
+//                                     row group rq = (tid >> 2) & 7; the 4 lanes of a quad hold 4 consecutive k of the
+//                                     same 4 rows and transpose them with DPP quad broadcasts: unit 4 = row 4 rq + q.
+// Rows/columns beyond the matrix are loaded from clamped (finite, in-matrix) addresses: they only reach accumulators
+// the epilogue never stores.  Only the K tail must be zeroed, and only in the last k-tile (a wave-uniform branch).
 template <int FORM, int R>
-__device__ __forceinline__ void x3_split_unit(const f32x4 (&reg)[4], int u, uint2 (&pk)[3], int tid, int r0, int Rtot,
-                                              int k0, int Kend) {
+__device__ __forceinline__ void x3p_load(f32x4 (&reg)[R / 32], const float* __restrict__ P, int64_t ld, int r0, int Rtot,
+                                         int k0, int Kend, int tid) {
+    constexpr int NU = R / 32;
+    if (FORM == FORM_KC) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int f = tid + NT * u;
+            const int row = r0 + (f >> 3), k = k0 + 4 * (f & 7);
+            reg[u] = *reinterpret_cast<const f32x4*>(P + (int64_t)(row < Rtot ? row : Rtot - 1) * ld +
+                                                     (k + 3 < Kend ? k : 0));
+        }
+    } else {
+        const int c4 = tid >> 3, kq = tid & 7;
+        const int x = r0 + 4 * c4;
+        const int xo = (x + 3 < Rtot) ? x : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = k0 + 4 * kq + j;
+            reg[j] = *reinterpret_cast<const f32x4*>(P + (int64_t)(o < Kend ? o : Kend - 1) * ld + xo);
+        }
+        if (NU == 5) {
+            const int o = k0 + 4 * (tid >> 5) + (tid & 3);
+            const int xt = r0 + 128 + 4 * ((tid >> 2) & 7);
+            reg[NU - 1] = *reinterpret_cast<const f32x4*>(P + (int64_t)(o < Kend ? o : Kend - 1) * ld +
+                                                          ((xt + 3 < Rtot) ? xt : 0));
+        }
+    }
+}
+
+template <int J>
+__device__ __forceinline__ float x3_quad_bcast(float v) {  // value of lane J of this lane's quad
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), J * 0x55, 0xF, 0xF, true));
+}
+
+template <int FORM, int R>
+__device__ __forceinline__ void x3p_split(const f32x4 (&reg)[R / 32], int u, uint2 (&pk)[3], int tid, int k0, int Kend) {
     float v[4];
+    const bool tail = k0 + X3_BK > Kend;
     if (FORM == FORM_KC) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = reg[u][j];
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = reg[j][u];
-    }
-    if (k0 + X3_BK > Kend) {
-        if (FORM == FORM_KC) {
-            const int c4 = (tid + NT * u) & 7;
-            const unsigned m = (k0 + c4 * 4 + 3 < Kend) ? 0xFFFFFFFFu : 0u;
+        if (tail) {
+            const unsigned m = (k0 + 4 * ((tid + NT * u) & 7) + 3 < Kend) ? 0xFFFFFFFFu : 0u;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(__float_as_uint(v[j]) & m);
-        } else {
-            const int kq = tid & 7;
+        }
+    } else if (u < 4) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (k0 + kq * 4 + j < Kend) ? v[j] : 0.f;
+        for (int j = 0; j < 4; ++j) v[j] = reg[j][u];
+        if (tail) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (k0 + 4 * (tid & 7) + j < Kend) ? v[j] : 0.f;
+        }
+    } else {
+        const f32x4 t = reg[R / 32 - 1];
+        const int q = tid & 3;
+        float c[4][4];  // c[j][e]: component e of lane j of the quad
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            c[0][e] = x3_quad_bcast<0>(t[e]);
+            c[1][e] = x3_quad_bcast<1>(t[e]);
+            c[2][e] = x3_quad_bcast<2>(t[e]);
+            c[3][e] = x3_quad_bcast<3>(t[e]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = q == 0 ? c[j][0] : q == 1 ? c[j][1] : q == 2 ? c[j][2] : c[j][3];
+            if (tail) v[j] = (k0 + 4 * (tid >> 5) + j < Kend) ? v[j] : 0.f;
         }
     }
     f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
@@ -561,14 +640,16 @@ __device__ __forceinline__ void x3_split_unit(const f32x4 (&reg)[4], int u, uint
 }
 
 template <int FORM, int R>
-__device__ __forceinline__ void x3_write_unit(char* S, int u, const uint2 (&pk)[3], int tid) {
+__device__ __forceinline__ void x3p_write(char* S, int u, const uint2 (&pk)[3], int tid) {
     constexpr int PLANE = R * X3_LD;
     int off;
     if (FORM == FORM_KC) {
         const int f = tid + NT * u;
         off = (f >> 3) * X3_LD + (f & 7) * 8;
-    } else {
+    } else if (u < 4) {
         off = ((tid >> 3) * 4 + u) * X3_LD + (tid & 7) * 8;
+    } else {
+        off = (128 + 4 * ((tid >> 2) & 7) + (tid & 3)) * X3_LD + (tid >> 5) * 8;
     }
 #pragma unroll
     for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(S + p * PLANE + off) = pk[p];
@@ -582,6 +663,7 @@ struct X3Regs {
 template <int AFORM, int BFORM, int BM, int BN, int WGM, int WGN, bool VEC, int EPI>
 __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
     static_assert(WGM * WGN == 4, "4 wavefronts per workgroup");
+    static_assert(VEC || (BM == 128 && BN == 128), "element-guarded matrices use the square tile");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int A_BYTES = 3 * BM * X3_LD, B_BYTES = 3 * BN * X3_LD;
@@ -617,21 +699,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
 
-    constexpr int NVA = X3Regs<AFORM, BM>::NV, NVB = X3Regs<BFORM, BN>::NV;
-    f32x4 ra[NVA], rb[NVB];
-    unsigned va[NVA], vb[NVB];
-    auto load_ab = [&](int kt) {
-        const int k0 = kt * X3_BK;
-        if (AFORM == FORM_KC)
-            load_tile<FORM_KC, BM, X3_BK, VEC>(ra, va, g.A, g.lda, bm * BM, g.M, k0, g.K, tid);
-        else
-            x3_load_rc<BM, VEC>(ra, va, g.A, g.lda, bm * BM, g.M, k0, g.K, tid);
-        if (BFORM == FORM_KC)
-            load_tile<FORM_KC, BN, X3_BK, VEC>(rb, vb, g.B, g.ldb, bn * BN, g.N, k0, g.K, tid);
-        else
-            x3_load_rc<BN, VEC>(rb, vb, g.B, g.ldb, bn * BN, g.N, k0, g.K, tid);
-    };
-    auto mfma_group = [&](int ks, int i, int n, const bf16x8 (&fa)[3][TM], const bf16x8 (&fb)[3][TN]) {
+    auto mfma_group = [&](int i, int n, const bf16x8 (&fa)[3][TM], const bf16x8 (&fb)[3][TN]) {
         f32x16 c = acc[i][n];  // smallest terms first
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][n], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][n], c, 0, 0, 0);
@@ -657,65 +725,155 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
         }
     };
     if (nkt > 0) {
-        load_ab(kt_beg);
-        if (VEC && NVA == 4 && NVB == 4 && TM == 2 && TN == 2) {
+        if constexpr (VEC) {
             // Software pipeline (one raw staging set + packed planes): while tile t is multiplied, the registers of
-            // tile t+1 (loaded during tile t-1) are split into packed bf16 planes BETWEEN the first half of the MFMAs
-            // (VALU hidden in the matrix-core shadow), the freed registers are immediately reissued as the loads of
-            // tile t+2, and after the barrier only the ds_write burst remains.
-            uint2 pka[4][3], pkb[4][3];
+            // tile t+1 (loaded during tile t-1) are split into packed bf16 planes BETWEEN the MFMA groups of the first
+            // k-step, the freed registers are immediately reissued as the loads of tile t+2, and after the barrier
+            // only the ds_write burst remains.
+            constexpr int NUA = BM / 32, NUB = BN / 32, NG = TM * TN;
+            static_assert(NG >= NUA && NG >= NUB, "one split unit per MFMA group");
+            f32x4 ra[NUA], rb[NUB];
+            uint2 pka[NUA][3], pkb[NUB][3];
+            auto load_ab = [&](int kt) {
+                x3p_load<AFORM, BM>(ra, g.A, g.lda, bm * BM, g.M, kt * X3_BK, g.K, tid);
+                x3p_load<BFORM, BN>(rb, g.B, g.ldb, bn * BN, g.N, kt * X3_BK, g.K, tid);
+            };
             auto split_unit = [&](int u, int kt) {
-                const int k0 = kt * X3_BK;
-                x3_split_unit<AFORM, BM>(ra, u, pka[u], tid, bm * BM, g.M, k0, g.K);
-                x3_split_unit<BFORM, BN>(rb, u, pkb[u], tid, bn * BN, g.N, k0, g.K);
+                if (u < NUA) x3p_split<AFORM, BM>(ra, u, pka[u < NUA ? u : 0], tid, kt * X3_BK, g.K);
+                if (u < NUB) x3p_split<BFORM, BN>(rb, u, pkb[u < NUB ? u : 0], tid, kt * X3_BK, g.K);
             };
             auto write_all = [&]() {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    x3_write_unit<AFORM, BM>(As, u, pka[u], tid);
-                    x3_write_unit<BFORM, BN>(Bs, u, pkb[u], tid);
-                }
-            };
+                for (int u = 0; u < NUA; ++u) x3p_write<AFORM, BM>(As, u, pka[u], tid);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) split_unit(u, kt_beg);
+                for (int u = 0; u < NUB; ++u) x3p_write<BFORM, BN>(Bs, u, pkb[u], tid);
+            };
+            load_ab(kt_beg);
+#pragma unroll
+            for (int u = 0; u < NG; ++u) split_unit(u, kt_beg);
             if (nkt > 1) load_ab(kt_beg + 1);
             write_all();
             __syncthreads();
-            for (int kt = 0; kt < nkt; ++kt) {
-                const bool more = kt + 1 < nkt;
-                bf16x8 fa[3][TM], fb[3][TN];
-                load_frags(0, fa, fb);
-                // k-step 0: 4 MFMA groups, one split unit (A and B) after each
+#if MMVAE_X3_STAMPS
+            long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            long long tprev = clock64();
+#define X3_STAMP(i)                       \
+    {                                     \
+        const long long tn_ = clock64();  \
+        st[i] += tn_ - tprev;             \
+        tprev = tn_;                      \
+    }
+#else
+#define X3_STAMP(i)
+#endif
+            // One 16-deep k-step.  Square wave tiles (2x2 blocks) read all their fragments up front; the 1x5 / 5x1 wave
+            // tiles of the 160-wide block tiles keep the short side's fragments and stream the long side's one block
+            // ahead of its MFMA group (two 3-plane sets), which is what keeps them inside 256 VGPRs.
+            auto frag3 = [&](bf16x8 (&f)[3], const char* S, int plane_bytes, int row, int ks) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int p = 0; p < 3; ++p)
+                    f[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(S + p * plane_bytes + row * X3_LD +
+                                                                                       ks * 32 + half * 16));
+            };
+            auto mfma6 = [&](f32x16& cc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+                f32x16 c = cc;  // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+                cc = c;
+            };
+            auto kstep = [&](int ks, bool do_split, int kt_next) {
+                if constexpr (TM == 2 && TN == 2) {
+                    bf16x8 fa[3][TM], fb[3][TN];
+                    load_frags(ks, fa, fb);
 #pragma unroll
-                    for (int n = 0; n < TN; ++n) {
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int n = 0; n < TN; ++n) {
 #if MMVAE_X3_ABLATE != 4
-                        mfma_group(0, i, n, fa, fb);
+                            mfma_group(i, n, fa, fb);
 #endif
 #if MMVAE_X3_ABLATE != 1
-                        if (more) split_unit(i * TN + n, kt_beg + kt + 1);
+                            if (do_split) split_unit(i * TN + n, kt_next);
+#endif
+                        }
+                } else {
+                    constexpr bool STREAM_B = TM == 1;
+                    static_assert(TM == 1 || TN == 1, "streamed fragments: one side has a single 32-row block");
+                    constexpr int NL = STREAM_B ? TN : TM;
+                    bf16x8 fs[3], fl[2][3];  // short side (kept), long side (double-buffered)
+                    if (STREAM_B) {
+                        frag3(fs, As, PA, wm * WTM + l31, ks);
+                        frag3(fl[0], Bs, PB, wn * WTN + l31, ks);
+                    } else {
+                        frag3(fs, Bs, PB, wn * WTN + l31, ks);
+                        frag3(fl[0], As, PA, wm * WTM + l31, ks);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) {
+                        if (j + 1 < NL) {
+                            if (STREAM_B)
+                                frag3(fl[(j + 1) & 1], Bs, PB, wn * WTN + (j + 1) * 32 + l31, ks);
+                            else
+                                frag3(fl[(j + 1) & 1], As, PA, wm * WTM + (j + 1) * 32 + l31, ks);
+                        }
+#if MMVAE_X3_ABLATE != 4
+                        if (STREAM_B)
+                            mfma6(acc[0][j < TN ? j : 0], fs, fl[j & 1]);
+                        else
+                            mfma6(acc[j < TM ? j : 0][0], fl[j & 1], fs);
+#endif
+#if MMVAE_X3_ABLATE != 1
+                        if (do_split) split_unit(j, kt_next);
 #endif
                     }
+                }
+            };
+            for (int kt = 0; kt < nkt; ++kt) {
+                const bool more = kt + 1 < nkt;
+                X3_STAMP(0)
+                kstep(0, more, kt_beg + kt + 1);  // MFMA groups with one split unit (A and B) after each
+                X3_STAMP(1)  // k-step 0 MFMAs issued + split of the next tile done
 #if MMVAE_X3_ABLATE != 2
                 if (kt + 2 < nkt) load_ab(kt_beg + kt + 2);  // raw registers are free again: next-next tile in flight
 #endif
-                load_frags(1, fa, fb);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int n = 0; n < TN; ++n) {
-#if MMVAE_X3_ABLATE != 4
-                        mfma_group(1, i, n, fa, fb);
-#endif
-                    }
+                X3_STAMP(2)
+                kstep(1, false, 0);
+                X3_STAMP(3)  // k-step 1 MFMAs issued
                 __syncthreads();  // every wave is done reading this k-tile
+                X3_STAMP(4)
 #if MMVAE_X3_ABLATE != 3
                 if (more) write_all();
 #endif
+                X3_STAMP(5)  // plane writes issued and landed
                 __syncthreads();
+                X3_STAMP(6)
             }
-        } else {  // element-guarded (unaligned) matrices: plain loop
+#if MMVAE_X3_STAMPS
+            if (bid == 0 && lane == 0) {
+                for (int i = 0; i < 7; ++i) g_x3_stamps[wave * 8 + i] = st[i];
+                g_x3_stamps[wave * 8 + 7] = nkt;
+            }
+#endif
+        } else {  // element-guarded (unaligned) matrices: plain loop, square tile
+            constexpr int NVA = X3Regs<AFORM, BM>::NV, NVB = X3Regs<BFORM, BN>::NV;
+            f32x4 ra[NVA], rb[NVB];
+            unsigned va[NVA], vb[NVB];
+            auto load_ab = [&](int kt) {
+                const int k0 = kt * X3_BK;
+                if (AFORM == FORM_KC)
+                    load_tile<FORM_KC, BM, X3_BK, VEC>(ra, va, g.A, g.lda, bm * BM, g.M, k0, g.K, tid);
+                else
+                    x3_load_rc<BM, VEC>(ra, va, g.A, g.lda, bm * BM, g.M, k0, g.K, tid);
+                if (BFORM == FORM_KC)
+                    load_tile<FORM_KC, BN, X3_BK, VEC>(rb, vb, g.B, g.ldb, bn * BN, g.N, k0, g.K, tid);
+                else
+                    x3_load_rc<BN, VEC>(rb, vb, g.B, g.ldb, bn * BN, g.N, k0, g.K, tid);
+            };
+            load_ab(kt_beg);
             x3_store<AFORM, BM, VEC>(As, ra, va, tid, bm * BM, g.M, kt_beg * X3_BK, g.K);
             x3_store<BFORM, BN, VEC>(Bs, rb, vb, tid, bn * BN, g.N, kt_beg * X3_BK, g.K);
             __syncthreads();
@@ -729,7 +887,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int n = 0; n < TN; ++n) mfma_group(ks, i, n, fa, fb);
+                        for (int n = 0; n < TN; ++n) mfma_group(i, n, fa, fb);
                 }
                 __syncthreads();
                 if (more) {
@@ -741,6 +899,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
             }
         }
     }
+#if MMVAE_X3_ABLATE == 5  // no epilogue (accumulators kept alive through a never-taken branch)
+    if (g.alpha != 123.456f) return;
+#endif
     gemm_epilogue<BM, BN, WGM, WGN, EPI>(acc, g, bm, bn, z, reinterpret_cast<float*>(lds));
 }
 
@@ -772,7 +933,8 @@ struct TileShape {
 
 TileShape tile_shape(int layout, int id) {
     if (id == 0 || id == 3) return {128, 128, 2};
-    if (id == 1) return {128, 160, 2};
+    if (id == 1 || id == 4) return {128, 160, 2};
+    if (id == 5) return {160, 128, 2};
     return {64, 64, 4};
 }
 
@@ -801,24 +963,32 @@ int launch_gemm_vec(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) 
 int g_precision = MMVAE_GEMM_PRECISION_BF16X3;  // process-wide, set by mmvae_gemm_set_precision
 
 template <int AFORM, int BFORM, bool VEC, int EPI>
-int launch_gemm_x3(const GemmArgs& g, int nblocks, hipStream_t s) {
-    hipLaunchKernelGGL((gemm_x3_kernel<AFORM, BFORM, 128, 128, 2, 2, VEC, EPI>), dim3(nblocks), dim3(NT), 0, s, g);
+int launch_gemm_x3(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) {
+    if (VEC && tile_id == 4)
+        hipLaunchKernelGGL((gemm_x3_kernel<AFORM, BFORM, 128, 160, 4, 1, true, EPI>), dim3(nblocks), dim3(NT), 0, s, g);
+    else if (VEC && tile_id == 5 && EPI == EPI_STD)
+        hipLaunchKernelGGL((gemm_x3_kernel<AFORM, BFORM, 160, 128, 1, 4, true, EPI_STD>), dim3(nblocks), dim3(NT), 0, s,
+                           g);
+    else if (tile_id == 3)
+        hipLaunchKernelGGL((gemm_x3_kernel<AFORM, BFORM, 128, 128, 2, 2, VEC, EPI>), dim3(nblocks), dim3(NT), 0, s, g);
+    else
+        return MMVAE_ERR_ARG;
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }
 
-// tile_id 3 = the bf16x3 kernel (128x128 tile)
+// tile_id 3, 4, 5 = the bf16x3 kernel (128x128, 128x160, 160x128 tiles; the last two need 16-byte-regular operands)
 template <int AFORM, int BFORM, int EPI>
 int launch_gemm_forms(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) {
-    if (tile_id == 3)
-        return g.aligned == 2 ? launch_gemm_x3<AFORM, BFORM, true, EPI>(g, nblocks, s)
-                              : launch_gemm_x3<AFORM, BFORM, false, EPI>(g, nblocks, s);
+    if (tile_id >= 3)
+        return g.aligned == 2 ? launch_gemm_x3<AFORM, BFORM, true, EPI>(tile_id, g, nblocks, s)
+                              : launch_gemm_x3<AFORM, BFORM, false, EPI>(tile_id, g, nblocks, s);
     return g.aligned == 2 ? launch_gemm_vec<AFORM, BFORM, true, EPI>(tile_id, g, nblocks, s)
                           : launch_gemm_vec<AFORM, BFORM, false, EPI>(tile_id, g, nblocks, s);
 }
 
 int bk_of(int layout, int tile_id) {
-    if (tile_id == 3) return X3_BK;
+    if (tile_id >= 3) return X3_BK;
     if (tile_id == 0) return MMVAE_GEMM_BK0;
     return (tile_id == 1 && layout == MMVAE_GEMM_NT) ? 16 : 32;
 }
@@ -867,6 +1037,25 @@ void plan(int layout, int M, int N, int K, int* tile_id, int* splitk) {
     }
 }
 
+// bf16x3 tile for an unsplit GEMM over 16-byte-regular operands: the shape whose (rounds x tile area) is smallest
+// (20000 = 125 x 160: a 512 x 20000 output is 628 square tiles = 2 rounds of the 512 resident slots, but 500 tiles of
+// 128x160 = 1 round).  allow_tall: the 160x128 shape has no fused-recon instantiation.
+int x3_tile_for(int M, int N, bool allow_tall) {
+    const long slots = 512;
+    int best = 3;
+    long best_cost = -1;
+    for (int id = 3; id <= (allow_tall ? 5 : 4); ++id) {
+        const TileShape ts = tile_shape(0, id);
+        const long tiles = (long)ceil_div_i(M, ts.bm) * ceil_div_i(N, ts.bn);
+        const long cost = ((tiles + slots - 1) / slots) * ts.bm * ts.bn;
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = id;
+        }
+    }
+    return best;
+}
+
 }  // namespace
 
 extern "C" int mmvae_gemm_plan(int layout, int M, int N, int K, int* tile_out, int* splitk_out) {
@@ -901,7 +1090,10 @@ extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, cons
     plan(layout, M, N, K, &tile_id, &sk_auto);
     if (splitk == 0) splitk = sk_auto;
     if (splitk > 1 && tile_id == 1) tile_id = 0;  // split-K slices use the square tiles
-    if (g_precision == MMVAE_GEMM_PRECISION_BF16X3 && tile_id != 2) tile_id = 3;  // chip-filling GEMMs: bf16x3 cores
+    int aligned = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+    if (aligned && M % 4 == 0 && N % 4 == 0 && K % 4 == 0) aligned = 2;
+    if (g_precision == MMVAE_GEMM_PRECISION_BF16X3 && tile_id != 2)  // chip-filling GEMMs: bf16x3 cores
+        tile_id = (aligned == 2 && splitk == 1) ? x3_tile_for(M, N, true) : 3;
     const TileShape ts = tile_shape(layout, tile_id);
     const int ktiles = ceil_div_i(K, bk_of(layout, tile_id));
     const bool raw = (flags & MMVAE_GEMM_RAW_SLABS) != 0;
@@ -926,8 +1118,7 @@ extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, cons
     g.alpha = alpha;
     g.flags = flags;
     g.x_rows = 1;
-    g.aligned = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
-    if (g.aligned && M % 4 == 0 && N % 4 == 0 && K % 4 == 0) g.aligned = 2;
+    g.aligned = aligned;
     if (raw) {
         g.C = C;
         g.ldc = ldc;
@@ -962,13 +1153,18 @@ extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, cons
     return MMVAE_OK;
 }
 
-// Upper bound on the se_part rows written by the fused decoder/recon kernel (one row per column tile: 128 genes on the
-// bf16x3 path, 160 on the exact-f32 path).  Rows beyond the tiles actually written must be zero-initialised by the
-// caller ONCE (the library never reads what it did not write: mmvae_elbo_finalize takes T = mmvae_recon_tiles_used).
+// Rows of se_part the fused decoder/recon kernel defines (one row per column tile; the tile is 128 or 160 genes wide
+// depending on mode and shape -- rows beyond the tiles actually used are written as zeros).
 extern "C" int mmvae_recon_tiles(int G) {
     if (G <= 0) return 0;
     return ceil_div_i(G, g_precision == MMVAE_GEMM_PRECISION_BF16X3 ? 128 : 160);
 }
+
+#if MMVAE_X3_STAMPS
+extern "C" int mmvae_debug_x3_stamps(long long* out32) {
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_x3_stamps), sizeof(long long) * 32) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int mmvae_gemm_set_precision(int mode) {
     if (mode != MMVAE_GEMM_PRECISION_F32 && mode != MMVAE_GEMM_PRECISION_BF16X3) return MMVAE_ERR_ARG;
@@ -997,8 +1193,12 @@ extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, 
     g.N = G;
     g.K = H;
     const bool x3 = g_precision == MMVAE_GEMM_PRECISION_BF16X3;
+    g.aligned = aligned16(h) && aligned16(W) && (ldh % 4 == 0) && (ldw % 4 == 0);
+    if (g.aligned && rows % 4 == 0 && G % 4 == 0 && H % 4 == 0) g.aligned = 2;
+    const int tile_id = !x3 ? 1 : (g.aligned == 2 ? x3_tile_for(rows, G, false) : 3);
     g.mt = ceil_div_i(rows, 128);
-    g.nt = ceil_div_i(G, x3 ? 128 : 160);
+    g.nt = ceil_div_i(G, tile_shape(0, tile_id).bn);
+    g.se_tiles = mmvae_recon_tiles(G);  // rows nt .. se_tiles-1 of se_part are zeroed by the last column tile
     g.ktiles = ceil_div_i(H, x3 ? X3_BK : 16);
     g.ktiles_per_split = g.ktiles;
     g.alpha = 1.f;
@@ -1010,9 +1210,7 @@ extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, 
     g.ldxhat = ldxhat;
     g.lddp = lddp;
     g.x_rows = x_rows;
-    g.aligned = aligned16(h) && aligned16(W) && (ldh % 4 == 0) && (ldw % 4 == 0);
-    if (g.aligned && rows % 4 == 0 && G % 4 == 0 && H % 4 == 0) g.aligned = 2;
-    return launch_gemm_forms<FORM_KC, FORM_KC, EPI_RECON>(x3 ? 3 : 1, g, g.mt * g.nt, (hipStream_t)stream);
+    return launch_gemm_forms<FORM_KC, FORM_KC, EPI_RECON>(tile_id, g, g.mt * g.nt, (hipStream_t)stream);
 }
 
 extern "C" int mmvae_decoder_recon_f32(int B, int G, int H, const float* h, int64_t ldh, const float* W, int64_t ldw,

@@ -71,6 +71,25 @@ def test_gemm_random(ops, layout, M, N, K, splitk):
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(508, 19996, 72), (19996, 508, 72), (1024, 20000, 64), (20000, 1024, 40)])
+def test_gemm_wide_and_tall_tiles(ops, layout, M, N, K):
+    """Chip-filling outputs where the planner picks the 128x160 / 160x128 bf16x3 tiles (fewer rounds of resident
+    workgroups): ragged last tiles, a K tail (K % 32 != 0) and the DPP-transposed rows 128..159 of RC operands."""
+    a, b = _asym(M, K), _asym(K, N) + 1.0
+    A = a if layout != 2 else a.t().contiguous()
+    Bm = b.t().contiguous() if layout == 0 else b
+    out = ops.gemm(layout, dev(A), dev(Bm), splitk=1)
+    ref = dev(a).double() @ dev(b).double()
+    assert torch.equal(out.double(), ref), f"max err {(out.double() - ref).abs().max()}"
+    a, b = rnd(M, K, seed=11), rnd(K, N, seed=12)
+    A = a if layout != 2 else a.t().contiguous()
+    Bm = b.t().contiguous() if layout == 0 else b
+    out = ops.gemm(layout, dev(A), dev(Bm), splitk=1)
+    ref = dev(a).double() @ dev(b).double()
+    assert rel_l2(out.cpu(), ref.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
 def test_gemm_unaligned_strides(ops, layout):
     """Leading dimensions that are not multiples of 4 floats (e.g. 60530 / 52437-gene matrices)."""
     M, N, K = 70, 45, 131
@@ -103,7 +122,8 @@ def test_gemm_raw_slabs(ops, layout):
     assert rel_l2(slabs.sum(0), a.double() @ b.double()) < 2e-6
 
 
-@pytest.mark.parametrize("R,B,G,H", [(8, 8, 64, 48), (33, 33, 257, 72), (128, 128, 2000, 256), (66, 33, 131, 40)])
+@pytest.mark.parametrize("R,B,G,H", [(8, 8, 64, 48), (33, 33, 257, 72), (128, 128, 2000, 256), (66, 33, 131, 40),
+                                     (512, 512, 19996, 72), (1024, 512, 20000, 64)])
 def test_decoder_recon(ops, R, B, G, H):
     h, W, bias = rnd(R, H, seed=1), rnd(G, H, seed=2, scale=0.2), rnd(G, seed=3, scale=0.1)
     x = rnd(B, G, seed=4).abs()
@@ -121,6 +141,10 @@ def test_decoder_recon(ops, R, B, G, H):
     # optional outputs off
     _, _, se2 = ops.decoder_recon(dev(h), dev(W), dev(bias), dev(x), want_xhat=False, want_dP=False)
     assert torch.equal(se2, se_part)
+    # every row of se_part is defined by the call (tile rows the chosen tiling does not use are written as zeros)
+    poisoned = torch.full((ops.recon_tiles(G), R), float("nan"), device="cuda")
+    _, _, se3 = ops.decoder_recon(dev(h), dev(W), dev(bias), dev(x), want_xhat=False, want_dP=False, se_part=poisoned)
+    assert torch.equal(se3, se_part)
 
 
 # --------------------------------------------------------------------------------------------------- FC epilogues
