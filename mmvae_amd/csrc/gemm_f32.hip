@@ -28,6 +28,9 @@ namespace {
 #ifndef MMVAE_GEMM_BK0
 #define MMVAE_GEMM_BK0 32  // k-tile of the 128x128 block tile
 #endif
+#ifndef MMVAE_X3_PERSISTENT
+#define MMVAE_X3_PERSISTENT 0  // 1: grid capped at 512 workgroups looping over work items (measured: no gain)
+#endif
 #ifndef MMVAE_X3_STAMPS
 #define MMVAE_X3_STAMPS 0  // diagnostic build: per-phase cycle sums of the bf16x3 loop (block 0, one lane per wave)
 #endif
@@ -78,6 +81,8 @@ struct GemmArgs {
     int64_t ldx, ldxhat, lddp;
     int x_rows;    // x row = output row % x_rows (K-sample decode stacks K copies of the batch)
     int se_tiles;  // rows of se_part the caller reads (>= nt); the last column tile zeroes rows nt .. se_tiles-1
+    int c_vec;     // C (or the slabs) 16-byte regular: aligned base, ldc % 4 == 0, N % 4 == 0 -> 16-byte epilogue stores
+    int nwork;     // bf16x3 kernel: work items (output tiles x split-K slices), looped over by <= 512 workgroups
 };
 
 // HBM -> registers.  r0: first row (KC) / column (RC) of this tile along the non-K axis, Rtot its extent.
@@ -161,6 +166,13 @@ __device__ __forceinline__ f32x4 load_frag(const float* S, int row, int kk, int 
     }
 }
 
+// value of lane (quad base + S_q) for lane q of each quad (DPP quad_perm)
+template <int S0, int S1, int S2, int S3>
+__device__ __forceinline__ float quad_perm(float v) {
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(0, __float_as_int(v), S0 | (S1 << 2) | (S2 << 4) | (S3 << 6), 0xF, 0xF, true));
+}
+
 // Epilogue shared by the fp32-MFMA and the bf16x3-MFMA kernels (the C/D register layout of the 32x32 MFMAs is
 // dtype-independent): col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
 template <int BM, int BN, int WGM, int WGN, int EPI, int TM, int TN>
@@ -178,6 +190,49 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
         const bool accum = !raw && (g.flags & MMVAE_GEMM_ACCUMULATE);
         const bool relu = !raw && (g.flags & MMVAE_GEMM_RELU);
         const float alpha = raw ? 1.f : g.alpha;
+        if (g.c_vec) {
+            // 16-byte stores: the 4 lanes of a quad hold a 4 row x 4 column patch column-wise (one column each, rows
+            // e = 4 gq .. 4 gq + 3); a quad transpose (2 DPP exchange stages) gives every lane one row x 4 columns.
+            // A quarter of the store instructions of the dword path: the epilogue is store-issue bound when every
+            // workgroup of a round stores at once.
+            const int q = lane & 3;
+            const bool odd = q & 1, hi = q & 2;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    const int col = bn * BN + wn * WTN + n * 32 + (l31 & ~3);
+                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (!raw && g.bias && col < g.N) bv = *reinterpret_cast<const f32x4*>(g.bias + col);
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        float a0 = acc[i][n][4 * gq], a1 = acc[i][n][4 * gq + 1], a2 = acc[i][n][4 * gq + 2],
+                              a3 = acc[i][n][4 * gq + 3];
+                        // stage 1: exchange with lane ^ 1
+                        const float r0 = quad_perm<1, 0, 3, 2>(odd ? a0 : a1), r1 = quad_perm<1, 0, 3, 2>(odd ? a2 : a3);
+                        const float c0 = odd ? r0 : a0, c1 = odd ? a1 : r0, c2 = odd ? r1 : a2, c3 = odd ? a3 : r1;
+                        // stage 2: exchange with lane ^ 2
+                        const float t0 = quad_perm<2, 3, 0, 1>(hi ? c0 : c2), t1 = quad_perm<2, 3, 0, 1>(hi ? c1 : c3);
+                        f32x4 v;
+                        v[0] = hi ? t0 : c0;
+                        v[1] = hi ? t1 : c1;
+                        v[2] = hi ? c2 : t0;
+                        v[3] = hi ? c3 : t1;
+                        const int row = bm * BM + wm * WTM + i * 32 + 8 * gq + 4 * half + q;
+                        if (row < g.M && col < g.N) {
+                            float* cp = C + (int64_t)row * g.ldc + col;
+                            v = v * alpha + bv;
+                            if (accum) v += *reinterpret_cast<const f32x4*>(cp);
+                            if (relu) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                            }
+                            *reinterpret_cast<f32x4*>(cp) = v;
+                        }
+                    }
+                }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -375,6 +430,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #if MMVAE_X3_STAMPS
 __device__ long long g_x3_stamps[32];
+__device__ long long g_x3_trace[4096 * 4];  // per workgroup: 100 MHz wall clock at entry, loop start, loop end, exit
 #endif
 constexpr int X3_BK = 32;
 constexpr int X3_LD = 80;  // bytes per LDS row per plane
@@ -679,11 +735,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
     const int l31 = lane & 31, half = lane >> 5;
 
     const int nwg = gridDim.x, bid = blockIdx.x;
+#if MMVAE_X3_STAMPS
+    if (tid == 0 && bid < 4096) g_x3_trace[bid * 4 + 0] = wall_clock64();
+#endif
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int tiles = g.mt * g.nt;
-    const int z = L / tiles;
-    const int t = L - z * tiles;
+    // Persistent over work items (output tile x split-K slice): the grid is at most the chip's resident slots, and a
+    // workgroup's epilogue stores drain behind the main loop of its next item instead of idling the matrix cores
+    // (a 128x160 tile's epilogue is 14 us of a 77 us item when 512 workgroups store at once).
+    for (int w = L; w < g.nwork; w += nwg) {
+    const int z = w / tiles;
+    const int t = w - z * tiles;
     const int bm = t % g.mt, bn = t / g.mt;
 
     const int kt_beg = z * g.ktiles_per_split;
@@ -755,6 +818,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
             write_all();
             __syncthreads();
 #if MMVAE_X3_STAMPS
+            if (tid == 0 && bid < 4096) g_x3_trace[bid * 4 + 1] = wall_clock64();
             long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             long long tprev = clock64();
 #define X3_STAMP(i)                       \
@@ -857,6 +921,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
                 for (int i = 0; i < 7; ++i) g_x3_stamps[wave * 8 + i] = st[i];
                 g_x3_stamps[wave * 8 + 7] = nkt;
             }
+            if (tid == 0 && bid < 4096) g_x3_trace[bid * 4 + 2] = wall_clock64();
 #endif
         } else {  // element-guarded (unaligned) matrices: plain loop, square tile
             constexpr int NVA = X3Regs<AFORM, BM>::NV, NVB = X3Regs<BFORM, BN>::NV;
@@ -900,9 +965,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
         }
     }
 #if MMVAE_X3_ABLATE == 5  // no epilogue (accumulators kept alive through a never-taken branch)
-    if (g.alpha != 123.456f) return;
+    if (g.alpha != 123.456f) continue;
 #endif
     gemm_epilogue<BM, BN, WGM, WGN, EPI>(acc, g, bm, bn, z, reinterpret_cast<float*>(lds));
+    if (EPI == EPI_RECON) __syncthreads();  // the epilogue's LDS scratch is overwritten by the next item's prologue
+    }  // work items
+#if MMVAE_X3_STAMPS
+    if (tid == 0 && bid < 4096) {
+        __builtin_amdgcn_s_waitcnt(0);  // stores of this wave issued and acknowledged
+        g_x3_trace[bid * 4 + 3] = wall_clock64();
+    }
+#endif
 }
 
 // Fixed-order reduction of split-K slabs + the standard epilogue.
@@ -963,7 +1036,14 @@ int launch_gemm_vec(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) 
 int g_precision = MMVAE_GEMM_PRECISION_BF16X3;  // process-wide, set by mmvae_gemm_set_precision
 
 template <int AFORM, int BFORM, bool VEC, int EPI>
-int launch_gemm_x3(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) {
+int launch_gemm_x3(int tile_id, const GemmArgs& g0, int nwork, hipStream_t s) {
+    GemmArgs g = g0;
+    g.nwork = nwork;
+#if MMVAE_X3_PERSISTENT
+    const int nblocks = nwork < 512 ? nwork : 512;  // 2 resident workgroups per CU: the rest is looped over
+#else
+    const int nblocks = nwork;
+#endif
     if (VEC && tile_id == 4)
         hipLaunchKernelGGL((gemm_x3_kernel<AFORM, BFORM, 128, 160, 4, 1, true, EPI>), dim3(nblocks), dim3(NT), 0, s, g);
     else if (VEC && tile_id == 5 && EPI == EPI_STD)
@@ -1133,6 +1213,8 @@ extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, cons
         g.ldc = ldc;
         g.slab_stride = 0;
     }
+    g.c_vec = aligned16(g.C) && g.ldc % 4 == 0 && N % 4 == 0 && (g.slab_stride % 4 == 0) &&
+              (!bias || aligned16(bias)) ? 1 : 0;
     const int nblocks = g.mt * g.nt * splitk;
     int rc;
     if (layout == MMVAE_GEMM_NT)
@@ -1163,6 +1245,9 @@ extern "C" int mmvae_recon_tiles(int G) {
 #if MMVAE_X3_STAMPS
 extern "C" int mmvae_debug_x3_stamps(long long* out32) {
     return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_x3_stamps), sizeof(long long) * 32) == hipSuccess ? 0 : 1;
+}
+extern "C" int mmvae_debug_x3_trace(long long* out, int n_blocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x3_trace), sizeof(long long) * 4 * n_blocks) == hipSuccess ? 0 : 1;
 }
 #endif
 

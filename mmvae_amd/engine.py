@@ -112,6 +112,8 @@ class StepEngine:
         self._klw_host = None
         self.world = mdist.world_size()
         # weight-gradient GEMMs run on a side stream inside the captured graph (fork/join edges)
+        if os.environ.get("MMVAE_SIDE_STREAM", "0") != "0":
+            side_stream = True
         self.side_stream = torch.cuda.Stream(device=self.device) if side_stream else None
         # only the small (latency-bound) weight-gradient GEMMs go aside; chip-filling ones stay in order on the main stream
         self.side_max_elems = int(os.environ.get("MMVAE_SIDE_MAX_ELEMS", 2 * 1024 * 1024))

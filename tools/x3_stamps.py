@@ -25,7 +25,24 @@ for name, (lay, a, b, shp) in cases.items():
     torch.cuda.synchronize()
     buf = (ctypes.c_longlong * 32)()
     assert fn(buf) == 0
-    print(name)
+    nb = 2048
+    tr = (ctypes.c_longlong * (4 * nb))()
+    assert lib.mmvae_debug_x3_trace(tr, nb) == 0
+    import numpy as np
+    T = np.array(tr[:], dtype=np.int64).reshape(nb, 4)
+    T = T[T[:, 3] > 0]
+    t0 = T[:, 0].min()
+    T = (T - t0) / 100.0  # us
+    order = np.argsort(T[:, 0])
+    T = T[order]
+    print(name, f": {len(T)} workgroups; kernel span {T[:, 3].max():.1f} us")
+    print(f"   entry: first wave of workgroups (<5us) {int((T[:, 0] < 5).sum())}, later starts at "
+          f"{np.percentile(T[T[:, 0] >= 5, 0], [0, 50, 100]) if (T[:, 0] >= 5).any() else '-'} us")
+    print(f"   prologue (entry->loop) median {np.median(T[:, 1] - T[:, 0]):.1f} us, max {np.max(T[:, 1] - T[:, 0]):.1f}")
+    print(f"   main loop median {np.median(T[:, 2] - T[:, 1]):.1f} us, min {np.min(T[:, 2] - T[:, 1]):.1f}, max {np.max(T[:, 2] - T[:, 1]):.1f}")
+    print(f"   epilogue median {np.median(T[:, 3] - T[:, 2]):.1f} us, max {np.max(T[:, 3] - T[:, 2]):.1f}")
+    first = T[T[:, 0] < 5]
+    print(f"   first-round exits: {np.percentile(first[:, 3], [0, 50, 100])} us")
     for w in range(4):
         n = buf[w * 8 + 7]
         tot = sum(buf[w * 8 + i] for i in range(7))
