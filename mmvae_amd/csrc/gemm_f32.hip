@@ -254,6 +254,62 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
     } else {
         // bias + ReLU + squared error + dP; per-cell SE reduced over the 32 lanes that share a row.
         float* rowsum = lds;  // [WGN][BM] scratch: the operand tiles are dead after the final barrier
+        if (g.c_vec) {
+            // 16-byte path (x, xhat, dP 16-byte regular): quad transpose as in the standard epilogue, so that x is
+            // read and xhat / dP are written as one row x 4 genes per lane; the row's SE is then the sum over the 8
+            // lanes of a half that share q = lane & 3 (strides 4, 8, 16).
+            const int q = lane & 3;
+            const bool odd = q & 1, hi = q & 2;
+            f32x4 bv[TN];
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                const int col = bn * BN + wn * WTN + n * 32 + (l31 & ~3);
+                bv[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (g.bias && col < g.N) bv[n] = *reinterpret_cast<const f32x4*>(g.bias + col);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int rloc = wm * WTM + i * 32 + 8 * gq + 4 * half + q;
+                    const int row = bm * BM + rloc;
+                    const int xr = row % g.x_rows;
+                    float sr = 0.f;
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) {
+                        const float a0 = acc[i][n][4 * gq], a1 = acc[i][n][4 * gq + 1], a2 = acc[i][n][4 * gq + 2],
+                                    a3 = acc[i][n][4 * gq + 3];
+                        const float r0 = quad_perm<1, 0, 3, 2>(odd ? a0 : a1), r1 = quad_perm<1, 0, 3, 2>(odd ? a2 : a3);
+                        const float c0 = odd ? r0 : a0, c1 = odd ? a1 : r0, c2 = odd ? r1 : a2, c3 = odd ? a3 : r1;
+                        const float t0 = quad_perm<2, 3, 0, 1>(hi ? c0 : c2), t1 = quad_perm<2, 3, 0, 1>(hi ? c1 : c3);
+                        f32x4 p;
+                        p[0] = hi ? t0 : c0;
+                        p[1] = hi ? t1 : c1;
+                        p[2] = hi ? c2 : t0;
+                        p[3] = hi ? c3 : t1;
+                        const int col = bn * BN + wn * WTN + n * 32 + (l31 & ~3);
+                        if (row < g.M && col < g.N) {
+                            p += bv[n];
+                            const f32x4 xv = *reinterpret_cast<const f32x4*>(g.x + (int64_t)xr * g.ldx + col);
+                            f32x4 xh, dp;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                xh[j] = fmaxf(p[j], 0.f);
+                                const float d = xh[j] - xv[j];
+                                sr += d * d;
+                                dp[j] = (p[j] > 0.f) ? 2.f * d : 0.f;
+                            }
+                            if (g.xhat) *reinterpret_cast<f32x4*>(g.xhat + (int64_t)row * g.ldxhat + col) = xh;
+                            if (g.dP) *reinterpret_cast<f32x4*>(g.dP + (int64_t)row * g.lddp + col) = dp;
+                        }
+                    }
+                    sr += __shfl_xor(sr, 4, 64);
+                    sr += __shfl_xor(sr, 8, 64);
+                    sr += __shfl_xor(sr, 16, 64);
+                    if (l31 < 4) rowsum[wn * BM + rloc] = sr;
+                }
+            }
+        } else {
         float bv[TN];
 #pragma unroll
         for (int n = 0; n < TN; ++n) {
@@ -285,6 +341,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
                 s = half_wave_sum(s);
                 if (l31 == 0) rowsum[wn * BM + rloc] = s;
             }
+        }
         }
         __syncthreads();
         if (tid < BM) {
@@ -1295,6 +1352,8 @@ extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, 
     g.ldxhat = ldxhat;
     g.lddp = lddp;
     g.x_rows = x_rows;
+    g.c_vec = G % 4 == 0 && aligned16(x) && ldx % 4 == 0 && (!xhat || (aligned16(xhat) && ldxhat % 4 == 0)) &&
+              (!dP || (aligned16(dP) && lddp % 4 == 0)) && (!bias || aligned16(bias));
     return launch_gemm_forms<FORM_KC, FORM_KC, EPI_RECON>(tile_id, g, g.mt * g.nt, (hipStream_t)stream);
 }
 
