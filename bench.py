@@ -36,14 +36,15 @@ def parse():
 # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks (no sparsity)
 BF16_DENSE_TFLOPS = 2500.0
 F32_MFMA_TFLOPS = 157.3
-# HBM bytes per launch of the roofline kernel from the PMC pass in profiles/ (TCC_EA0_RDREQ/WRREQ-derived, corrected as
-# the guide prescribes); None until that pass has been collected for the shipped kernel.
-HBM_TRAFFIC_PMC_BYTES = None
+# HBM bytes per launch of the roofline kernel, from the separate rocprofv3 --pmc passes summarised in
+# profiles/r1_pmc_roofline_kernel.csv: 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, in KiB.
+# Algorithmic bytes of the launch: 4 (B*1024 + B*G + 1024*G) = 125.0 MB (X is re-read by the 8 row tiles: 2x fetch).
+HBM_TRAFFIC_PMC_BYTES = (2 * 40400 + 80000) * 1024
 
 
 def time_dominant_kernel(cfg, device, iters=20):
-    """Roofline leg: the dominant kernel of the step (3 launches per step, ~25 % of the GPU time in
-    profiles/r1_bench_kernel_stats.csv) -- the weight-gradient GEMM of a G-wide layer, dW[1024, G] = dY^T[1024, B] .
+    """Roofline leg: the dominant kernel of the step (2 launches per step -- enc-L1 dW and, with the tile transposed,
+    dec-L2 dW -- ~23 % of the GPU time in profiles/r1_bench_kernel_stats.csv) -- the weight-gradient GEMM of a G-wide layer, dW[1024, G] = dY^T[1024, B] .
     X[B, G] (TN layout, fp32 in / fp32 out, computed as 6 bf16 MFMAs per product = gemm_x3_kernel<TN>) -- launched on
     the current stream with HIP events around each launch.  Returns (avg seconds per launch, algorithmic FLOPs per
     launch = 2 M N K)."""
@@ -57,13 +58,15 @@ def time_dominant_kernel(cfg, device, iters=20):
     for _ in range(3):
         ops.gemm(ops.GEMM_TN, dY, X, out=dW, splitk=1)
     torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-    for s, e in evs:
-        s.record()
+    # one event pair around `iters` back-to-back launches on the launch stream: the average is the kernel's duration
+    # (an event pair per launch would add the ~10 us host launch latency to every sample)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
         ops.gemm(ops.GEMM_TN, dY, X, out=dW, splitk=1)
-        e.record()
+    e1.record()
     torch.cuda.synchronize()
-    t = sum(s.elapsed_time(e) for s, e in evs) / iters * 1e-3
+    t = e0.elapsed_time(e1) / iters * 1e-3
     return t, 2.0 * H1 * G * B
 
 
@@ -199,7 +202,7 @@ def main():
         # flops is the dense bf16 peak / 6; the exact-f32 mode is bounded by the fp32 MFMA peak.
         peak = BF16_DENSE_TFLOPS / 6.0 if x3 else F32_MFMA_TFLOPS
         out["roofline"] = {"bound": "mfma",
-                           "kernel": ("gemm_x3_kernel<TN,128x128> (bf16x3 MFMA)" if x3 else "gemm_f32_kernel<TN> (f32 MFMA)")
+                           "kernel": ("gemm_x3_kernel<TN,128x160> (bf16x3 MFMA)" if x3 else "gemm_f32_kernel<TN> (f32 MFMA)")
                                      + ": dW of a G-wide layer",
                            "achieved": fl / tk / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl / tk / (peak * 1e12),
                            "traffic": HBM_TRAFFIC_PMC_BYTES, "us_per_launch": tk * 1e6, "flops_per_launch": fl,

@@ -76,7 +76,8 @@ const char* mmvae_build_arch(void);
 int mmvae_gemm_set_precision(int mode);
 int mmvae_gemm_get_precision(void);
 
-/* Library heuristic: picks the block tile (128 or 64) and split-K factor for a shape.  Pure host function. */
+/* Library heuristic: picks the block tile (128 or 64; the bf16x3 path may widen a 128 tile to 128x160 / 160x128 at
+ * launch when that needs fewer rounds of resident workgroups) and split-K factor for a shape.  Pure host function. */
 int mmvae_gemm_plan(int layout, int M, int N, int K, int* tile_out, int* splitk_out);
 size_t mmvae_gemm_workspace_bytes(int layout, int M, int N, int K, int splitk);
 
@@ -93,6 +94,8 @@ int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, const float* A,
  *   xhat   = max(P, 0)                                   (optional store)
  *   dP     = 2 (xhat - x) * 1[P > 0]                     (optional store; unscaled d recon / d P)
  *   se_part[t, b] = sum over the genes of column tile t of (xhat - x)^2                 (t < mmvae_recon_tiles(G))
+ *                   The column tile is 128 or 160 genes wide (mode and shape decide); all mmvae_recon_tiles(G) rows
+ *                   are written by every call, rows the chosen tiling does not use as zeros.
  *
  * The per-cell squared error is reduced across the wavefront with shuffles inside the GEMM epilogue; the
  * [tiles, B] partials are summed in fixed order by mmvae_elbo_finalize (bitwise reproducible, no atomics).
