@@ -151,7 +151,10 @@ int mmvae_fc_epilogue_fwd(int B, int N, const float* in, int64_t ld_in, int n_sl
  *   no BN: dz = dy
  *   dbias = sum_b dz                                         (grad of the Linear bias; ahead of a BatchNorm this is
  *                                                             zero in exact arithmetic and is evaluated in closed form)
- * dz_out may be NULL (pure column sum).  dz_out may alias din when n_slabs == 1. */
+ * dz_out may be NULL (pure column sum).  dz_out may alias din when n_slabs == 1.
+ * Without BN, a non-NULL workspace always receives the per-row-chunk column partials of dz as [ceil(B/32)][N] floats;
+ * they are summed into dbias when dbias is non-NULL.  With dbias == NULL the caller finishes them itself, e.g.
+ * together with other pending reductions in one mmvae_sum_parts_batch launch. */
 int mmvae_fc_epilogue_bwd(int B, int N, const float* din, int64_t ld_in, int n_slabs, const float* addend,
                           const float* row_scale, const uint8_t* keep_mask, float dropout_p, int relu,
                           const float* a, const float* z, const float* gamma, const float* save_mean,
@@ -262,6 +265,22 @@ int mmvae_philox_normal(int64_t n, float* out, uint64_t* rng_state, uint64_t str
                         mmvae_stream_t stream);
 /* rng_state[1] += by  (one call at the end of a step whose fills used distinct stream_ids with advance = 0). */
 int mmvae_philox_advance(uint64_t* rng_state, uint64_t by, mmvae_stream_t stream);
+
+/* Batched fixed-order reduction of partial results: for every job
+ *     dst[r, c] (+)= alpha * sum_{p < n_parts} src[p * part_stride + r * ld_src + c]        (p ascending)
+ * in ONE launch (grid.y = job).  Finishes split-K slabs of several weight-gradient GEMMs (MMVAE_GEMM_RAW_SLABS) and
+ * the column partials of mmvae_fc_epilogue_bwd together, where one launch per reduction would cost more than the
+ * reductions (a dependent launch is ~4.5 us inside a hipGraph).  `jobs` is a DEVICE array.  flags: MMVAE_GEMM_ACCUMULATE. */
+typedef struct {
+    const float* src;
+    float* dst;
+    int64_t part_stride, ld_src, ld_dst;
+    int32_t n_parts, rows, cols;
+    float alpha;
+    uint32_t flags;
+    uint32_t reserved;
+} mmvae_sum_job;
+int mmvae_sum_parts_batch(int n_jobs, const mmvae_sum_job* jobs, mmvae_stream_t stream);
 
 /* Small utilities used by the step engine: y = alpha*x (+ y), fill. */
 int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, float* y, mmvae_stream_t stream);

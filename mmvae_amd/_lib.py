@@ -83,7 +83,15 @@ PROTOTYPES = {
     "mmvae_philox_advance": (_i, [_p, _u64, _p]),
     "mmvae_axpby": (_i, [_l, _f, _p, _f, _p, _p]),
     "mmvae_scale_rows": (_i, [_i, _i, _p, _l, _p, _p, _l, _p]),
+    "mmvae_sum_parts_batch": (_i, [_i, _p, _p]),
 }
+
+
+class SumJob(C.Structure):
+    """mmvae_sum_job (include/mmvae_hip.h): one fixed-order reduction of mmvae_sum_parts_batch."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("part_stride", C.c_int64), ("ld_src", C.c_int64),
+                ("ld_dst", C.c_int64), ("n_parts", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("alpha", C.c_float), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class HipLibraryError(RuntimeError):

@@ -432,6 +432,40 @@ __global__ __launch_bounds__(256) void axpby4_kernel(int64_t n4, float alpha, co
     }
 }
 
+// One workgroup column (blockIdx.y) per job; elements of a job are spread over gridDim.x workgroups.
+__global__ __launch_bounds__(256) void sum_parts_batch_kernel(const mmvae_sum_job* __restrict__ jobs) {
+    const mmvae_sum_job j = jobs[blockIdx.y];
+    const bool acc = j.flags & MMVAE_GEMM_ACCUMULATE;
+    const bool vec = (j.cols % 4 == 0) && (j.ld_src % 4 == 0) && (j.ld_dst % 4 == 0) && (j.part_stride % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(j.src) | reinterpret_cast<uintptr_t>(j.dst)) & 15) == 0;
+    if (vec) {
+        const int c4n = j.cols / 4;
+        const int64_t total = (int64_t)j.rows * c4n;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            const int r = (int)(i / c4n), c = (int)(i - (int64_t)r * c4n) * 4;
+            const float* sp = j.src + (int64_t)r * j.ld_src + c;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < j.n_parts; ++p) s += *reinterpret_cast<const f32x4*>(sp + (int64_t)p * j.part_stride);
+            f32x4 v = s * j.alpha;
+            float* dp = j.dst + (int64_t)r * j.ld_dst + c;
+            if (acc) v += *reinterpret_cast<const f32x4*>(dp);
+            *reinterpret_cast<f32x4*>(dp) = v;
+        }
+    } else {
+        const int64_t total = (int64_t)j.rows * j.cols;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            const int r = (int)(i / j.cols), c = (int)(i - (int64_t)r * j.cols);
+            const float* sp = j.src + (int64_t)r * j.ld_src + c;
+            float s = 0.f;
+            for (int p = 0; p < j.n_parts; ++p) s += sp[(int64_t)p * j.part_stride];
+            float v = s * j.alpha;
+            float* dp = j.dst + (int64_t)r * j.ld_dst + c;
+            if (acc) v += *dp;
+            *dp = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void scale_rows_kernel(int B, int N, const float* __restrict__ x, int64_t ldx,
                                                          const float* __restrict__ rs, float* __restrict__ y,
                                                          int64_t ldy) {
@@ -597,6 +631,13 @@ extern "C" int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, f
     else
         hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, n, alpha, x,
                            beta, y);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_sum_parts_batch(int n_jobs, const mmvae_sum_job* jobs, mmvae_stream_t stream) {
+    if (n_jobs <= 0 || n_jobs > 65535 || !jobs) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(sum_parts_batch_kernel, dim3(64, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }

@@ -438,8 +438,8 @@ extern "C" int mmvae_fc_epilogue_bwd(int B, int N, const float* din, int64_t ld_
     if (relu && !a_act) return MMVAE_ERR_ARG;
     if (keep_mask && (dropout_p < 0.f || dropout_p >= 1.f)) return MMVAE_ERR_ARG;
     if (has_bn && (!z || !save_mean || !save_invstd || !dz_out)) return MMVAE_ERR_ARG;
-    if (!dz_out && !dbias) return MMVAE_ERR_ARG;
-    const bool need_ws = has_bn || dbias;
+    if (!dz_out && !dbias && !workspace) return MMVAE_ERR_ARG;
+    const bool need_ws = has_bn || dbias || workspace;  // without BN a given workspace always receives the partials
     if (need_ws && (!workspace || workspace_bytes < mmvae_fc_workspace_bytes(B, N))) return MMVAE_ERR_WORKSPACE;
     BwdArgs a = {};
     a.din = din;

@@ -112,6 +112,7 @@ class StepEngine:
         self._klw_host = None
         self.world = mdist.world_size()
         # weight-gradient GEMMs run on a side stream inside the captured graph (fork/join edges)
+        self.batch_finish = os.environ.get("MMVAE_BATCH_FINISH", "1") != "0"
         if os.environ.get("MMVAE_SIDE_STREAM", "0") != "0":
             side_stream = True
         self.side_stream = torch.cuda.Stream(device=self.device) if side_stream else None
@@ -246,6 +247,9 @@ class _Plan:
         self.metric_slots: Dict[str, int] = {}
         self.segments: List = []  # list of closure lists, separated by ("allreduce", opt) markers
         self._cur: List = []
+        self._sum_jobs: List = []      # reductions queued for the next mmvae_sum_parts_batch launch
+        self._sum_keep: List = []
+        self._job_tables: List = []    # device job tables of the launches already emitted
         self._ws_bytes = 0
         self._slab_floats = 0
         self._graphs: Optional[list] = None
@@ -289,6 +293,14 @@ class _Plan:
         """Complete GEMM (internal split-K reduce through a workspace when the plan asks for it).  side=True runs it
         on the engine's side stream (weight gradients: off the backward critical path) with its own workspace."""
         sk = self._plan_gemm(layout, M, N, K)
+        if side and sk > 1 and self.eng.batch_finish and not (flags & ~ACC) and bias is None:
+            # weight gradient with a split: raw slabs into a buffer of its own, summed later together with every other
+            # pending reduction of the backward pass in ONE mmvae_sum_parts_batch launch (a reduce launch per GEMM is
+            # ~5 us of pure launch cost)
+            slabs = self.eng.buf(f"dwslabs.{self._next_defer_id()}", (sk, M, N))
+            self._emit_gemm(layout, M, N, K, 1.0, A, lda, Bm, ldb, slabs, N, None, RAW, sk, False)
+            self._defer_sum(slabs, sk, M * N, M, N, N, Cm, ldc, alpha, flags & ACC)
+            return
         nbytes = self.lib.mmvae_gemm_workspace_bytes(layout, M, N, K, sk)
         if side and self.eng.side_stream is not None and M * N <= self.eng.side_max_elems:
             self._ws_side_bytes = max(getattr(self, "_ws_side_bytes", 0), nbytes)
@@ -319,6 +331,27 @@ class _Plan:
 
         self._cur.append(call)
         self._side_dirty = False
+
+    def _next_defer_id(self) -> int:
+        # position in this plan's program: the same geometry built again (another input pointer) shares the buffers
+        self._defer_id = getattr(self, "_defer_id", 0) + 1
+        return self._defer_id
+
+    def _defer_sum(self, src, n_parts, part_stride, rows, cols, ld_src, dst, ld_dst, alpha=1.0, flags=0):
+        """Queue dst[rows, cols] (+)= alpha * sum of n_parts partial results at src; see _flush_sums."""
+        self._sum_jobs.append(_lib.SumJob(_p(src), _p(dst), part_stride, ld_src, ld_dst, n_parts, rows, cols, float(alpha),
+                                          int(flags), 0))
+        self._sum_keep.append((src, dst))
+
+    def _flush_sums(self):
+        """One launch for every reduction queued since the last flush (before anything reads those gradients)."""
+        if not self._sum_jobs:
+            return
+        arr = (_lib.SumJob * len(self._sum_jobs))(*self._sum_jobs)
+        jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.eng.device)
+        self._job_tables.append(jobs_dev)  # lives as long as the plan (the captured graph reads it on every replay)
+        self._emit(self.lib.mmvae_sum_parts_batch, len(self._sum_jobs), jobs_dev.data_ptr())
+        self._sum_jobs = []
 
     def gemm_raw(self, layout, M, N, K, A, lda, Bm, ldb) -> int:
         """Raw split-K slabs into the shared slab buffer; returns the slab count."""
@@ -393,13 +426,18 @@ class _Plan:
         relu_src = l.a if l.a is not None else l.d
         has_bn = l.bn is not None
 
+        own_ws = None
+        if not has_bn and l.gb is not None and self.eng.batch_finish:
+            own_ws = self._bias_partials(rows, l.n_out, l.gb)
+
         def call():
             din_ptr = _p(din) if din is not None else plan.slab.data_ptr()
+            ws = own_ws if own_ws is not None else plan.fcws
             rc = plan.lib.mmvae_fc_epilogue_bwd(
                 rows, l.n_out, din_ptr, l.n_out, S_in, _p(addend), None, _p(l.mask), l.p, int(l.relu),
                 _p(relu_src) if l.relu else None, _p(l.z), _p(l.bn.weight) if has_bn else None, _p(l.mean),
-                _p(l.invstd), int(has_bn), _p(l.dz), l.n_out, _p(l.gb), _p(l.ggamma) if has_bn else None,
-                _p(l.gbeta) if has_bn else None, plan.fcws.data_ptr(), plan.fcws.numel() * 4, _s())
+                _p(l.invstd), int(has_bn), _p(l.dz), l.n_out, _p(l.gb) if own_ws is None else None,
+                _p(l.ggamma) if has_bn else None, _p(l.gbeta) if has_bn else None, ws.data_ptr(), ws.numel() * 4, _s())
             if rc != 0:
                 raise _lib.HipLibraryError(f"mmvae_fc_epilogue_bwd failed with code {rc}")
 
@@ -413,15 +451,25 @@ class _Plan:
                       alpha=dx_alpha)
         return 0
 
+    def _bias_partials(self, rows, N, dbias):
+        """A [ceil(rows/32), N] partial-column-sum buffer of its own for one layer + the deferred sum into dbias."""
+        RC = (rows + 31) // 32
+        nfl = max(self.lib.mmvae_fc_workspace_bytes(rows, N) // 4, RC * N)
+        ws = self.eng.buf(f"biasparts.{self._next_defer_id()}", (nfl,))
+        self._defer_sum(ws, RC, N, 1, N, N, dbias, N)
+        return ws
+
     def _emit_fc_bwd(self, rows, N, din, addend, row_scale, dz_out, dbias):
         """Plain (no BN / ReLU / mask) column pass: dz = row_scale * (din + addend) (optional), dbias = column sums."""
         plan = self
         self._fcws_bytes = max(getattr(self, "_fcws_bytes", 0), self.lib.mmvae_fc_workspace_bytes(rows, N))
+        own_ws = self._bias_partials(rows, N, dbias) if (dbias is not None and self.eng.batch_finish) else None
 
         def call():
+            ws = own_ws if own_ws is not None else plan.fcws
             rc = plan.lib.mmvae_fc_epilogue_bwd(rows, N, _p(din), N, 1, _p(addend), _p(row_scale), None, 0.0, 0, None, None,
-                                                None, None, None, 0, _p(dz_out), N, _p(dbias), None, None,
-                                                plan.fcws.data_ptr(), plan.fcws.numel() * 4, _s())
+                                                None, None, None, 0, _p(dz_out), N, _p(dbias) if own_ws is None else None,
+                                                None, None, ws.data_ptr(), ws.numel() * 4, _s())
             if rc != 0:
                 raise _lib.HipLibraryError(f"mmvae_fc_epilogue_bwd (column sum) failed with code {rc}")
 
@@ -429,6 +477,7 @@ class _Plan:
 
     def optimizer(self, opt: HipAdam, max_norm: float, advance: bool = True, step: bool = True, defer: bool = False):
         self._join()
+        self._flush_sums()
         a = opt.arena
         g = opt.param_groups[0]
         b1, b2 = g["betas"]

@@ -478,6 +478,28 @@ def axpby(alpha: float, x: torch.Tensor, beta: float, y: torch.Tensor) -> torch.
     return y
 
 
+def sum_parts_batch(jobs) -> None:
+    """jobs: list of (src [n_parts, rows, cols] contiguous tensor, dst [rows, cols] tensor view, alpha, accumulate).
+    One launch; every dst = (dst +) alpha * sum over parts in part order."""
+    lib = _lib.load()
+    if not jobs:
+        return
+    arr = (_lib.SumJob * len(jobs))()
+    dev = jobs[0][0].device
+    for k, (src, dst, alpha, accumulate) in enumerate(jobs):
+        _chk(src, "src"), _chk(dst, "dst")
+        if src.dim() != 3 or not src.is_contiguous() or dst.dim() != 2 or tuple(src.shape[1:]) != tuple(dst.shape):
+            raise ValueError("sum_parts_batch: src must be contiguous [parts, rows, cols] and dst [rows, cols]")
+        if dst.shape[1] > 1 and dst.stride(1) != 1:
+            raise ValueError("sum_parts_batch: dst rows must be contiguous")
+        P, R, Cn = src.shape
+        arr[k] = _lib.SumJob(_ptr(src), _ptr(dst), R * Cn, Cn, dst.stride(0) if R > 1 else Cn, P, R, Cn, float(alpha),
+                             _lib.GEMM_ACCUMULATE if accumulate else 0, 0)
+    jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    _lib.check(lib.mmvae_sum_parts_batch(len(jobs), _ptr(jobs_dev), _stream()), "mmvae_sum_parts_batch")
+    torch.cuda.current_stream().synchronize()  # jobs_dev must outlive the launch
+
+
 def scale_rows(x: torch.Tensor, row_scale: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
     _chk(x, "x"), _chk(row_scale, "row_scale")

@@ -357,3 +357,25 @@ def test_bad_arguments_are_rejected_on_host(ops):
     lib = _lib.load()
     assert lib.mmvae_gemm_f32(7, 8, 8, 8, 1.0, a.data_ptr(), 16, a.data_ptr(), 16, a.data_ptr(), 8, None, 0, 1, None, 0,
                               None) == _lib.ERR_ARG
+
+
+# ------------------------------------------------------------------------------------------ batched partial sums
+def test_sum_parts_batch(ops):
+    """One launch, several fixed-order reductions of different shapes (split-K slabs, column partials), with and
+    without accumulate / alpha, aligned and odd sizes."""
+    jobs, refs = [], []
+    for k, (P, R, Cn, alpha, acc) in enumerate([(4, 64, 128, 1.0, False), (3, 33, 47, 0.5, True), (16, 1, 20000, 1.0, False),
+                                                (1, 8, 12, 2.0, False), (7, 1, 5, 1.0, True)]):
+        src = dev(rnd(P, R, Cn, seed=20 + k))
+        base = dev(rnd(R, Cn + 3, seed=40 + k))
+        dst = base[:, :Cn] if k % 2 else dev(rnd(R, Cn, seed=60 + k))
+        before = dst.clone()
+        s = torch.zeros(R, Cn, device="cuda")
+        for p in range(P):  # same order, same fp32 arithmetic: bitwise
+            s = s + src[p]
+        ref = s * alpha + (before if acc else 0)
+        jobs.append((src, dst, alpha, acc))
+        refs.append((dst, ref, alpha == 1.0 and not acc))
+    ops.sum_parts_batch(jobs)
+    for dst, ref, exact in refs:  # alpha / accumulate may be contracted into one fma by the compiler
+        assert torch.equal(dst, ref) if exact else torch.allclose(dst, ref, rtol=1e-6, atol=1e-6)
