@@ -22,13 +22,29 @@ BUCKET_BYTES = 64 << 20  # xGMI ring all-reduce is per-link bound: few, large me
 def init_from_env(backend: Optional[str] = None) -> int:
     """Initialise the default process group from torchrun's env (RANK / WORLD_SIZE / MASTER_*).  Returns world size."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _single_rank_collectives()) and not dist.is_initialized():
+        if world == 1:
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group(backend=backend)
     return world
+
+
+def _single_rank_collectives() -> bool:
+    """Diagnostics (MMVAE_SINGLE_RANK_COLLECTIVES=1): with one rank, still create the process group, issue every
+    collective and run the step engine's overlapped data-parallel program -- rehearses the N > 1 code path (streams,
+    events, RCCL launches beside graph replays) on a one-GPU box."""
+    return os.environ.get("MMVAE_SINGLE_RANK_COLLECTIVES", "0") != "0"
+
+
+def collectives_active() -> bool:
+    return world_size() > 1 or (_single_rank_collectives() and dist.is_available() and dist.is_initialized())
 
 
 def world_size() -> int:
@@ -44,19 +60,39 @@ def bucket_ranges(numel: int, bucket_bytes: int = BUCKET_BYTES) -> List[range]:
     return [range(s, min(s + per, numel)) for s in range(0, numel, per)]
 
 
+def all_reduce_flat(flat: torch.Tensor, group=None, bucket_bytes: int = BUCKET_BYTES) -> None:
+    """Sum-all-reduce a flat tensor in place, in contiguous buckets, ordered after the CURRENT stream (the process
+    group's communication stream waits for the current stream and the current stream waits for the collective, both
+    as stream dependencies: the host never blocks)."""
+    if not collectives_active():
+        return
+    for r in bucket_ranges(flat.numel(), bucket_bytes):
+        dist.all_reduce(flat[r.start:r.stop], op=dist.ReduceOp.SUM, group=group)
+
+
 class GradAllReducer:
     """Sum-all-reduces a flat gradient arena in contiguous buckets, optionally on a side stream so that it overlaps
-    with whatever the compute stream still has to do (remaining backward GEMMs / the other optimiser's update)."""
+    with whatever the compute stream still has to do (remaining backward GEMMs / the other optimiser's update).
 
-    def __init__(self, group=None, bucket_bytes: int = BUCKET_BYTES, side_stream: bool = True):
+    Two communicators: `group` carries the bulk exchange (the active expert's ~170 MB gradient arena, which the step
+    engine overlaps with the NEXT step), `small_group` the latency-bound ones (shared-VAE and adversary arenas, a few
+    MB) so that they never queue behind a bulk transfer on the same communicator.  Every rank issues the collectives
+    of both in the same program order."""
+
+    def __init__(self, group=None, bucket_bytes: int = BUCKET_BYTES, side_stream: bool = True, small_group=None):
         self.group = group
+        self.small_group = small_group if small_group is not None else group
         self.bucket_bytes = bucket_bytes
         self.stream = torch.cuda.Stream() if (side_stream and torch.cuda.is_available()) else None
         self._pending: list = []
 
+    def reduce_here(self, flat_grad: torch.Tensor, small: bool = False) -> None:
+        """Bucketed all-reduce ordered after (and completing on) the current stream."""
+        all_reduce_flat(flat_grad, self.small_group if small else self.group, self.bucket_bytes)
+
     def launch(self, flat_grad: torch.Tensor) -> None:
         """Enqueue the all-reduce of `flat_grad` (in place).  Returns immediately; call wait() before reading it."""
-        if world_size() == 1:
+        if not collectives_active():
             return
         if self.stream is not None and flat_grad.is_cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
@@ -75,18 +111,21 @@ class GradAllReducer:
 
 
 def attach(model, reducer: Optional[GradAllReducer] = None) -> GradAllReducer:
-    """Make every HipAdam of `model` average its gradients over the default process group."""
-    reducer = reducer or GradAllReducer()
+    """Make every HipAdam of `model` average its gradients over the default process group.  Collective call: every
+    rank must call it (a second communicator for the small arenas is created here)."""
     w = world_size()
+    if reducer is None:
+        small = dist.new_group() if (collectives_active() and os.environ.get("MMVAE_DP_SMALL_GROUP", "1") != "0") else None
+        reducer = GradAllReducer(small_group=small)
     for opt in model.optimizers():
-        opt.reducer = reducer if w > 1 else None
+        opt.reducer = reducer if collectives_active() else None
         opt.grad_scale = 1.0 / w
     return reducer
 
 
 def broadcast_parameters(model, src: int = 0) -> None:
     """Replicate rank `src`'s parameters and buffers (all ranks start from identical state)."""
-    if world_size() == 1:
+    if not collectives_active():
         return
     for t in list(model.parameters()) + list(model.buffers()):
         dist.broadcast(t.data, src=src)

@@ -118,13 +118,20 @@ class StepEngine:
         self.side_stream = torch.cuda.Stream(device=self.device) if side_stream else None
         # only the small (latency-bound) weight-gradient GEMMs go aside; chip-filling ones stay in order on the main stream
         self.side_max_elems = int(os.environ.get("MMVAE_SIDE_MAX_ELEMS", 2 * 1024 * 1024))
-        # Deferred expert update: the active expert's parameters are not read again until that expert's next step, so
-        # its (HBM-bound) Adam update runs on a second stream, concurrently with the next step's (MFMA-bound) work for
-        # another modality.  The clip norm / coefficient are still computed in order on the main stream.
+        # Overlapped data parallelism (default whenever gradients are exchanged).  The active expert's parameters are
+        # not read again until that expert's NEXT step (modalities alternate), so its gradient all-reduce (~170 MB
+        # over xGMI at C2) and the clip + Adam update that needs the reduced gradients run on a communication stream,
+        # concurrently with the next step's compute for another modality; the next step of the SAME expert waits for
+        # the event recorded behind that update.  The shared-VAE gradients (a few MB, needed every step) are final
+        # before the expert-encoder backward starts: their all-reduce is issued there, on a second stream and a second
+        # communicator, and hides behind the remaining backward GEMMs.  MMVAE_DP_OVERLAP=0 restores the in-order
+        # exchange; =1 forces the overlapped program on one rank (measured slower at N = 1: Adam is HBM-bound).
         if defer_expert_adam is None:
-            defer_expert_adam = os.environ.get("MMVAE_DEFER_EXPERT_ADAM", "0") != "0"  # measured slower on C2
-        self.defer_expert_adam = bool(defer_expert_adam) and len(model.module.experts) > 1
-        self.update_stream = torch.cuda.Stream(device=self.device) if self.defer_expert_adam else None
+            ov = os.environ.get("MMVAE_DP_OVERLAP", os.environ.get("MMVAE_DEFER_EXPERT_ADAM", ""))
+            defer_expert_adam = (ov != "0") if ov != "" else mdist.collectives_active()
+        self.overlap = bool(defer_expert_adam)
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.overlap else None
+        self.small_stream = torch.cuda.Stream(device=self.device) if self.overlap else None
         self._pending: Dict[str, torch.cuda.Event] = {}
 
     # ------------------------------------------------------------------------------------------------ buffers
@@ -143,8 +150,9 @@ class StepEngine:
 
     def flush(self) -> None:
         """Make the current stream wait for every deferred expert update (before parameters are read elsewhere)."""
-        if self.update_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.update_stream)
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            torch.cuda.current_stream().wait_stream(self.small_stream)
             self._pending.clear()
 
     # --------------------------------------------------------------------------------------------------- step
@@ -196,15 +204,8 @@ class StepEngine:
         ev = self._pending.pop(expert_id, None)
         if ev is not None:  # this expert's previous (deferred) update must land before its parameters are read
             torch.cuda.current_stream().wait_event(ev)
-        plan.run()
-        if plan.deferred:
-            main = torch.cuda.current_stream()
-            self.update_stream.wait_stream(main)
-            with torch.cuda.stream(self.update_stream):
-                for call in plan.deferred:
-                    call()
-                ev = torch.cuda.Event()
-                ev.record(self.update_stream)
+        ev = plan.run()
+        if ev is not None:
             self._pending[expert_id] = ev
         model.kl_annealing_fn.step()
         plan.log(model, expert_id)
@@ -254,7 +255,7 @@ class _Plan:
         self._slab_floats = 0
         self._graphs: Optional[list] = None
         self._runs = 0
-        self.deferred: List = []  # launches enqueued on the engine's update stream after the captured program
+        self.exp_norm_log = None  # overlapped mode: the expert's pre-clip gradient norm, copied on the comm stream
         self.metrics = eng.buf("metrics", (256,))
         self.rng_state = rng.state(eng.device)
         self._build()
@@ -475,7 +476,11 @@ class _Plan:
 
         self._cur.append(call)
 
-    def optimizer(self, opt: HipAdam, max_norm: float, advance: bool = True, step: bool = True, defer: bool = False):
+    def optimizer(self, opt: HipAdam, max_norm: float, advance: bool = True, step: bool = True, exchange: str = "inline"):
+        """Fused clip + Adam over one optimiser's arenas.  `exchange` places the gradient all-reduce under data
+        parallelism: "inline" (here, on the main stream), "wait" (it was begun earlier with _begin_exchange; the main
+        stream joins it here) or "deferred" (it and everything after it run on the communication stream, overlapped
+        with the next step)."""
         self._join()
         self._flush_sums()
         a = opt.arena
@@ -483,20 +488,19 @@ class _Plan:
         b1, b2 = g["betas"]
         gs = 1.0 / self.eng.world
         npart = self.lib.mmvae_sqnorm_partials(a.numel)
-        if self.eng.world > 1:
-            self._cut(("allreduce", opt))
+        if opt.reducer is not None or self.eng.overlap:
+            self._cut(("ar_" + exchange, opt))
         self._emit(self.lib.mmvae_grad_sqnorm, a.numel, _p(a.grad), _p(opt.partials))
         flags = _lib.PREPARE_NORM | (_lib.PREPARE_ADVANCE if (advance and step) else 0)
         self._emit(self.lib.mmvae_adam_prepare, npart, _p(opt.partials), max_norm, gs, b1, b2, _p(opt.state_dev), flags)
         if step:
-            if defer:
-                # the update reads state_dev (clip, bias corrections) written above; it must not see the NEXT step's
-                # prepare of the same optimiser -> training_step waits for the pending event before re-running it
-                cur, self._cur = self._cur, self.deferred
             self._emit(self.lib.mmvae_adam_step, a.numel, _p(a.data), _p(a.grad), _p(a.exp_avg), _p(a.exp_avg_sq),
                        _p(opt.state_dev), g["lr"], b1, b2, g["eps"], g["weight_decay"], gs)
-            if defer:
-                self._cur = cur
+
+    def _begin_exchange(self, opt: HipAdam):
+        """All gradients of `opt` are final here: start their all-reduce on the small-message stream."""
+        self._flush_sums()
+        self._cut(("ar_begin", opt))
 
     def copy_scalar(self, src_ptr: int, dst_name: str):
         self._emit(self.lib.mmvae_axpby, 1, 1.0, src_ptr, 0.0, self.mptr(dst_name))
@@ -590,15 +594,22 @@ class _Plan:
         self.gemm(NN, B, HV, Z, self.da, Z, self.var_enc.weight, HV, self.dq, HV, flags=ACC)
         # ---- backward, encoder side
         din, S = self.dq, 1
+        early = eng.overlap
+        if early and len(self.enc_layers) == self.n_expert_enc:  # no VAE-encoder layers: VAE gradients are final
+            self._begin_exchange(self.opt_vae)
         for j in range(len(self.enc_layers) - 1, -1, -1):
             l = self.enc_layers[j]
             hid = l.a if l.a is not None else l.d
             addend = self.adv_grad_into.get(id(hid)) if l.return_hidden else None
             S_next = self.bwd_layer(l, din, S, addend=addend, need_dx="raw" if j > 0 else "none")
             din, S = None, S_next
+            if early and j == self.n_expert_enc:  # the last VAE layer is done: what remains is the expert's encoder
+                self._begin_exchange(self.opt_vae)
         # ---- clip + Adam (reference order: clip vae, clip expert, step vae, step expert)
-        self.optimizer(self.opt_vae, self.clip_vae)
-        self.optimizer(self.opt_exp, self.clip_exp, defer=eng.defer_expert_adam)
+        self.optimizer(self.opt_vae, self.clip_vae, exchange="wait" if early else "inline")
+        self.optimizer(self.opt_exp, self.clip_exp, exchange="deferred" if early else "inline")
+        if early:
+            self.exp_norm_log = torch.zeros(1, dtype=torch.float32, device=eng.device)
         self.segments.append(self._cur)
         self._cur = []
         # noise: Philox fills (production) or explicit buffers (parity mode), at the head of the program
@@ -711,25 +722,62 @@ class _Plan:
         for c in self.conditions:
             self.labels_dev[c].copy_(cache[c], non_blocking=True)
 
-    def _run_segments_eager(self):
-        for seg in self.segments:
-            if isinstance(seg, tuple):
-                self._collective(seg)
-            else:
-                for call in seg:
-                    call()
-
-    def _collective(self, marker):
+    def _exchange(self, marker, tail):
+        """One data-parallel exchange point between two captured segments.  Returns the stream the rest of the
+        program runs on (None = stay on the main stream)."""
         kind, opt = marker
-        if opt.reducer is not None:
-            opt.reducer.launch(opt.arena.grad)
-            opt.reducer.wait()
+        red = opt.reducer
+        eng = self.eng
+        main = torch.cuda.current_stream()
+        if kind == "ar_inline":
+            if red is not None:
+                red.reduce_here(opt.arena.grad, small=True)
+        elif kind == "ar_begin":
+            eng.small_stream.wait_stream(main)
+            if red is not None:
+                with torch.cuda.stream(eng.small_stream):
+                    red.reduce_here(opt.arena.grad, small=True)
+        elif kind == "ar_wait":
+            main.wait_stream(eng.small_stream)
+        elif kind == "ar_deferred":
+            eng.comm_stream.wait_stream(main)
+            if red is not None:
+                with torch.cuda.stream(eng.comm_stream):
+                    red.reduce_here(opt.arena.grad)
+            return eng.comm_stream
+        else:
+            raise _lib.HipLibraryError(f"engine: unknown exchange marker {kind}")
+        return tail
+
+    def _run_program(self, items, launch):
+        tail = None  # once set, the rest of the program (the deferred update) runs on the communication stream
+        for it in items:
+            if isinstance(it, tuple):
+                tail = self._exchange(it, tail)
+            elif tail is None:
+                launch(it)
+            else:
+                with torch.cuda.stream(tail):
+                    launch(it)
+        if tail is None:
+            return None
+        with torch.cuda.stream(tail):
+            self.exp_norm_log.copy_(self.opt_exp.state_dev[1:2])
+            ev = torch.cuda.Event()
+            ev.record(tail)
+        return ev
+
+    @staticmethod
+    def _launch_eager(seg):
+        for call in seg:
+            call()
 
     def run(self):
+        """One step.  Returns the event behind the deferred expert update (overlapped data parallelism) or None."""
         self._runs += 1
-        if self._runs == 1:
-            self._run_segments_eager()  # a real step; also loads every code object before capture
-            return
+        if self._runs == 1 or os.environ.get("MMVAE_NO_GRAPH", "0") != "0":
+            # a real step; the first run also loads every code object before capture
+            return self._run_program(self.segments, self._launch_eager)
         if self._graphs is None:
             torch.cuda.synchronize()
             graphs = []
@@ -738,16 +786,13 @@ class _Plan:
                     graphs.append(seg)
                     continue
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread-local capture mode: a process group's watchdog thread may touch its events meanwhile
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     for call in seg:
                         call()
                 graphs.append(g)
             self._graphs = graphs
-        for g in self._graphs:
-            if isinstance(g, tuple):
-                self._collective(g)
-            else:
-                g.replay()
+        return self._run_program(self._graphs, lambda g: g.replay())
 
     def log(self, model, eid: str):
         m = self.metrics.clone()  # one small D2D copy; logged scalars are views of it (no host sync)
@@ -761,5 +806,8 @@ class _Plan:
                     model.auto_log({c: m[self.slot(f"{phase}_{i}/{c}")]}, tags=tags, key_pos="last")
                 model.log(f"grad_norms/{phase}_{i}", m[self.slot(f"grad_norms/{phase}_{i}")])
         model.log("grad_norms/vae", self.opt_vae.state_dev[1].clone())
-        model.log(f"grad_norms/expert_{eid}", self.opt_exp.state_dev[1].clone())
+        # overlapped mode: the norm is produced on the communication stream; the logged tensor is filled when that
+        # stream gets there (read it after engine.flush() / a device synchronisation)
+        model.log(f"grad_norms/expert_{eid}", self.exp_norm_log[0] if self.exp_norm_log is not None
+                  else self.opt_exp.state_dev[1].clone())
         model.auto_log(main, tags=[stage, eid])

@@ -49,7 +49,7 @@ def load_state(model, z, prefix):
     return missing
 
 
-def replay_training(name, device, use_engine=False, check=True):
+def replay_training(name, device, use_engine=False, check=True, prepare=None):
     """Runs the golden schedule through CMMVAEModel.training_step; returns list of per-step result dicts."""
     from mmvae_amd import backend
 
@@ -60,6 +60,8 @@ def replay_training(name, device, use_engine=False, check=True):
         load_state(model, z, "sd0/")
         model.train()
         model.trainer.set_stage("training")
+        if prepare is not None:
+            prepare(model)
         for t, eid in enumerate(case["schedule"]):
             x, eps, masks, labels = H.step_inputs(z, t)
             model.kl_annealing_fn.kl_weight = case["kl_weights"][t]

@@ -73,6 +73,15 @@ def _worker(rank, world, port, out_dir):
         assert all(torch.equal(gathered[0], g) for g in gathered), "ranks diverged"
         if rank == 0:
             torch.save(flat, os.path.join(out_dir, "dp.pt"))
+        # the engine's exchange primitives: default attach() builds a second communicator for the small arenas;
+        # both reduce a flat arena in place, in buckets
+        red2 = mdist.attach(model)
+        assert red2.small_group is not red2.group
+        for small in (False, True):
+            t = torch.full((5000,), float(rank + 1))
+            red2.bucket_bytes = 4096
+            red2.reduce_here(t, small=small)
+            assert torch.equal(t, torch.full((5000,), float(sum(range(1, world + 1)))))
     dist.destroy_process_group()
 
 
