@@ -282,6 +282,30 @@ typedef struct {
 } mmvae_sum_job;
 int mmvae_sum_parts_batch(int n_jobs, const mmvae_sum_job* jobs, mmvae_stream_t stream);
 
+/* Grouped launch of independent small GEMMs (same math and layouts as mmvae_gemm_f32, exact-f32 MFMA, 64x64 tiles,
+ * unsplit, alpha / bias / relu / accumulate epilogue): ONE grid covers the tiles of every job.  Used for the
+ * weight-gradient GEMMs of the core (<= 1024-wide) layers of a backward pass -- replaces the per-parameter
+ * `addmm` backward dispatches of autograd (components.py:276) -- which are independent of each other and only feed
+ * the optimiser.  Requirements per job (mmvae_gemm_batch_job_ok): 16-byte aligned A, B, C, bias; lda, ldb, ldc,
+ * M, N, K multiples of 4.  mmvae_gemm_batch_prepare is a pure host function: it validates a HOST array of jobs and
+ * fills first_block / n_blocks; the caller copies the array to the device once and passes that DEVICE array, the job
+ * count and total_blocks to every mmvae_gemm_batch_f32 launch. */
+typedef struct {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    int64_t lda, ldb, ldc;
+    int32_t layout, M, N, K;
+    float alpha;
+    uint32_t flags;      /* MMVAE_GEMM_RELU | MMVAE_GEMM_ACCUMULATE */
+    int32_t first_block; /* filled by mmvae_gemm_batch_prepare */
+    int32_t n_blocks;    /* filled by mmvae_gemm_batch_prepare */
+} mmvae_gemm_job;
+int mmvae_gemm_batch_job_ok(const mmvae_gemm_job* job);
+int mmvae_gemm_batch_prepare(int n_jobs, mmvae_gemm_job* jobs, int* total_blocks);
+int mmvae_gemm_batch_f32(int n_jobs, const mmvae_gemm_job* jobs_dev, int total_blocks, mmvae_stream_t stream);
+
 /* Small utilities used by the step engine: y = alpha*x (+ y), fill. */
 int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, float* y, mmvae_stream_t stream);
 int mmvae_scale_rows(int B, int N, const float* x, int64_t ldx, const float* row_scale, float* y, int64_t ldy,

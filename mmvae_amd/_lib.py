@@ -84,6 +84,9 @@ PROTOTYPES = {
     "mmvae_axpby": (_i, [_l, _f, _p, _f, _p, _p]),
     "mmvae_scale_rows": (_i, [_i, _i, _p, _l, _p, _p, _l, _p]),
     "mmvae_sum_parts_batch": (_i, [_i, _p, _p]),
+    "mmvae_gemm_batch_job_ok": (_i, [_p]),
+    "mmvae_gemm_batch_prepare": (_i, [_i, _p, C.POINTER(_i)]),
+    "mmvae_gemm_batch_f32": (_i, [_i, _p, _i, _p]),
 }
 
 
@@ -92,6 +95,14 @@ class SumJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("part_stride", C.c_int64), ("ld_src", C.c_int64),
                 ("ld_dst", C.c_int64), ("n_parts", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("alpha", C.c_float), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class GemmJob(C.Structure):
+    """mmvae_gemm_job (include/mmvae_hip.h): one GEMM of a grouped mmvae_gemm_batch_f32 launch."""
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("lda", C.c_int64),
+                ("ldb", C.c_int64), ("ldc", C.c_int64), ("layout", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
+                ("K", C.c_int32), ("alpha", C.c_float), ("flags", C.c_uint32), ("first_block", C.c_int32),
+                ("n_blocks", C.c_int32)]
 
 
 class HipLibraryError(RuntimeError):

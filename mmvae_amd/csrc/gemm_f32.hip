@@ -359,8 +359,21 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
 }
 
 // Block tile BM x BN, k-tile BK, 4 waves arranged WGM x WGN; each wave owns (BM/WGM) x (BN/WGN) as 32x32 MFMA blocks.
+// XCD-aware (bijective) remap of the workgroup id: each XCD (private L2) gets a contiguous run of work items.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int AFORM, int BFORM, int BM, int BN, int BK>
+struct F32Lds {
+    static constexpr int A_FLOATS = Tile<AFORM, BM, BK>::LDS_FLOATS, B_FLOATS = Tile<BFORM, BN, BK>::LDS_FLOATS;
+    static constexpr int FLOATS = 2 * A_FLOATS + 2 * B_FLOATS;
+};
+
+// One work item (output tile x split-K slice, linear index L: z slowest, M fastest) of the exact-f32 MFMA GEMM.
 template <int AFORM, int BFORM, int BM, int BN, int BK, int WGM, int WGN, bool VEC, int EPI>
-__global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gemm_f32_item(const GemmArgs& g, int L, float* lds) {
     static_assert(WGM * WGN == 4, "4 wavefronts per workgroup");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;  // wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;    // 32x32 MFMA blocks per wave
@@ -369,7 +382,6 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     using TB = Tile<BFORM, BN, BK>;
     constexpr int A_FLOATS = TA::LDS_FLOATS, B_FLOATS = TB::LDS_FLOATS;
     constexpr int KK = BK / 8;
-    __shared__ __attribute__((aligned(16))) float lds[2 * A_FLOATS + 2 * B_FLOATS];
     float* As = lds;
     float* Bs = lds + 2 * A_FLOATS;
 
@@ -379,10 +391,6 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, half = lane >> 5;
 
-    // XCD-aware (bijective) remap of the workgroup id, then z (split-K slice) slowest, M fastest.
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int tiles = g.mt * g.nt;
     const int z = L / tiles;
     const int t = L - z * tiles;
@@ -467,6 +475,55 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     }
 
     gemm_epilogue<BM, BN, WGM, WGN, EPI>(acc, g, bm, bn, z, lds);
+}
+
+// Block tile BM x BN, k-tile BK, 4 waves arranged WGM x WGN; each wave owns (BM/WGM) x (BN/WGN) as 32x32 MFMA blocks.
+template <int AFORM, int BFORM, int BM, int BN, int BK, int WGM, int WGN, bool VEC, int EPI>
+__global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[F32Lds<AFORM, BFORM, BM, BN, BK>::FLOATS];
+    // z (split-K slice) slowest, M fastest
+    gemm_f32_item<AFORM, BFORM, BM, BN, BK, WGM, WGN, VEC, EPI>(g, xcd_remap(blockIdx.x, gridDim.x), lds);
+}
+
+// Grouped launch of independent small GEMMs (64x64 tiles, exact-f32 MFMA, unsplit): one grid covers the tiles of
+// every job, so a backward pass's weight-gradient GEMMs of the core layers cost one launch (a dependent launch is
+// ~4-5 us on the step's critical path) and fill the chip together instead of 8-128 workgroups at a time.
+__global__ __launch_bounds__(NT) void gemm_f32_batch_kernel(const mmvae_gemm_job* __restrict__ jobs, int n_jobs) {
+    constexpr int LDS_FLOATS = F32Lds<FORM_KC, FORM_KC, 64, 64, 32>::FLOATS;  // the largest of the three layouts
+    static_assert(LDS_FLOATS >= F32Lds<FORM_KC, FORM_RC, 64, 64, 32>::FLOATS &&
+                      LDS_FLOATS >= F32Lds<FORM_RC, FORM_RC, 64, 64, 32>::FLOATS, "LDS size");
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    int j = 0;
+    while (j + 1 < n_jobs && L >= jobs[j + 1].first_block) ++j;  // wave-uniform
+    const mmvae_gemm_job& job = jobs[j];
+    GemmArgs g = {};
+    g.A = job.A;
+    g.B = job.B;
+    g.C = job.C;
+    g.bias = job.bias;
+    g.lda = job.lda;
+    g.ldb = job.ldb;
+    g.ldc = job.ldc;
+    g.M = job.M;
+    g.N = job.N;
+    g.K = job.K;
+    g.mt = (job.M + 63) / 64;
+    g.nt = (job.N + 63) / 64;
+    g.ktiles = (job.K + 31) / 32;
+    g.ktiles_per_split = g.ktiles;
+    g.alpha = job.alpha;
+    g.flags = job.flags;
+    g.aligned = 2;
+    g.c_vec = 1;
+    g.x_rows = 1;
+    const int l = L - job.first_block;
+    if (job.layout == MMVAE_GEMM_NT)
+        gemm_f32_item<FORM_KC, FORM_KC, 64, 64, 32, 2, 2, true, EPI_STD>(g, l, lds);
+    else if (job.layout == MMVAE_GEMM_NN)
+        gemm_f32_item<FORM_KC, FORM_RC, 64, 64, 32, 2, 2, true, EPI_STD>(g, l, lds);
+    else
+        gemm_f32_item<FORM_RC, FORM_RC, 64, 64, 32, 2, 2, true, EPI_STD>(g, l, lds);
 }
 
 // ====================================================================================================================
@@ -1289,6 +1346,43 @@ extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, cons
                            N, alpha, bias, flags, C, ldc);
         MMVAE_LAUNCH_CHECK();
     }
+    return MMVAE_OK;
+}
+
+// ---- grouped small GEMMs
+static bool batch_job_ok(const mmvae_gemm_job& j) {
+    if (j.layout < 0 || j.layout > 2 || j.M <= 0 || j.N <= 0 || j.K <= 0 || !j.A || !j.B || !j.C) return false;
+    if ((j.M | j.N | j.K) & 3) return false;
+    if (!aligned16(j.A) || !aligned16(j.B) || !aligned16(j.C) || (j.bias && !aligned16(j.bias))) return false;
+    if ((j.lda | j.ldb | j.ldc) & 3) return false;
+    const int64_t a_inner = (j.layout == MMVAE_GEMM_TN) ? j.M : j.K;
+    const int64_t b_inner = (j.layout == MMVAE_GEMM_NT) ? j.K : j.N;
+    if (j.lda < a_inner || j.ldb < b_inner || j.ldc < j.N) return false;
+    if (j.flags & ~(MMVAE_GEMM_RELU | MMVAE_GEMM_ACCUMULATE)) return false;
+    return true;
+}
+
+extern "C" int mmvae_gemm_batch_job_ok(const mmvae_gemm_job* job) { return job && batch_job_ok(*job) ? 1 : 0; }
+
+extern "C" int mmvae_gemm_batch_prepare(int n_jobs, mmvae_gemm_job* jobs, int* total_blocks) {
+    if (n_jobs <= 0 || n_jobs > 4096 || !jobs || !total_blocks) return MMVAE_ERR_ARG;
+    int64_t first = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        if (!batch_job_ok(jobs[i])) return MMVAE_ERR_ARG;
+        jobs[i].first_block = (int32_t)first;
+        jobs[i].n_blocks = ceil_div_i(jobs[i].M, 64) * ceil_div_i(jobs[i].N, 64);
+        first += jobs[i].n_blocks;
+        if (first > (1 << 30)) return MMVAE_ERR_ARG;
+    }
+    *total_blocks = (int)first;
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_gemm_batch_f32(int n_jobs, const mmvae_gemm_job* jobs_dev, int total_blocks,
+                                    mmvae_stream_t stream) {
+    if (n_jobs <= 0 || !jobs_dev || total_blocks <= 0) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(gemm_f32_batch_kernel, dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, jobs_dev, n_jobs);
+    MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }
 

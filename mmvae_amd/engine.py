@@ -113,6 +113,7 @@ class StepEngine:
         self.world = mdist.world_size()
         # weight-gradient GEMMs run on a side stream inside the captured graph (fork/join edges)
         self.batch_finish = os.environ.get("MMVAE_BATCH_FINISH", "1") != "0"
+        self.batch_gemms = os.environ.get("MMVAE_BATCH_GEMMS", "1") != "0"
         if os.environ.get("MMVAE_SIDE_STREAM", "0") != "0":
             side_stream = True
         self.side_stream = torch.cuda.Stream(device=self.device) if side_stream else None
@@ -248,6 +249,7 @@ class _Plan:
         self.metric_slots: Dict[str, int] = {}
         self.segments: List = []  # list of closure lists, separated by ("allreduce", opt) markers
         self._cur: List = []
+        self._gemm_jobs: List = []     # small weight-gradient GEMMs queued for the next mmvae_gemm_batch_f32 launch
         self._sum_jobs: List = []      # reductions queued for the next mmvae_sum_parts_batch launch
         self._sum_keep: List = []
         self._job_tables: List = []    # device job tables of the launches already emitted
@@ -290,9 +292,37 @@ class _Plan:
         self.lib.mmvae_gemm_plan(layout, M, N, K, C.byref(tile), C.byref(sk))
         return sk.value
 
+    def _queue_gemm(self, layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags) -> bool:
+        """Weight-gradient GEMMs of the core layers (the planner's 64x64-tile class) are independent of each other and
+        only feed the optimiser: queue them for ONE grouped launch (_flush_gemms) instead of a launch each."""
+        tile, sk = C.c_int(0), C.c_int(0)
+        self.lib.mmvae_gemm_plan(layout, M, N, K, C.byref(tile), C.byref(sk))
+        if tile.value != 2:
+            return False
+        job = _lib.GemmJob(_p(A), _p(Bm), _p(Cm), _p(bias), lda, ldb, ldc, layout, M, N, K, float(alpha), int(flags), 0, 0)
+        if not self.lib.mmvae_gemm_batch_job_ok(C.addressof(job)):
+            return False
+        self._gemm_jobs.append(job)
+        self._sum_keep.append((A, Bm, Cm, bias))
+        return True
+
+    def _flush_gemms(self):
+        if not self._gemm_jobs:
+            return
+        n = len(self._gemm_jobs)
+        arr = (_lib.GemmJob * n)(*self._gemm_jobs)
+        total = C.c_int(0)
+        _lib.check(self.lib.mmvae_gemm_batch_prepare(n, C.addressof(arr), C.byref(total)), "mmvae_gemm_batch_prepare")
+        jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.eng.device)
+        self._job_tables.append(jobs_dev)
+        self._emit(self.lib.mmvae_gemm_batch_f32, n, jobs_dev.data_ptr(), total.value)
+        self._gemm_jobs = []
+
     def gemm(self, layout, M, N, K, A, lda, Bm, ldb, Cm, ldc, bias=None, flags=0, alpha=1.0, side=False):
         """Complete GEMM (internal split-K reduce through a workspace when the plan asks for it).  side=True runs it
         on the engine's side stream (weight gradients: off the backward critical path) with its own workspace."""
+        if side and self.eng.batch_gemms and self._queue_gemm(layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags):
+            return
         sk = self._plan_gemm(layout, M, N, K)
         if side and sk > 1 and self.eng.batch_finish and not (flags & ~ACC) and bias is None:
             # weight gradient with a split: raw slabs into a buffer of its own, summed later together with every other
@@ -346,6 +376,7 @@ class _Plan:
 
     def _flush_sums(self):
         """One launch for every reduction queued since the last flush (before anything reads those gradients)."""
+        self._flush_gemms()
         if not self._sum_jobs:
             return
         arr = (_lib.SumJob * len(self._sum_jobs))(*self._sum_jobs)

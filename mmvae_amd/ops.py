@@ -500,6 +500,40 @@ def sum_parts_batch(jobs) -> None:
     torch.cuda.current_stream().synchronize()  # jobs_dev must outlive the launch
 
 
+def gemm_batch(jobs) -> None:
+    """Grouped launch of small GEMMs.  jobs: list of dicts {layout, a, b, out, bias=None, alpha=1.0, relu=False,
+    accumulate=False} with the operand conventions of gemm().  One launch (mmvae_gemm_batch_f32); raises when a job
+    does not meet the alignment requirements of the grouped kernel."""
+    lib = _lib.load()
+    if not jobs:
+        return
+    arr = (_lib.GemmJob * len(jobs))()
+    for k, j in enumerate(jobs):
+        a, b, out, bias, layout = j["a"], j["b"], j["out"], j.get("bias"), j["layout"]
+        _chk(a, "a"), _chk(b, "b"), _chk(out, "out"), _chk(bias, "bias")
+        ar, ac, lda = _mat(a, "a")
+        br, bc, ldb = _mat(b, "b")
+        M, N, ldc = _mat(out, "out")
+        if layout == GEMM_NT:
+            K, ok = ac, (ar, bc, br) == (M, ac, N)
+        elif layout == GEMM_NN:
+            K, ok = ac, (ar, br, bc) == (M, ac, N)
+        elif layout == GEMM_TN:
+            K, ok = ar, (ac, br, bc) == (M, ar, N)
+        else:
+            raise ValueError("layout")
+        if not ok or (bias is not None and (bias.numel() != N or not bias.is_contiguous())):
+            raise ValueError(f"gemm_batch job {k}: shapes a {tuple(a.shape)} b {tuple(b.shape)} out {tuple(out.shape)}")
+        flags = (GEMM_RELU if j.get("relu") else 0) | (GEMM_ACCUMULATE if j.get("accumulate") else 0)
+        arr[k] = _lib.GemmJob(_ptr(a), _ptr(b), _ptr(out), _ptr(bias), lda, ldb, ldc, layout, M, N, K,
+                              float(j.get("alpha", 1.0)), flags, 0, 0)
+    total = C.c_int(0)
+    _lib.check(lib.mmvae_gemm_batch_prepare(len(jobs), C.addressof(arr), C.byref(total)), "mmvae_gemm_batch_prepare")
+    jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(jobs[0]["a"].device)
+    _lib.check(lib.mmvae_gemm_batch_f32(len(jobs), _ptr(jobs_dev), total.value, _stream()), "mmvae_gemm_batch_f32")
+    torch.cuda.current_stream().synchronize()  # jobs_dev must outlive the launch
+
+
 def scale_rows(x: torch.Tensor, row_scale: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
     _chk(x, "x"), _chk(row_scale, "row_scale")
