@@ -306,6 +306,16 @@ int mmvae_gemm_batch_job_ok(const mmvae_gemm_job* job);
 int mmvae_gemm_batch_prepare(int n_jobs, mmvae_gemm_job* jobs, int* total_blocks);
 int mmvae_gemm_batch_f32(int n_jobs, const mmvae_gemm_job* jobs_dev, int total_blocks, mmvae_stream_t stream);
 
+/* CSR batch -> dense rows.  replaces: `x.to_dense()` on the `torch.sparse_csr` batches the datapipes
+ * yield when `return_dense: false` (vae.py:140-141, cmmvae_model.py:166-167, data/local/cellxgene_datapipe.py:178-183).
+ * nnz = stored elements (col_indices / values may be NULL when it is 0; row pointers are clamped to it).
+ * crow_indices [B+1] and col_indices [nnz] are int64 (torch's CSR index dtype), values [nnz] fp32, out [B, ldo] fp32.
+ * Column indices must be unique within a row (torch CSR invariant); indices outside [0, G) are dropped.
+ * At ~10 % density the dense MFMA GEMM of the first layer beats a gather SpMM on this chip, so the CSR
+ * path densifies straight into the step's input buffer: one pass, 4*B*G bytes written, 16*nnz bytes read. */
+int mmvae_csr_to_dense_f32(int B, int G, int64_t nnz, const int64_t* crow_indices, const int64_t* col_indices,
+                           const float* values, float* out, int64_t ldo, mmvae_stream_t stream);
+
 /* Small utilities used by the step engine: y = alpha*x (+ y), fill. */
 int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, float* y, mmvae_stream_t stream);
 int mmvae_scale_rows(int B, int N, const float* x, int64_t ldx, const float* row_scale, float* y, int64_t ldy,

@@ -42,3 +42,15 @@ def on_hip(t: torch.Tensor) -> bool:
         "Move the model and batch to the GPU, or (host-logic tests / config C1 only) wrap the call in "
         "mmvae_amd.backend.cpu_plumbing()."
     )
+
+
+def to_dense(x: torch.Tensor) -> torch.Tensor:
+    """Dense rows of a `torch.sparse_csr` batch: the HIP pass (ops.csr_to_dense) on the device; torch's own on CPU
+    plumbing.  Dense tensors pass through."""
+    if x.layout != torch.sparse_csr:
+        return x
+    if on_hip(x.values()):
+        from . import ops
+
+        return ops.csr_to_dense(x)
+    return x.to_dense()

@@ -156,13 +156,87 @@ class StepEngine:
             torch.cuda.current_stream().wait_stream(self.small_stream)
             self._pending.clear()
 
+    # ------------------------------------------------------------------------------------------------- inputs
+    def _select_input(self, x: torch.Tensor, base_key: tuple):
+        """Plan selection: graphs are keyed by the input pointer once a pointer has been seen twice (resident
+        batches); otherwise the batch is copied into a static buffer.  Returns (plan key, the tensor the plan reads)."""
+        B = x.shape[0]
+        if x.layout == torch.sparse_csr:  # CSR batch: densified by one HIP pass straight into the static input buffer
+            from . import ops
+
+            x_in = self.buf(f"x_static.{base_key[1]}", (B, x.shape[1]))
+            ops.csr_to_dense(x, out=x_in)
+            return base_key + (0, 0), x_in
+        pkey = base_key + (x.data_ptr(), x.stride(0))
+        seen = self._ptr_seen.get(pkey, 0)
+        self._ptr_seen[pkey] = seen + 1
+        n_ptr_plans = sum(1 for k in self._plans if k[-2] != 0)
+        if pkey in self._plans or (seen >= 1 and n_ptr_plans < MAX_POINTER_PLANS):
+            return pkey, x
+        x_in = self.buf(f"x_static.{base_key[1]}", (B, x.shape[1]))
+        if x.is_contiguous():  # own 16-byte copy kernel: the runtime's blit kernel reaches < 1 TB/s here
+            from . import ops
+
+            ops.axpby(1.0, x, 0.0, x_in)
+        else:
+            x_in.copy_(x)
+        if len(self._ptr_seen) > 4096:
+            self._ptr_seen.clear()
+        return base_key + (0, 0), x_in
+
+    @staticmethod
+    def _dense_f32(x: torch.Tensor) -> torch.Tensor:
+        if x.layout == torch.sparse_csr:
+            return x  # densified in _select_input
+        if x.dtype != torch.float32 or x.dim() != 2 or (x.shape[1] > 1 and x.stride(1) != 1):
+            x = x.float().contiguous()
+        return x
+
+    def _set_kl_weight(self):
+        """Per-step host values -> device scalars (the captured graphs read the device word)."""
+        klw = float(self.model.kl_annealing_fn.kl_weight)
+        if klw != self._klw_host:
+            self.klw_dev.fill_(klw)
+            self._klw_host = klw
+
+    # ------------------------------------------------------------------------------------- eval / predict (f3)
+    def _forward_only(self, mode: str, x: torch.Tensor, expert_id: str):
+        """Forward-only plan (no autograd, no gradients, no optimiser): eval-mode BatchNorm (running statistics), no
+        dropout, one rsample.  mode "validate": + fused reconstruction / ELBO; mode "embed": stops at z."""
+        x = self._dense_f32(x)
+        ev = self._pending.pop(expert_id, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+        enc_mod = self.model.module.vae.encoder
+        explicit = enc_mod.explicit_eps is not None
+        B = x.shape[0]
+        key, x_in = self._select_input(x, (mode, expert_id, B, 1, explicit))
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = _Plan(self, expert_id, B, 1, explicit, x_in, mode=mode)
+            self._plans[key] = plan
+        self._set_kl_weight()
+        if explicit:
+            plan.eps.copy_(enc_mod.explicit_eps.reshape(plan.eps.shape))
+        plan.run()
+        return plan
+
+    def validation_step(self, x: torch.Tensor, metadata, expert_id: str) -> dict:
+        """`CMMVAEModel.validation_step` (models/cmmvae_model.py:219-248) as one captured forward program.  Returns the
+        loss dict of `BaseVAE.elbo` (device scalars)."""
+        plan = self._forward_only("validate", x, expert_id)
+        m = plan.metrics.clone()
+        return {RK.LOSS: m[0], RK.RECON_LOSS: m[1], RK.KL_LOSS: m[2], RK.KL_WEIGHT: m[3]}
+
+    def latent_embeddings(self, x: torch.Tensor, metadata, expert_id: str) -> torch.Tensor:
+        """z of `CMMVAE.get_latent_embeddings` (modules/cmmvae.py:115-142) as one captured forward program."""
+        plan = self._forward_only("embed", x, expert_id)
+        return plan.z[0].clone()
+
     # --------------------------------------------------------------------------------------------------- step
     def training_step(self, x: torch.Tensor, metadata, expert_id: str) -> None:
         model = self.model
-        if x.layout == torch.sparse_csr:
-            x = x.to_dense()
-        if x.dtype != torch.float32 or x.dim() != 2 or (x.shape[1] > 1 and x.stride(1) != 1):
-            x = x.float().contiguous()
+        x = self._dense_f32(x)
         enc_mod = model.module.vae.encoder
         expert = model.module.experts[expert_id]
         explicit = enc_mod.explicit_eps is not None or expert.encoder.explicit_masks is not None
@@ -170,34 +244,12 @@ class StepEngine:
         if enc_mod.explicit_eps is not None and enc_mod.explicit_eps.dim() == 3:
             K = enc_mod.explicit_eps.shape[0]
         B = x.shape[0]
-        # plan selection: graphs are keyed by the input pointer once a pointer has been seen twice (resident
-        # batches); otherwise the batch is copied into a static buffer.
-        pkey = (expert_id, B, K, explicit, x.data_ptr(), x.stride(0))
-        seen = self._ptr_seen.get(pkey, 0)
-        self._ptr_seen[pkey] = seen + 1
-        n_ptr_plans = sum(1 for k in self._plans if k[4] != 0)
-        if pkey in self._plans or (seen >= 1 and n_ptr_plans < MAX_POINTER_PLANS):
-            key, x_in = pkey, x
-        else:
-            key = (expert_id, B, K, explicit, 0, 0)
-            x_in = self.buf(f"x_static.{expert_id}", (B, x.shape[1]))
-            if x.is_contiguous():  # own 16-byte copy kernel: the runtime's blit kernel reaches < 1 TB/s here
-                from . import ops
-
-                ops.axpby(1.0, x, 0.0, x_in)
-            else:
-                x_in.copy_(x)
-            if len(self._ptr_seen) > 4096:
-                self._ptr_seen.clear()
+        key, x_in = self._select_input(x, ("train", expert_id, B, K, explicit))
         plan = self._plans.get(key)
         if plan is None:
             plan = _Plan(self, expert_id, B, K, explicit, x_in)
             self._plans[key] = plan
-        # per-step host values -> device scalars
-        klw = float(model.kl_annealing_fn.kl_weight)
-        if klw != self._klw_host:
-            self.klw_dev.fill_(klw)
-            self._klw_host = klw
+        self._set_kl_weight()
         if explicit:
             plan.load_explicit_noise(enc_mod, expert)
         if plan.has_adv:
@@ -213,8 +265,9 @@ class StepEngine:
 
 
 class _Plan:
-    def __init__(self, eng: StepEngine, eid: str, B: int, K: int, explicit: bool, x: torch.Tensor):
+    def __init__(self, eng: StepEngine, eid: str, B: int, K: int, explicit: bool, x: torch.Tensor, mode: str = "train"):
         self.eng, self.eid, self.B, self.K, self.explicit = eng, eid, B, K, explicit
+        self.mode = mode
         self.x = x
         self.R = B * K
         model = eng.model
@@ -421,12 +474,13 @@ class _Plan:
         l.z = eng.buf(f"{tag}.z", (rows, l.n_out)) if l.bn is not None else None
         l.mean = eng.buf(f"{tag}.mean", (l.n_out,)) if l.bn is not None else None
         l.invstd = eng.buf(f"{tag}.invstd", (l.n_out,)) if l.bn is not None else None
-        l.mask = eng.buf(f"{tag}.mask", (rows, l.n_out), torch.uint8) if l.p > 0 else None
-        l.a = eng.buf(f"{tag}.a", (rows, l.n_out)) if (l.p > 0 and l.return_hidden) else None
-        l.dz = eng.buf(f"{tag}.dz", (rows, l.n_out))
+        l.mask = eng.buf(f"{tag}.mask", (rows, l.n_out), torch.uint8) if (l.p > 0 and training) else None
+        l.a = eng.buf(f"{tag}.a", (rows, l.n_out)) if (l.p > 0 and l.return_hidden and training) else None
+        l.dz = eng.buf(f"{tag}.dz", (rows, l.n_out)) if training else None
+        p_drop = l.p if training else 0.0
         self._fcws_bytes = max(getattr(self, "_fcws_bytes", 0), self.lib.mmvae_fc_workspace_bytes(rows, l.n_out))
         sk = self._plan_gemm(NT, rows, l.n_out, l.n_in)
-        if l.bn is None and l.p == 0 and sk == 1:
+        if l.bn is None and p_drop == 0 and sk == 1:
             self.gemm(NT, rows, l.n_out, l.n_in, cur, ld_cur, l.W, l.n_in, l.d, l.n_out, bias=l.b,
                       flags=RELU if l.relu else 0)
             return l.d
@@ -441,8 +495,9 @@ class _Plan:
 
         def call():
             rc = plan.lib.mmvae_fc_epilogue_fwd(rows, l.n_out, plan.slab.data_ptr(), l.n_out, S, _p(l.b),
-                                                C.byref(bnp) if bnp is not None else None, 1, int(l.relu), _p(l.mask),
-                                                l.p, _p(l.z), _p(l.a), _p(l.d), l.n_out, _p(l.mean), _p(l.invstd),
+                                                C.byref(bnp) if bnp is not None else None, int(training), int(l.relu),
+                                                _p(l.mask), p_drop, _p(l.z), _p(l.a), _p(l.d), l.n_out, _p(l.mean),
+                                                _p(l.invstd),
                                                 plan.fcws.data_ptr(), plan.fcws.numel() * 4, _s())
             if rc != 0:
                 raise _lib.HipLibraryError(f"mmvae_fc_epilogue_fwd failed with code {rc}")
@@ -543,10 +598,12 @@ class _Plan:
         x, ldx = self.x, self.x.stride(0) if self.x.shape[0] > 1 else self.x.shape[1]
         self.eps = eng.buf("eps", (K, B, Z))
 
+        train = self.mode == "train"
         # ---- forward, encoder side
         cur, ld = x, ldx
         for i, l in enumerate(self.enc_layers):
-            cur = self.fwd_layer(f"{self.eid}.enc{i}" if i < self.n_expert_enc else f"vae.enc{i}", l, cur, ld, B)
+            cur = self.fwd_layer(f"{self.eid}.enc{i}" if i < self.n_expert_enc else f"vae.enc{i}", l, cur, ld, B,
+                                 training=train)
             ld = l.n_out
         q, HV = cur, self.enc_layers[-1].n_out
         # ---- heads + reparameterisation
@@ -560,10 +617,12 @@ class _Plan:
         self.gemm(NT, B, Z, HV, q, HV, self.var_enc.weight, HV, self.a_raw, Z, bias=self.var_enc.bias)
         self._emit(lib.mmvae_reparam_kl_fwd, B, Z, K, _p(self.mu), _p(self.a_raw), _p(self.eps), self.var_eps,
                    _p(self.std), _p(self.z), _p(self.kl_row), _p(self.stat))
+        if self.mode == "embed":  # predict path: the program ends at z
+            return self._finish_forward_only()
         # ---- forward, decoder side (rows R = K*B)
         cur, ld = self.z, Z
         for i, l in enumerate(self.dec_layers[:-1]):
-            cur = self.fwd_layer(f"{self.eid}.dec{i}.K{K}", l, cur, ld, R)
+            cur = self.fwd_layer(f"{self.eid}.dec{i}.K{K}", l, cur, ld, R, training=train)
             ld = l.n_out
         last = self.dec_layers[-1]
         fused_last = last.relu and last.bn is None and last.p == 0
@@ -571,7 +630,7 @@ class _Plan:
             raise _lib.HipLibraryError("engine: the last decoder layer must be Linear+ReLU (fused recon epilogue)")
         last.inp, last.ld_inp, last.rows = cur, ld, R
         T = lib.mmvae_recon_tiles(G)
-        self.dP = eng.buf(f"dP.{G}", (R, G))
+        self.dP = eng.buf(f"dP.{G}", (R, G)) if train else None
         self.se_part = eng.buf(f"se_part.{G}", (T, R))
         self.w = eng.buf("w", (R,))
         self._emit(lib.mmvae_decoder_recon_rows_f32, R, B, G, last.n_in, _p(cur), ld, _p(last.W), last.n_in,
@@ -579,6 +638,8 @@ class _Plan:
         self.recon_row = eng.buf("recon_row", (B,))
         self._emit(lib.mmvae_elbo_finalize, B, K, T, _p(self.se_part), _p(self.kl_row), _p(self.stat), Z,
                    _p(eng.klw_dev), 1.0, _p(self.metrics), _p(self.w), _p(self.recon_row))
+        if not train:  # validation: the program ends with the ELBO terms in the metrics buffer
+            return self._finish_forward_only()
         # total loss slot starts as the ELBO loss
         self._emit(lib.mmvae_axpby, 1, 1.0, _p(self.metrics), 0.0, self.mptr("total_loss"))
 
@@ -655,6 +716,25 @@ class _Plan:
             self._emit(lib.mmvae_philox_advance, _p(self.rng_state), (n_max + 3) // 4)
             self.segments[0] = self._cur + self.segments[0]
             self._cur = []
+        self._size_workspaces()
+
+    def _finish_forward_only(self):
+        """Close a forward-only program: rsample noise at its head, shared workspaces sized."""
+        eng, lib = self.eng, self.lib
+        self.exp_norm_log = None
+        self.has_adv = False
+        self.segments.append(self._cur)
+        self._cur = []
+        if not self.explicit:
+            n = self.K * self.B * self.Z
+            self._emit(lib.mmvae_philox_normal, n, _p(self.eps), _p(self.rng_state), rng.STREAM_NORMAL, 0)
+            self._emit(lib.mmvae_philox_advance, _p(self.rng_state), (n + 3) // 4)
+            self.segments[0] = self._cur + self.segments[0]
+            self._cur = []
+        self._size_workspaces()
+
+    def _size_workspaces(self):
+        eng = self.eng
         self.fcws = eng.buf("fc_ws", (max(getattr(self, "_fcws_bytes", 0) // 4, 1),))
         for key, t in eng._pool.items():
             if key[0] == "fc_ws" and t.numel() > self.fcws.numel():

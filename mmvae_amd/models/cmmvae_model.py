@@ -114,7 +114,7 @@ class CMMVAEModel(BaseModel):
 
         qz, pz, z, xhats, hidden_representations = self.module(x=x, metadata=metadata, expert_id=expert_id)
         if x.layout == torch.sparse_csr:
-            x = x.to_dense()
+            x = backend.to_dense(x)
         main_loss_dict = self.module.vae.elbo(qz, pz, x, xhats[expert_id], self.kl_annealing_fn.kl_weight)
         main_loss_dict["Mean"], main_loss_dict["Variance"] = self._posterior_stats(qz)
         total_loss = main_loss_dict[RK.LOSS]
@@ -167,10 +167,14 @@ class CMMVAEModel(BaseModel):
         """Eval-mode forward + ELBO, logged under the current stage (:219-248)."""
         self._flush_engine()
         x, metadata, expert_id = batch
-        qz, pz, z, xhats, hidden_representations = self.module(x, metadata, expert_id)
-        if x.layout == torch.sparse_csr:
-            x = x.to_dense()
-        loss_dict = self.module.vae.elbo(qz, pz, x, xhats[expert_id], self.kl_annealing_fn.kl_weight)
+        engine = None if self.module.training else self._get_engine(x)
+        if engine is not None:  # forward-only captured program (eval-mode BatchNorm, no dropout, one rsample)
+            loss_dict = engine.validation_step(x, metadata, expert_id)
+        else:
+            qz, pz, z, xhats, hidden_representations = self.module(x, metadata, expert_id)
+            if x.layout == torch.sparse_csr:
+                x = backend.to_dense(x)
+            loss_dict = self.module.vae.elbo(qz, pz, x, xhats[expert_id], self.kl_annealing_fn.kl_weight)
         self.auto_log(loss_dict, tags=[self.stage_name, expert_id])
         if getattr(self.trainer, "validating", False):
             self.log("val_loss", loss_dict[RK.LOSS], logger=False, on_epoch=True)
@@ -181,6 +185,11 @@ class CMMVAEModel(BaseModel):
     def predict_step(self, batch, batch_idx: int = 0):
         self._flush_engine()
         x, metadata, species = batch
+        engine = None if self.module.training else self._get_engine(x)
+        if engine is not None:
+            z = engine.latent_embeddings(x, metadata, species)
+            metadata["species"] = species
+            return {RK.Z: (z, metadata)}
         return self.module.get_latent_embeddings(x, metadata, species)
 
     # -------------------------------------------------------------------------------------------------- optimisers

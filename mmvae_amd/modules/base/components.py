@@ -203,6 +203,8 @@ class FCBlock(nn.Module):
     def forward(self, x: torch.Tensor):
         """Returns the output, or (output, hidden) when any layer has return_hidden (components.py:292-314):
         hidden holds the tensor right after the activation ("af"), before dropout."""
+        if x.layout == torch.sparse_csr:  # CSR batches (datapipes with return_dense: false) are densified on entry
+            x = backend.to_dense(x)
         if not backend.on_hip(x):
             return self._forward_cpu_plumbing(x)
         hidden = []

@@ -48,7 +48,7 @@ class BaseVAE(nn.Module):
         """loss = recon + kl_weight * KL, KL = sum over latent, MEAN over cells; recon = SUM of squared errors over
         cells x genes (vae.py:136-152).  xhat with K*B rows selects the K-sample log-mean-exp extension."""
         if x.layout == torch.sparse_csr:
-            x = x.to_dense()
+            x = backend.to_dense(x)
         if backend.on_hip(xhat):
             cache = getattr(qz, "_mmvae", None)
             if cache is not None:

@@ -500,6 +500,32 @@ def sum_parts_batch(jobs) -> None:
     torch.cuda.current_stream().synchronize()  # jobs_dev must outlive the launch
 
 
+def csr_to_dense(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Dense fp32 [B, G] rows of a `torch.sparse_csr` batch (device), written by one HIP pass."""
+    lib = _lib.load()
+    if x.layout != torch.sparse_csr or x.dim() != 2:
+        raise ValueError("csr_to_dense: expected a 2-D torch.sparse_csr tensor")
+    crow, col, val = x.crow_indices(), x.col_indices(), x.values()
+    if not val.is_cuda:
+        raise _lib.HipLibraryError("csr_to_dense: CPU tensors have no HIP path")
+    if crow.dtype != torch.int64 or col.dtype != torch.int64:
+        crow, col = crow.long(), col.long()
+    if val.dtype != torch.float32:
+        val = val.float()
+    B, G = x.shape
+    if out is None:
+        out = torch.empty((B, G), dtype=torch.float32, device=val.device)
+    _chk(out, "out")
+    if tuple(out.shape) != (B, G):
+        raise ValueError(f"out {tuple(out.shape)} != {(B, G)}")
+    nnz = int(val.numel())
+    crow, col, val = crow.contiguous(), col.contiguous(), val.contiguous()
+    _lib.check(lib.mmvae_csr_to_dense_f32(B, G, nnz, crow.data_ptr(), col.data_ptr() if nnz else None,
+                                          val.data_ptr() if nnz else None, _ptr(out), _mat(out, "out")[2], _stream()),
+               "mmvae_csr_to_dense_f32")
+    return out
+
+
 def gemm_batch(jobs) -> None:
     """Grouped launch of small GEMMs.  jobs: list of dicts {layout, a, b, out, bias=None, alpha=1.0, relu=False,
     accumulate=False} with the operand conventions of gemm().  One launch (mmvae_gemm_batch_f32); raises when a job

@@ -225,7 +225,7 @@ def model_forward(spec: ModelSpec, sd, x, expert_id: str, eps, training: bool, m
     zk = z.reshape(-1, z.shape[-1])
     sh, _ = fcblock_forward(sd, "vae.decoder", spec.vae_decoder, zk, training, masks, hp, bn_updates)
     xhat, _ = fcblock_forward(sd, f"experts.{expert_id}.decoder", dec, sh, training, masks, hp, bn_updates)
-    return {"mu": mu, "std": std, "z": z, "xhat": xhat, "hidden": hidden}
+    return {"mu": mu, "std": std, "z": z, "xhat": xhat, "hidden": hidden, "shared_xhat": sh}
 
 
 def elbo(mu, std, x, xhat, kl_weight: float, K: int = 1):
@@ -371,7 +371,22 @@ def eval_step(spec: ModelSpec, sd, x, expert_id: str, eps, kl_weight: float, hp:
     with torch.no_grad():
         fwd = model_forward(spec, sd, x, expert_id, eps, False, None, hp)
         e = elbo(fwd["mu"], fwd["std"], x, fwd["xhat"], kl_weight, 1)
-    return {**e, "z": fwd["z"], "xhat": fwd["xhat"]}
+    return {**e, "z": fwd["z"], "xhat": fwd["xhat"], "mu": fwd["mu"]}
+
+
+def cross_generate(spec: ModelSpec, sd, x, expert_id: str, eps, hp: HParams):
+    """CMMVAE.forward(..., cross_generate=True) in eval mode (modules/cmmvae.py:95-107): the shared decoder output is
+    decoded through EVERY expert.  Returns {expert: xhat}."""
+    with torch.no_grad():
+        fwd = model_forward(spec, sd, x, expert_id, eps, False, None, hp)
+        return {other: fcblock_forward(sd, f"experts.{other}.decoder", dec, fwd["shared_xhat"], False, None, hp)[0]
+                for other, (_, dec) in spec.experts.items()}
+
+
+def latent_embeddings(spec: ModelSpec, sd, x, expert_id: str, eps, hp: HParams):
+    """CMMVAE.get_latent_embeddings (modules/cmmvae.py:115-142): expert encoder + VAE encoder, one rsample -> z."""
+    with torch.no_grad():
+        return model_forward(spec, sd, x, expert_id, eps, False, None, hp)["z"]
 
 
 def linear_kl_weight(step_count: int, min_kl=1e-7, max_kl=1e-5, warmup_steps=1e3, climax_steps=1e4) -> float:

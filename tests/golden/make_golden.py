@@ -228,6 +228,15 @@ def run_case(case):
                 out[f"eval/out/{k}"] = ld[k].numpy().copy()
             out["eval/out/z"] = z.numpy().copy()
             out["eval/out/xhat"] = xhats[eid].numpy().copy()
+            out["eval/out/mu"] = qz.loc.numpy().copy()
+            # ---- cross-generation (cmmvae.py:95-107; runners/cross_generation.py:87-152): decode the shared latent
+            #      through every expert; and the predict path, get_latent_embeddings (cmmvae.py:115-142)
+            with torch.no_grad():
+                _, _, _, xh_all, _ = module(x, metadata, eid, cross_generate=True)
+                emb = module.get_latent_embeddings(x, metadata, eid)
+            for other, xh in xh_all.items():
+                out[f"eval/out/xhat_cross/{other}"] = xh.numpy().copy()
+            out["eval/out/embedding_z"] = emb["z"][0].numpy().copy()
         finally:
             Normal.rsample = orig_rsample
     out["case_json"] = np.array(json.dumps(case))
@@ -274,6 +283,10 @@ def main():
     for name, case in CASES.items():
         out = run_case(dict(case))
         path = os.path.join(OUT_DIR, f"{name}.npz")
+        if os.path.exists(path):  # regenerated vectors must reproduce the committed ones bit for bit
+            old = np.load(path)
+            for k in old.files:
+                assert k in out and np.array_equal(np.asarray(old[k]), np.asarray(out[k])), f"{name}: {k} changed"
         np.savez_compressed(path, **out)
         print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")
     ann = annealing_vectors()

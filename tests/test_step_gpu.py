@@ -56,3 +56,65 @@ def test_engine_overlapped_exchange_with_single_rank_rccl(monkeypatch):
     finally:
         torch.cuda.synchronize()
         td.destroy_process_group()
+
+
+def _trained_mirror(name, tmpdir, use_engine):
+    """The mirror holding the reference's own post-training state of a golden case, in eval mode."""
+    case, z = H.load_case(name)
+    model = MU.build_mirror(case, "cuda", tmpdir, use_engine=use_engine)
+    T = len(case["schedule"]) - 1
+    MU.load_state(model, z, f"step{T}/sd/")
+    model.eval()
+    model.trainer.set_stage("validation")
+    x, eps, _, labels = H.step_inputs(z, T)
+    meta = {cond: [f"{cond}_{int(i)}" for i in idx] for cond, idx in labels.items()}
+    import pandas as pd
+
+    metadata = pd.DataFrame(meta if meta else {"dummy": [0] * x.shape[0]})
+    model.module.vae.encoder.explicit_eps = eps.cuda()
+    return case, z, model, x.cuda(), metadata, str(z["eval/expert_id"])
+
+
+@pytest.mark.parametrize("use_engine", [False, True])
+@pytest.mark.parametrize("name", H.CASES)
+def test_eval_and_predict_paths_match_reference(name, use_engine, tmp_path):
+    """validation_step (eval-mode forward + ELBO, cmmvae_model.py:219-248), predict_step /
+    get_latent_embeddings (cmmvae.py:115-142) and cross-generation (cmmvae.py:95-107) on the HIP path against the
+    reference's own outputs.  Tolerances: losses rtol 1e-4 (eval mode right after 2-3 steps runs on barely-warmed
+    running statistics: activations are huge), tensors rel-L2 <= 2e-5."""
+    import numpy as np
+
+    case, z, model, x, metadata, eid = _trained_mirror(name, str(tmp_path), use_engine)
+    with torch.no_grad():
+        ld = model.validation_step((x, metadata, eid))
+        torch.cuda.synchronize()
+        for k in ("loss", "recon_loss", "kl_loss"):
+            ref = float(np.array(z[f"eval/out/{k}"]))
+            assert abs(float(ld[k]) - ref) <= 1e-4 * abs(ref) + 1e-5, (k, float(ld[k]), ref)
+        assert f"loss/validation/{eid}" in model.logged
+        emb = model.predict_step((x, metadata, eid))
+        assert H.rel_l2(emb["z"][0], z["eval/out/embedding_z"]) < 2e-5
+        assert (emb["z"][1]["species"] == eid).all()
+        qz, pz, zz, xhats, hidden = model.module(x, metadata, eid, cross_generate=True)
+        assert set(xhats) == set(case["experts"])
+        for other, xh in xhats.items():
+            assert H.rel_l2(xh, z[f"eval/out/xhat_cross/{other}"]) < 2e-5
+        assert H.rel_l2(zz, z["eval/out/z"]) < 2e-5
+
+
+@pytest.mark.parametrize("use_engine", [False, True])
+def test_csr_batches_train_like_dense_ones(use_engine, monkeypatch):
+    """a `torch.sparse_csr` batch (what the datapipes yield with return_dense: false) is densified by
+    the HIP pass and must give the reference's results bit for bit the same way the dense batch does."""
+    import tests.helpers as HH
+
+    orig = HH.step_inputs
+
+    def csr_inputs(z, t):
+        x, eps, masks, labels = orig(z, t)
+        return x.to_sparse_csr(), eps, masks, labels
+
+    monkeypatch.setattr(HH, "step_inputs", csr_inputs)
+    monkeypatch.setattr(MU.H, "step_inputs", csr_inputs)
+    case, z, results = MU.replay_training("two_mod_odd", "cuda", use_engine=use_engine)
+    MU.check_against_golden(case, z, results)
