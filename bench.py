@@ -28,6 +28,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", help="BASELINE config: c1..c5 (c2 = the configuration the metric is quoted on)")
     ap.add_argument("--no-engine", action="store_true", help="module (autograd) path instead of the captured engine")
+    ap.add_argument("--mode", default="train", choices=["train", "validate", "predict"],
+                    help="train = the headline metric; validate / predict = the forward-only programs (SURVEY 8 f3)")
+    ap.add_argument("--input", default="dense", choices=["dense", "csr"],
+                    help="csr: batches arrive as torch.sparse_csr (resident in HBM) and are densified per step (8 f1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample")
     return ap.parse_args()
@@ -145,10 +149,21 @@ def main():
         data[eid] = [(synthetic.synthetic_counts(B, G, seed=1234 + 97 * i + 13 * j + 1000 * rank, device=device),
                       synthetic.synthetic_metadata(B, seed=5 + j + 1000 * rank)) for j in range(n_res)]
 
+    if a.input == "csr":
+        data = {eid: [(x.to_sparse_csr(), m) for x, m in v] for eid, v in data.items()}
+    if a.mode != "train":
+        model.eval()
+        model.trainer.set_stage("validation" if a.mode == "validate" else "predict")
+
     def step(i):
         eid = eids[i % len(eids)]  # rank-synchronous round-robin schedule
         x, meta = data[eid][(i // len(eids)) % n_res]
-        model.training_step((x, meta, eid), i)
+        if a.mode == "train":
+            model.training_step((x, meta, eid), i)
+        elif a.mode == "validate":
+            model.validation_step((x, meta, eid))
+        else:
+            model.predict_step((x, meta, eid), i)
 
     def sync():
         torch.cuda.synchronize()
@@ -183,11 +198,13 @@ def main():
         G = max(cfg["experts"].values())
         cells_per_s = B * world * a.steps / el
         out = {
-            "metric": "cells/sec per MMVAE train step", "value": cells_per_s, "unit": "cells/s", "n_gpus": world,
+            "metric": {"train": "cells/sec per MMVAE train step", "validate": "cells/sec per MMVAE validation step",
+                       "predict": "cells/sec per MMVAE predict step (latent embeddings)"}[a.mode], "value": cells_per_s, "unit": "cells/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.config}: {len(eids)}-modality MMVAE train step, {G} genes each, latent 128, "
-                                   f"K={K}, batch {B}/GPU, adversarial={cfg['adversarial']}",
+                                   f"K={K}, batch {B}/GPU, adversarial={cfg['adversarial']}"
+                                   + (", CSR input densified per step" if a.input == "csr" else ""),
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "path": "module" if (a.no_engine or not model._engine) else "engine(hipGraph)"},
             "step_flops_per_cell": synthetic.flops_per_cell(G, K),
