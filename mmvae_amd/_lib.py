@@ -11,6 +11,8 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmmvae_hip.so")
+if os.environ.get("MMVAE_LIB"):  # A/B runs of two builds of the same source tree (diagnostics)
+    LIB_PATH = os.environ["MMVAE_LIB"]
 
 OK, ERR_ARG, ERR_LAUNCH, ERR_WORKSPACE = 0, 1, 2, 3
 _ERR_NAMES = {1: "MMVAE_ERR_ARG", 2: "MMVAE_ERR_LAUNCH", 3: "MMVAE_ERR_WORKSPACE"}

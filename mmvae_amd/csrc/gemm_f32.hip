@@ -22,6 +22,7 @@
 //   * The last decoder layer has its own epilogue: bias + ReLU + (xhat - x)^2 + dP, with the per-cell squared
 //     error reduced across the wavefront by shuffles (mmvae_decoder_recon_f32).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -769,10 +770,10 @@ __device__ __forceinline__ float x3_quad_bcast(float v) {  // value of lane J of
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), J * 0x55, 0xF, 0xF, true));
 }
 
-template <int FORM, int R>
+template <int FORM, int R, bool TAILCHK>
 __device__ __forceinline__ void x3p_split(const f32x4 (&reg)[R / 32], int u, uint2 (&pk)[3], int tid, int k0, int Kend) {
     float v[4];
-    const bool tail = k0 + X3_BK > Kend;
+    const bool tail = TAILCHK && (k0 + X3_BK > Kend);  // steady-state k-tiles are instantiated without the check
     if (FORM == FORM_KC) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = reg[u][j];
@@ -789,20 +790,22 @@ __device__ __forceinline__ void x3p_split(const f32x4 (&reg)[R / 32], int u, uin
             for (int j = 0; j < 4; ++j) v[j] = (k0 + 4 * (tid & 7) + j < Kend) ? v[j] : 0.f;
         }
     } else {
+        // 4 x 4 transpose inside each quad (lane q holds k = q, rows in its 4 components -> row q, k in v[0..3]):
+        // two DPP exchange stages with plain selects (a 4-way select chain here compiles to divergent branches, which
+        // would cut the k-loop body into basic blocks and stop the MFMA / VALU interleave)
         const f32x4 t = reg[R / 32 - 1];
         const int q = tid & 3;
-        float c[4][4];  // c[j][e]: component e of lane j of the quad
+        const bool odd = q & 1, hi2 = q & 2;
+        const float r0 = quad_perm<1, 0, 3, 2>(odd ? t[0] : t[1]), r1 = quad_perm<1, 0, 3, 2>(odd ? t[2] : t[3]);
+        const float c0 = odd ? r0 : t[0], c1 = odd ? t[1] : r0, c2 = odd ? r1 : t[2], c3 = odd ? t[3] : r1;
+        const float t0 = quad_perm<2, 3, 0, 1>(hi2 ? c0 : c2), t1 = quad_perm<2, 3, 0, 1>(hi2 ? c1 : c3);
+        v[0] = hi2 ? t0 : c0;
+        v[1] = hi2 ? t1 : c1;
+        v[2] = hi2 ? c2 : t0;
+        v[3] = hi2 ? c3 : t1;
+        if (tail) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            c[0][e] = x3_quad_bcast<0>(t[e]);
-            c[1][e] = x3_quad_bcast<1>(t[e]);
-            c[2][e] = x3_quad_bcast<2>(t[e]);
-            c[3][e] = x3_quad_bcast<3>(t[e]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] = q == 0 ? c[j][0] : q == 1 ? c[j][1] : q == 2 ? c[j][2] : c[j][3];
-            if (tail) v[j] = (k0 + 4 * (tid >> 5) + j < Kend) ? v[j] : 0.f;
+            for (int j = 0; j < 4; ++j) v[j] = (k0 + 4 * (tid >> 5) + j < Kend) ? v[j] : 0.f;
         }
     }
     f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
@@ -824,6 +827,77 @@ __device__ __forceinline__ void x3p_write(char* S, int u, const uint2 (&pk)[3], 
 #pragma unroll
     for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(S + p * PLANE + off) = pk[p];
 }
+
+// ---- staged split.  The 22 VALU instructions that split one unit (4 consecutive-k fp32 values) into its three packed
+// bf16 planes, cut into 6 chunks of <= 4: the hand-interleaved k-step issues one chunk behind each MFMA of a 6-MFMA
+// group, so that a wave's own VALU work fits into the issue slots its MFMAs leave free (an MFMA holds the SIMD's vector
+// issue for 8 of its 32 cycles; 4 single-issue VALU instructions take 16).  Left to the compiler, the 6 MFMAs are emitted
+// back to back and the unit's instructions as one run of 25-45, and the matrix pipe idles through every run unless the
+// partner wave of the SIMD happens to be in its MFMA phase.
+struct X3Stage {
+    float v[4], h[4], r[4];
+};
+template <int FORM, int R>
+__device__ __forceinline__ void x3s_fetch(X3Stage& s, const f32x4 (&reg)[R / 32], int u, int tid) {
+    if (FORM == FORM_KC) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s.v[j] = reg[u][j];
+    } else if (u < 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s.v[j] = reg[j][u];
+    } else {  // rows 128..159 of a 160-row RC tile: 4 x 4 transpose inside each quad (see x3p_split)
+        const f32x4 t = reg[R / 32 - 1];
+        const int q = tid & 3;
+        const bool odd = q & 1, hi2 = q & 2;
+        const float r0 = quad_perm<1, 0, 3, 2>(odd ? t[0] : t[1]), r1 = quad_perm<1, 0, 3, 2>(odd ? t[2] : t[3]);
+        const float c0 = odd ? r0 : t[0], c1 = odd ? t[1] : r0, c2 = odd ? r1 : t[2], c3 = odd ? t[3] : r1;
+        const float t0 = quad_perm<2, 3, 0, 1>(hi2 ? c0 : c2), t1 = quad_perm<2, 3, 0, 1>(hi2 ? c1 : c3);
+        s.v[0] = hi2 ? t0 : c0;
+        s.v[1] = hi2 ? t1 : c1;
+        s.v[2] = hi2 ? c2 : t0;
+        s.v[3] = hi2 ? c3 : t1;
+    }
+}
+__device__ __forceinline__ float x3_hi(float a) { return __uint_as_float(__float_as_uint(a) & 0xFFFF0000u); }
+__device__ __forceinline__ unsigned x3_pair2(float lo, float hi) {
+    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+template <int P>
+__device__ __forceinline__ void x3s_phase(X3Stage& s, uint2 (&pk)[3]) {
+    if constexpr (P == 0) {
+        pk[0].x = x3_pair2(s.v[0], s.v[1]);
+        pk[0].y = x3_pair2(s.v[2], s.v[3]);
+        s.h[0] = x3_hi(s.v[0]);
+        s.h[1] = x3_hi(s.v[1]);
+    } else if constexpr (P == 1) {
+        s.h[2] = x3_hi(s.v[2]);
+        s.h[3] = x3_hi(s.v[3]);
+        s.r[0] = x3_sub(s.v[0], s.h[0]);
+        s.r[1] = x3_sub(s.v[1], s.h[1]);
+    } else if constexpr (P == 2) {
+        s.r[2] = x3_sub(s.v[2], s.h[2]);
+        s.r[3] = x3_sub(s.v[3], s.h[3]);
+        pk[1].x = x3_pair2(s.r[0], s.r[1]);
+        s.h[0] = x3_hi(s.r[0]);
+    } else if constexpr (P == 3) {
+        s.h[1] = x3_hi(s.r[1]);
+        s.h[2] = x3_hi(s.r[2]);
+        s.h[3] = x3_hi(s.r[3]);
+        pk[1].y = x3_pair2(s.r[2], s.r[3]);
+    } else if constexpr (P == 4) {
+        s.r[0] = x3_sub(s.r[0], s.h[0]);
+        s.r[1] = x3_sub(s.r[1], s.h[1]);
+        s.r[2] = x3_sub(s.r[2], s.h[2]);
+        s.r[3] = x3_sub(s.r[3], s.h[3]);
+    } else {
+        pk[2].x = x3_pair2(s.r[0], s.r[1]);  // <= 8 significant bits left: the top half IS the value
+        pk[2].y = x3_pair2(s.r[2], s.r[3]);
+    }
+}
+#ifndef MMVAE_X3_INTERLEAVE
+#define MMVAE_X3_INTERLEAVE 1  // 1: hand-interleaved steady-state k-step; 0: compiler-scheduled
+#endif
+#define X3_SB() __builtin_amdgcn_sched_barrier(0)
 
 template <int FORM, int R>
 struct X3Regs {
@@ -903,21 +977,26 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
     };
     if (nkt > 0) {
         if constexpr (VEC) {
-            // Software pipeline (one raw staging set + packed planes): while tile t is multiplied, the registers of
-            // tile t+1 (loaded during tile t-1) are split into packed bf16 planes BETWEEN the MFMA groups of the first
-            // k-step, the freed registers are immediately reissued as the loads of tile t+2, and after the barrier
-            // only the ds_write burst remains.
+            // Software pipeline over 16-byte-regular operands with K % 32 == 0 (one raw staging set + packed planes).
+            // While k-tile t is multiplied, the raw registers of tile t+1 (loaded during tile t-1) are split into
+            // packed bf16 planes, one chunk of <= 4 VALU instructions behind every MFMA; the operand with more split
+            // units is split during k-step 0, the other one during k-step 1, and each operand's raw registers are
+            // re-issued as the loads of tile t+2 as soon as its last unit is split; after the barrier only the
+            // ds_write burst remains.  The body is the same for every k-tile: the last one splits and writes a tile
+            // that nobody reads (its loads are clamped into the matrix), which is cheaper than a second copy of the
+            // loop body with guards (the guarded copies pushed the kernel into scratch spills).
             constexpr int NUA = BM / 32, NUB = BN / 32, NG = TM * TN;
             static_assert(NG >= NUA && NG >= NUB, "one split unit per MFMA group");
+            constexpr bool A_FIRST = NUA > NUB;
             f32x4 ra[NUA], rb[NUB];
             uint2 pka[NUA][3], pkb[NUB][3];
-            auto load_ab = [&](int kt) {
-                x3p_load<AFORM, BM>(ra, g.A, g.lda, bm * BM, g.M, kt * X3_BK, g.K, tid);
-                x3p_load<BFORM, BN>(rb, g.B, g.ldb, bn * BN, g.N, kt * X3_BK, g.K, tid);
-            };
-            auto split_unit = [&](int u, int kt) {
-                if (u < NUA) x3p_split<AFORM, BM>(ra, u, pka[u < NUA ? u : 0], tid, kt * X3_BK, g.K);
-                if (u < NUB) x3p_split<BFORM, BN>(rb, u, pkb[u < NUB ? u : 0], tid, kt * X3_BK, g.K);
+            auto load_a = [&](int kt) { x3p_load<AFORM, BM>(ra, g.A, g.lda, bm * BM, g.M, kt * X3_BK, g.K, tid); };
+            auto load_b = [&](int kt) { x3p_load<BFORM, BN>(rb, g.B, g.ldb, bn * BN, g.N, kt * X3_BK, g.K, tid); };
+            auto reload = [&](int phase, int kt) {
+                if ((phase == 0) == A_FIRST)
+                    load_a(kt);
+                else
+                    load_b(kt);
             };
             auto write_all = [&]() {
 #pragma unroll
@@ -925,10 +1004,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int u = 0; u < NUB; ++u) x3p_write<BFORM, BN>(Bs, u, pkb[u], tid);
             };
-            load_ab(kt_beg);
+            load_a(kt_beg);
+            load_b(kt_beg);
 #pragma unroll
-            for (int u = 0; u < NG; ++u) split_unit(u, kt_beg);
-            if (nkt > 1) load_ab(kt_beg + 1);
+            for (int u = 0; u < NG; ++u) {
+                if (u < NUA) x3p_split<AFORM, BM, false>(ra, u, pka[u < NUA ? u : 0], tid, kt_beg * X3_BK, g.K);
+                if (u < NUB) x3p_split<BFORM, BN, false>(rb, u, pkb[u < NUB ? u : 0], tid, kt_beg * X3_BK, g.K);
+            }
+            load_a(kt_beg + 1);
+            load_b(kt_beg + 1);
             write_all();
             __syncthreads();
 #if MMVAE_X3_STAMPS
@@ -944,88 +1028,132 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
 #else
 #define X3_STAMP(i)
 #endif
-            // One 16-deep k-step.  Square wave tiles (2x2 blocks) read all their fragments up front; the 1x5 / 5x1 wave
-            // tiles of the 160-wide block tiles keep the short side's fragments and stream the long side's one block
-            // ahead of its MFMA group (two 3-plane sets), which is what keeps them inside 256 VGPRs.
-            auto frag3 = [&](bf16x8 (&f)[3], const char* S, int plane_bytes, int row, int ks) {
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    f[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(S + p * plane_bytes + row * X3_LD +
-                                                                                       ks * 32 + half * 16));
+            auto frag1 = [&](bf16x8& f, const char* S, int plane_bytes, int row, int ks, int p) {
+                f = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(S + p * plane_bytes + row * X3_LD + ks * 32 +
+                                                                               half * 16));
             };
-            auto mfma6 = [&](f32x16& cc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
-                f32x16 c = cc;  // smallest terms first
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
-                cc = c;
-            };
-            auto kstep = [&](int ks, bool do_split, int kt_next) {
+            // One 16-deep k-step: 6 MFMAs per 32x32 block (smallest terms first), one split chunk behind every MFMA,
+            // the next block's fragment reads behind the last three MFMAs, sched_barrier fences pin the order.
+            auto kstep_il = [&](int ks) {
+                const bool first_is_a = (ks == 0) == A_FIRST;  // which operand this k-step splits
+                X3Stage st_;
+                auto fetch = [&](int u) {
+                    if (first_is_a) {
+                        if (u < NUA) x3s_fetch<AFORM, BM>(st_, ra, u, tid);
+                    } else {
+                        if (u < NUB) x3s_fetch<BFORM, BN>(st_, rb, u, tid);
+                    }
+                };
+                auto chunk = [&](int u, auto P) {
+                    constexpr int PH = decltype(P)::value;
+                    if (first_is_a) {
+                        if (u < NUA) x3s_phase<PH>(st_, pka[u < NUA ? u : 0]);
+                    } else {
+                        if (u < NUB) x3s_phase<PH>(st_, pkb[u < NUB ? u : 0]);
+                    }
+                };
+                using I0 = std::integral_constant<int, 0>;
+                using I1 = std::integral_constant<int, 1>;
+                using I2 = std::integral_constant<int, 2>;
+                using I3 = std::integral_constant<int, 3>;
+                using I4 = std::integral_constant<int, 4>;
+                using I5 = std::integral_constant<int, 5>;
+#define X3_GROUP(C, A2, A1, A0, B0, B1, B2, U, RD)                        \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B0, C, 0, 0, 0);       \
+    chunk(U, I0{});                                                        \
+    X3_SB();                                                               \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, C, 0, 0, 0);       \
+    chunk(U, I1{});                                                        \
+    X3_SB();                                                               \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B2, C, 0, 0, 0);       \
+    chunk(U, I2{});                                                        \
+    X3_SB();                                                               \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, C, 0, 0, 0);       \
+    chunk(U, I3{});                                                        \
+    RD(0);                                                                 \
+    X3_SB();                                                               \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B1, C, 0, 0, 0);       \
+    chunk(U, I4{});                                                        \
+    RD(1);                                                                 \
+    X3_SB();                                                               \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, C, 0, 0, 0);       \
+    chunk(U, I5{});                                                        \
+    RD(2);                                                                 \
+    X3_SB();
                 if constexpr (TM == 2 && TN == 2) {
                     bf16x8 fa[3][TM], fb[3][TN];
-                    load_frags(ks, fa, fb);
+                    // first the fragments of block (0,0), in the order its MFMAs consume them
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
+                    for (int p = 2; p >= 0; --p) frag1(fa[p][0], As, PA, wm * WTM + l31, ks, p);
 #pragma unroll
-                        for (int n = 0; n < TN; ++n) {
-#if MMVAE_X3_ABLATE != 4
-                            mfma_group(i, n, fa, fb);
-#endif
-#if MMVAE_X3_ABLATE != 1
-                            if (do_split) split_unit(i * TN + n, kt_next);
-#endif
-                        }
+                    for (int p = 0; p < 3; ++p) frag1(fb[p][0], Bs, PB, wn * WTN + l31, ks, p);
+                    X3_SB();
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int i = gq >> 1, n = gq & 1;
+                        fetch(gq);
+                        // reads behind this block's last three MFMAs: block 0 -> b[.][1], block 1 -> a[.][1]
+                        auto rd = [&](int slot) {
+                            if (gq == 0) frag1(fb[slot][1], Bs, PB, wn * WTN + 32 + l31, ks, slot);
+                            if (gq == 1) frag1(fa[2 - slot][1], As, PA, wm * WTM + 32 + l31, ks, 2 - slot);
+                        };
+                        f32x16 c = acc[i][n];
+                        X3_GROUP(c, fa[2][i], fa[1][i], fa[0][i], fb[0][n], fb[1][n], fb[2][n], gq, rd)
+                        acc[i][n] = c;
+                    }
                 } else {
                     constexpr bool STREAM_B = TM == 1;
                     static_assert(TM == 1 || TN == 1, "streamed fragments: one side has a single 32-row block");
                     constexpr int NL = STREAM_B ? TN : TM;
                     bf16x8 fs[3], fl[2][3];  // short side (kept), long side (double-buffered)
                     if (STREAM_B) {
-                        frag3(fs, As, PA, wm * WTM + l31, ks);
-                        frag3(fl[0], Bs, PB, wn * WTN + l31, ks);
+#pragma unroll
+                        for (int p = 2; p >= 0; --p) frag1(fs[p], As, PA, wm * WTM + l31, ks, p);
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) frag1(fl[0][p], Bs, PB, wn * WTN + l31, ks, p);
                     } else {
-                        frag3(fs, Bs, PB, wn * WTN + l31, ks);
-                        frag3(fl[0], As, PA, wm * WTM + l31, ks);
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) frag1(fs[p], Bs, PB, wn * WTN + l31, ks, p);
+#pragma unroll
+                        for (int p = 2; p >= 0; --p) frag1(fl[0][p], As, PA, wm * WTM + l31, ks, p);
                     }
+                    X3_SB();
 #pragma unroll
                     for (int j = 0; j < NL; ++j) {
-                        if (j + 1 < NL) {
-                            if (STREAM_B)
-                                frag3(fl[(j + 1) & 1], Bs, PB, wn * WTN + (j + 1) * 32 + l31, ks);
-                            else
-                                frag3(fl[(j + 1) & 1], As, PA, wm * WTM + (j + 1) * 32 + l31, ks);
+                        fetch(j);
+                        auto rd = [&](int slot) {  // the next block's planes in the order its MFMAs consume them
+                            if (j + 1 < NL) {
+                                if (STREAM_B)
+                                    frag1(fl[(j + 1) & 1][slot], Bs, PB, wn * WTN + (j + 1) * 32 + l31, ks, slot);
+                                else
+                                    frag1(fl[(j + 1) & 1][2 - slot], As, PA, wm * WTM + (j + 1) * 32 + l31, ks, 2 - slot);
+                            }
+                        };
+                        if (STREAM_B) {
+                            f32x16 c = acc[0][j < TN ? j : 0];
+                            X3_GROUP(c, fs[2], fs[1], fs[0], fl[j & 1][0], fl[j & 1][1], fl[j & 1][2], j, rd)
+                            acc[0][j < TN ? j : 0] = c;
+                        } else {
+                            f32x16 c = acc[j < TM ? j : 0][0];
+                            X3_GROUP(c, fl[j & 1][2], fl[j & 1][1], fl[j & 1][0], fs[0], fs[1], fs[2], j, rd)
+                            acc[j < TM ? j : 0][0] = c;
                         }
-#if MMVAE_X3_ABLATE != 4
-                        if (STREAM_B)
-                            mfma6(acc[0][j < TN ? j : 0], fs, fl[j & 1]);
-                        else
-                            mfma6(acc[j < TM ? j : 0][0], fl[j & 1], fs);
-#endif
-#if MMVAE_X3_ABLATE != 1
-                        if (do_split) split_unit(j, kt_next);
-#endif
                     }
                 }
+#undef X3_GROUP
             };
             for (int kt = 0; kt < nkt; ++kt) {
-                const bool more = kt + 1 < nkt;
                 X3_STAMP(0)
-                kstep(0, more, kt_beg + kt + 1);  // MFMA groups with one split unit (A and B) after each
-                X3_STAMP(1)  // k-step 0 MFMAs issued + split of the next tile done
-#if MMVAE_X3_ABLATE != 2
-                if (kt + 2 < nkt) load_ab(kt_beg + kt + 2);  // raw registers are free again: next-next tile in flight
-#endif
+                kstep_il(0);
+                X3_STAMP(1)
+                reload(0, kt_beg + kt + 2);  // this operand's raw registers are free again: next-next tile in flight
                 X3_STAMP(2)
-                kstep(1, false, 0);
+                kstep_il(1);
+                reload(1, kt_beg + kt + 2);
                 X3_STAMP(3)  // k-step 1 MFMAs issued
                 __syncthreads();  // every wave is done reading this k-tile
                 X3_STAMP(4)
-#if MMVAE_X3_ABLATE != 3
-                if (more) write_all();
-#endif
+                write_all();
                 X3_STAMP(5)  // plane writes issued and landed
                 __syncthreads();
                 X3_STAMP(6)
@@ -1174,9 +1302,9 @@ int launch_gemm_x3(int tile_id, const GemmArgs& g0, int nwork, hipStream_t s) {
 // tile_id 3, 4, 5 = the bf16x3 kernel (128x128, 128x160, 160x128 tiles; the last two need 16-byte-regular operands)
 template <int AFORM, int BFORM, int EPI>
 int launch_gemm_forms(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) {
-    if (tile_id >= 3)
-        return g.aligned == 2 ? launch_gemm_x3<AFORM, BFORM, true, EPI>(tile_id, g, nblocks, s)
-                              : launch_gemm_x3<AFORM, BFORM, false, EPI>(tile_id, g, nblocks, s);
+    if (tile_id >= 3)  // the pipelined bf16x3 loop needs 16-byte-regular operands and whole k-tiles
+        return (g.aligned == 2 && g.K % X3_BK == 0) ? launch_gemm_x3<AFORM, BFORM, true, EPI>(tile_id, g, nblocks, s)
+                                                    : launch_gemm_x3<AFORM, BFORM, false, EPI>(tile_id, g, nblocks, s);
     return g.aligned == 2 ? launch_gemm_vec<AFORM, BFORM, true, EPI>(tile_id, g, nblocks, s)
                           : launch_gemm_vec<AFORM, BFORM, false, EPI>(tile_id, g, nblocks, s);
 }
@@ -1287,7 +1415,7 @@ extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, cons
     int aligned = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     if (aligned && M % 4 == 0 && N % 4 == 0 && K % 4 == 0) aligned = 2;
     if (g_precision == MMVAE_GEMM_PRECISION_BF16X3 && tile_id != 2)  // chip-filling GEMMs: bf16x3 cores
-        tile_id = (aligned == 2 && splitk == 1) ? x3_tile_for(M, N, true) : 3;
+        tile_id = (aligned == 2 && K % X3_BK == 0 && splitk == 1) ? x3_tile_for(M, N, true) : 3;
     const TileShape ts = tile_shape(layout, tile_id);
     const int ktiles = ceil_div_i(K, bk_of(layout, tile_id));
     const bool raw = (flags & MMVAE_GEMM_RAW_SLABS) != 0;
@@ -1431,7 +1559,7 @@ extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, 
     const bool x3 = g_precision == MMVAE_GEMM_PRECISION_BF16X3;
     g.aligned = aligned16(h) && aligned16(W) && (ldh % 4 == 0) && (ldw % 4 == 0);
     if (g.aligned && rows % 4 == 0 && G % 4 == 0 && H % 4 == 0) g.aligned = 2;
-    const int tile_id = !x3 ? 1 : (g.aligned == 2 ? x3_tile_for(rows, G, false) : 3);
+    const int tile_id = !x3 ? 1 : ((g.aligned == 2 && H % X3_BK == 0) ? x3_tile_for(rows, G, false) : 3);
     g.mt = ceil_div_i(rows, 128);
     g.nt = ceil_div_i(G, tile_shape(0, tile_id).bn);
     g.se_tiles = mmvae_recon_tiles(G);  // rows nt .. se_tiles-1 of se_part are zeroed by the last column tile

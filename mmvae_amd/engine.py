@@ -642,6 +642,8 @@ class _Plan:
             return self._finish_forward_only()
         # total loss slot starts as the ELBO loss
         self._emit(lib.mmvae_axpby, 1, 1.0, _p(self.metrics), 0.0, self.mptr("total_loss"))
+        for _ in range(int(os.environ.get("MMVAE_EXTRA_LAUNCHES", "0"))):  # diagnostics: price of one trivial launch
+            self._emit(lib.mmvae_axpby, 1, 1.0, _p(self.metrics), 0.0, self.mptr("total_loss"))
 
         # ---- adversarial phases
         hidden = [l.a if l.a is not None else l.d for l in self.enc_layers if l.return_hidden]
