@@ -735,34 +735,41 @@ __device__ __forceinline__ void x3_pack4_lean(f32x2 lo, f32x2 hi, uint2 (&pk)[3]
 //                                     same 4 rows and transpose them with DPP quad broadcasts: unit 4 = row 4 rq + q.
 // Rows/columns beyond the matrix are loaded from clamped (finite, in-matrix) addresses: they only reach accumulators
 // the epilogue never stores.  Only the K tail must be zeroed, and only in the last k-tile (a wave-uniform branch).
+// Loads are addressed as (wave-uniform tile base, advanced by the k-tile) + (per-thread byte offset, constant over the
+// k-loop): the offsets are computed once per work item, the loop itself spends no VALU on addresses (global_load with an
+// SGPR base and a 32-bit VGPR offset).  Requires K % 32 == 0 (no k clamp) and < 4 GiB between a tile's first and last
+// byte of one k-tile (124 * ld bytes).
 template <int FORM, int R>
-__device__ __forceinline__ void x3p_load(f32x4 (&reg)[R / 32], const float* __restrict__ P, int64_t ld, int r0, int Rtot,
-                                         int k0, int Kend, int tid) {
+__device__ __forceinline__ void x3p_offsets(unsigned (&off)[R / 32], int64_t ld, int r0, int Rtot, int tid) {
     constexpr int NU = R / 32;
     if (FORM == FORM_KC) {
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int f = tid + NT * u;
-            const int row = r0 + (f >> 3), k = k0 + 4 * (f & 7);
-            reg[u] = *reinterpret_cast<const f32x4*>(P + (int64_t)(row < Rtot ? row : Rtot - 1) * ld +
-                                                     (k + 3 < Kend ? k : 0));
+            const int row = r0 + (f >> 3);
+            off[u] = (unsigned)(((int64_t)((row < Rtot ? row : Rtot - 1) - r0) * ld + 4 * (f & 7)) * 4);
         }
     } else {
         const int c4 = tid >> 3, kq = tid & 7;
-        const int x = r0 + 4 * c4;
-        const int xo = (x + 3 < Rtot) ? x : 0;
+        const int xo = (r0 + 4 * c4 + 3 < Rtot) ? 4 * c4 : 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int o = k0 + 4 * kq + j;
-            reg[j] = *reinterpret_cast<const f32x4*>(P + (int64_t)(o < Kend ? o : Kend - 1) * ld + xo);
-        }
+        for (int j = 0; j < 4; ++j) off[j] = (unsigned)(((int64_t)(4 * kq + j) * ld + xo) * 4);
         if (NU == 5) {
-            const int o = k0 + 4 * (tid >> 5) + (tid & 3);
-            const int xt = r0 + 128 + 4 * ((tid >> 2) & 7);
-            reg[NU - 1] = *reinterpret_cast<const f32x4*>(P + (int64_t)(o < Kend ? o : Kend - 1) * ld +
-                                                          ((xt + 3 < Rtot) ? xt : 0));
+            const int xt = 128 + 4 * ((tid >> 2) & 7);
+            off[NU - 1] = (unsigned)(((int64_t)(4 * (tid >> 5) + (tid & 3)) * ld + ((r0 + xt + 3 < Rtot) ? xt : 0)) * 4);
         }
     }
+}
+// tile base of k-tile kt: first row/column r0 of the tile, first k of the k-tile
+template <int FORM>
+__device__ __forceinline__ const char* x3p_base(const float* __restrict__ P, int64_t ld, int r0, int kt) {
+    const int64_t k0 = (int64_t)kt * X3_BK;
+    return reinterpret_cast<const char*>(FORM == FORM_KC ? P + (int64_t)r0 * ld + k0 : P + k0 * ld + r0);
+}
+template <int NU>
+__device__ __forceinline__ void x3p_load(f32x4 (&reg)[NU], const char* __restrict__ base, const unsigned (&off)[NU]) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) reg[u] = *reinterpret_cast<const f32x4*>(base + off[u]);
 }
 
 template <int J>
@@ -894,6 +901,10 @@ __device__ __forceinline__ void x3s_phase(X3Stage& s, uint2 (&pk)[3]) {
         pk[2].y = x3_pair2(s.r[2], s.r[3]);
     }
 }
+#ifndef MMVAE_X3_PRIO_TOGGLE
+#define MMVAE_X3_PRIO_TOGGLE 0  // 1: alternate the wave priority per k-tile, opposite phase per wave slot (measured: the
+                                // two workgroups of a CU finish closer together, the kernel does not get shorter)
+#endif
 #ifndef MMVAE_X3_INTERLEAVE
 #define MMVAE_X3_INTERLEAVE 1  // 1: hand-interleaved steady-state k-step; 0: compiler-scheduled
 #endif
@@ -990,8 +1001,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
             constexpr bool A_FIRST = NUA > NUB;
             f32x4 ra[NUA], rb[NUB];
             uint2 pka[NUA][3], pkb[NUB][3];
-            auto load_a = [&](int kt) { x3p_load<AFORM, BM>(ra, g.A, g.lda, bm * BM, g.M, kt * X3_BK, g.K, tid); };
-            auto load_b = [&](int kt) { x3p_load<BFORM, BN>(rb, g.B, g.ldb, bn * BN, g.N, kt * X3_BK, g.K, tid); };
+            unsigned offa[NUA], offb[NUB];
+            x3p_offsets<AFORM, BM>(offa, g.lda, bm * BM, g.M, tid);
+            x3p_offsets<BFORM, BN>(offb, g.ldb, bn * BN, g.N, tid);
+            const int kt_last = g.ktiles - 1;  // loads past the end re-read the last k-tile (never multiplied)
+            auto load_a = [&](int kt) { x3p_load<NUA>(ra, x3p_base<AFORM>(g.A, g.lda, bm * BM, min(kt, kt_last)), offa); };
+            auto load_b = [&](int kt) { x3p_load<NUB>(rb, x3p_base<BFORM>(g.B, g.ldb, bn * BN, min(kt, kt_last)), offb); };
             auto reload = [&](int phase, int kt) {
                 if ((phase == 0) == A_FIRST)
                     load_a(kt);
@@ -1034,6 +1049,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
             };
             // One 16-deep k-step: 6 MFMAs per 32x32 block (smallest terms first), one split chunk behind every MFMA,
             // the next block's fragment reads behind the last three MFMAs, sched_barrier fences pin the order.
+            bf16x8 fa[3][TM == 2 ? 2 : 1], fb[3][TN == 2 ? 2 : 1];  // 2x2 wave tiles: all fragments of a k-step
+            bf16x8 fs[3], fl[2][3];                                  // 1x5 / 5x1 wave tiles: short side, streamed long side
             auto kstep_il = [&](int ks) {
                 const bool first_is_a = (ks == 0) == A_FIRST;  // which operand this k-step splits
                 X3Stage st_;
@@ -1058,6 +1075,33 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
                 using I3 = std::integral_constant<int, 3>;
                 using I4 = std::integral_constant<int, 4>;
                 using I5 = std::integral_constant<int, 5>;
+#define X3_GROUP_FS(C, A2, A1, A0, B0, B1, B2, U, RD, FS)                  \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B0, C, 0, 0, 0);       \
+    chunk(U, I0{});                                                        \
+    FS(0);                                                                 \
+    X3_SB();                                                               \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, C, 0, 0, 0);       \
+    chunk(U, I1{});                                                        \
+    X3_SB();                                                               \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B2, C, 0, 0, 0);       \
+    chunk(U, I2{});                                                        \
+    FS(2);                                                                 \
+    X3_SB();                                                               \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, C, 0, 0, 0);       \
+    chunk(U, I3{});                                                        \
+    RD(0);                                                                 \
+    FS(3);                                                                 \
+    X3_SB();                                                               \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B1, C, 0, 0, 0);       \
+    chunk(U, I4{});                                                        \
+    RD(1);                                                                 \
+    FS(4);                                                                 \
+    X3_SB();                                                               \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, C, 0, 0, 0);       \
+    chunk(U, I5{});                                                        \
+    RD(2);                                                                 \
+    FS(5);                                                                 \
+    X3_SB();
 #define X3_GROUP(C, A2, A1, A0, B0, B1, B2, U, RD)                        \
     C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B0, C, 0, 0, 0);       \
     chunk(U, I0{});                                                        \
@@ -1081,21 +1125,26 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
     RD(2);                                                                 \
     X3_SB();
                 if constexpr (TM == 2 && TN == 2) {
-                    bf16x8 fa[3][TM], fb[3][TN];
-                    // first the fragments of block (0,0), in the order its MFMAs consume them
+                    // k-step 0 reads the fragments of block (0,0) up front; k-step 1 finds them prefetched (behind the
+                    // MFMAs of k-step 0's last two blocks, into the registers those blocks no longer need)
+                    if (ks == 0) {
 #pragma unroll
-                    for (int p = 2; p >= 0; --p) frag1(fa[p][0], As, PA, wm * WTM + l31, ks, p);
+                        for (int p = 2; p >= 0; --p) frag1(fa[p][0], As, PA, wm * WTM + l31, 0, p);
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) frag1(fb[p][0], Bs, PB, wn * WTN + l31, ks, p);
+                        for (int p = 0; p < 3; ++p) frag1(fb[p][0], Bs, PB, wn * WTN + l31, 0, p);
+                    }
                     X3_SB();
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         const int i = gq >> 1, n = gq & 1;
                         fetch(gq);
-                        // reads behind this block's last three MFMAs: block 0 -> b[.][1], block 1 -> a[.][1]
+                        // reads behind this block's last three MFMAs: block 0 -> b[.][1], block 1 -> a[.][1];
+                        // in k-step 0, blocks 2 and 3 -> a[.][0] and b[.][0] of k-step 1
                         auto rd = [&](int slot) {
                             if (gq == 0) frag1(fb[slot][1], Bs, PB, wn * WTN + 32 + l31, ks, slot);
                             if (gq == 1) frag1(fa[2 - slot][1], As, PA, wm * WTM + 32 + l31, ks, 2 - slot);
+                            if (ks == 0 && gq == 2) frag1(fa[2 - slot][0], As, PA, wm * WTM + l31, 1, 2 - slot);
+                            if (ks == 0 && gq == 3) frag1(fb[slot][0], Bs, PB, wn * WTN + l31, 1, slot);
                         };
                         f32x16 c = acc[i][n];
                         X3_GROUP(c, fa[2][i], fa[1][i], fa[0][i], fb[0][n], fb[1][n], fb[2][n], gq, rd)
@@ -1105,44 +1154,87 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
                     constexpr bool STREAM_B = TM == 1;
                     static_assert(TM == 1 || TN == 1, "streamed fragments: one side has a single 32-row block");
                     constexpr int NL = STREAM_B ? TN : TM;
-                    bf16x8 fs[3], fl[2][3];  // short side (kept), long side (double-buffered)
-                    if (STREAM_B) {
+                    // short side fs (kept over the k-step), long side fl (double-buffered, one block ahead).  k-step 0
+                    // reads fs and the first long-side block up front; its last block prefetches both for k-step 1:
+                    // the long-side block into the fl buffer that block does not use, fs IN PLACE -- a plane of fs is
+                    // re-read as soon as the last MFMA that consumes it has been issued.
+                    const int par = ks == 0 ? 0 : (NL & 1);  // fl buffer of this k-step's first block
+                    if (ks == 0) {
+                        if (STREAM_B) {
 #pragma unroll
-                        for (int p = 2; p >= 0; --p) frag1(fs[p], As, PA, wm * WTM + l31, ks, p);
+                            for (int p = 2; p >= 0; --p) frag1(fs[p], As, PA, wm * WTM + l31, 0, p);
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) frag1(fl[0][p], Bs, PB, wn * WTN + l31, ks, p);
-                    } else {
+                            for (int p = 0; p < 3; ++p) frag1(fl[0][p], Bs, PB, wn * WTN + l31, 0, p);
+                        } else {
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) frag1(fs[p], Bs, PB, wn * WTN + l31, ks, p);
+                            for (int p = 0; p < 3; ++p) frag1(fs[p], Bs, PB, wn * WTN + l31, 0, p);
 #pragma unroll
-                        for (int p = 2; p >= 0; --p) frag1(fl[0][p], As, PA, wm * WTM + l31, ks, p);
+                            for (int p = 2; p >= 0; --p) frag1(fl[0][p], As, PA, wm * WTM + l31, 0, p);
+                        }
                     }
                     X3_SB();
 #pragma unroll
                     for (int j = 0; j < NL; ++j) {
                         fetch(j);
+                        const int cur = (j + par) & 1;
+                        const bool last0 = ks == 0 && j == NL - 1;  // the block that prefetches for k-step 1
                         auto rd = [&](int slot) {  // the next block's planes in the order its MFMAs consume them
                             if (j + 1 < NL) {
                                 if (STREAM_B)
-                                    frag1(fl[(j + 1) & 1][slot], Bs, PB, wn * WTN + (j + 1) * 32 + l31, ks, slot);
+                                    frag1(fl[cur ^ 1][slot], Bs, PB, wn * WTN + (j + 1) * 32 + l31, ks, slot);
                                 else
-                                    frag1(fl[(j + 1) & 1][2 - slot], As, PA, wm * WTM + (j + 1) * 32 + l31, ks, 2 - slot);
+                                    frag1(fl[cur ^ 1][2 - slot], As, PA, wm * WTM + (j + 1) * 32 + l31, ks, 2 - slot);
+                            } else if (last0) {
+                                if (STREAM_B)
+                                    frag1(fl[cur ^ 1][slot], Bs, PB, wn * WTN + l31, 1, slot);
+                                else
+                                    frag1(fl[cur ^ 1][2 - slot], As, PA, wm * WTM + l31, 1, 2 - slot);
+                            }
+                        };
+                        // in-place prefetch of fs for k-step 1, behind the last MFMA that reads each plane:
+                        // STREAM_B (fs = a): a2 after MFMA 0, a1 after MFMA 3, a0 after MFMA 5
+                        // else     (fs = b): b2 after MFMA 2, b1 after MFMA 4, b0 after MFMA 5
+                        auto fsrd = [&](int m) {
+                            if (!last0) return;
+                            if (STREAM_B) {
+                                if (m == 0) frag1(fs[2], As, PA, wm * WTM + l31, 1, 2);
+                                if (m == 3) frag1(fs[1], As, PA, wm * WTM + l31, 1, 1);
+                                if (m == 5) frag1(fs[0], As, PA, wm * WTM + l31, 1, 0);
+                            } else {
+                                if (m == 2) frag1(fs[2], Bs, PB, wn * WTN + l31, 1, 2);
+                                if (m == 4) frag1(fs[1], Bs, PB, wn * WTN + l31, 1, 1);
+                                if (m == 5) frag1(fs[0], Bs, PB, wn * WTN + l31, 1, 0);
                             }
                         };
                         if (STREAM_B) {
                             f32x16 c = acc[0][j < TN ? j : 0];
-                            X3_GROUP(c, fs[2], fs[1], fs[0], fl[j & 1][0], fl[j & 1][1], fl[j & 1][2], j, rd)
+                            X3_GROUP_FS(c, fs[2], fs[1], fs[0], fl[cur][0], fl[cur][1], fl[cur][2], j, rd, fsrd)
                             acc[0][j < TN ? j : 0] = c;
                         } else {
                             f32x16 c = acc[j < TM ? j : 0][0];
-                            X3_GROUP(c, fl[j & 1][2], fl[j & 1][1], fl[j & 1][0], fs[0], fs[1], fs[2], j, rd)
+                            X3_GROUP_FS(c, fl[cur][2], fl[cur][1], fl[cur][0], fs[0], fs[1], fs[2], j, rd, fsrd)
                             acc[j < TM ? j : 0][0] = c;
                         }
                     }
                 }
 #undef X3_GROUP
+#undef X3_GROUP_FS
             };
+#if MMVAE_X3_PRIO_TOGGLE
+            // slot of this wave in its SIMD's wave buffer (HW_REG_HW_ID bits 3:0): the two co-resident waves of a SIMD
+            // (one per workgroup) sit in different slots
+            const int wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+#endif
             for (int kt = 0; kt < nkt; ++kt) {
+#if MMVAE_X3_PRIO_TOGGLE
+                // the two workgroups of a CU share each SIMD's issue and matrix pipe; at equal priority the older wave
+                // wins every arbitration and the younger workgroup runs ~35 % longer (the kernel ends with it).  Alternating
+                // the priority per k-tile, in opposite phase for the two wave slots, time-shares the SIMD between them.
+                if ((kt ^ wave_slot) & 1)
+                    __builtin_amdgcn_s_setprio(1);
+                else
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                 X3_STAMP(0)
                 kstep_il(0);
                 X3_STAMP(1)
