@@ -336,6 +336,10 @@ class ConditionalLayers(nn.Module):
                 f"Could not intialize the conditional layers either due to the directory not existing yet\n{directory}")
         without_species = [c for c in conditionals if c != "species"]
         paths = collect_species_files(directory, without_species)
+        if "species" in conditionals:
+            # the reference removes "species" from the caller's list and appends it again (components.py:509-511): the
+            # list that "parallel" / unordered selection shuffles -- and that fixes the concatenation order -- has it last
+            conditionals = without_species + ["species"]
         self.shared_conditionals = list(paths["shared"].keys())
         self.is_parallel = bool(selection_order) and selection_order[0] == "parallel"
         self.shuffle_selection_order = False

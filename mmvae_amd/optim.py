@@ -58,14 +58,19 @@ class ParamArena:
     def grad_view(self, i: int) -> torch.Tensor:
         return self.view(self.grad, i)
 
-    def gather_grads(self) -> None:
-        """Bring autograd-produced .grad tensors into the gradient arena (D2D copies; no-ops for arena views)."""
+    def gather_grads(self) -> List[int]:
+        """Bring autograd-produced .grad tensors into the gradient arena (D2D copies; no-ops for arena views).
+        Returns the indices of the parameters WITHOUT a gradient (their arena slice is zeroed, so the global norm is
+        right, and the optimiser skips them like torch.optim.Adam skips `p.grad is None`)."""
+        inactive = []
         for i, p in enumerate(self.params):
             gv = self.grad_view(i)
             if p.grad is None:
                 gv.zero_()
+                inactive.append(i)
             elif p.grad.data_ptr() != gv.data_ptr():
                 gv.copy_(p.grad)
+        return inactive
 
 
 class HipAdam(torch.optim.Optimizer):
@@ -86,6 +91,11 @@ class HipAdam(torch.optim.Optimizer):
             raise RuntimeError("HipAdam needs device parameters (or caller-enabled backend.cpu_plumbing())")
         dev = self.arena.device
         self.state_dev = torch.zeros(8, dtype=torch.float32, device=dev)  # step, norm, clip, bc1, bc2
+        # torch.optim.Adam counts steps per parameter and skips parameters without a gradient (conditional layers:
+        # the conditions absent from a batch).  While every parameter has taken part in every step the counts are all
+        # equal to state_dev[0] and live on the device only; the first partial step materialises them here.
+        self._steps: Optional[List[int]] = None
+        self._inactive: List[int] = []
         if self._hip:
             self.partials = torch.empty(max(ops.sqnorm_partials(self.arena.numel), 1), dtype=torch.float32, device=dev)
 
@@ -102,7 +112,7 @@ class HipAdam(torch.optim.Optimizer):
     def compute_grad_norm(self) -> torch.Tensor:
         """Gather grads into the arena and compute their global L2 norm (device scalar).  step() reuses it."""
         a = self.arena
-        a.gather_grads()
+        self._inactive = a.gather_grads()
         self._allreduce()
         if self._hip:
             b1, b2 = self.param_groups[0]["betas"]
@@ -132,16 +142,80 @@ class HipAdam(torch.optim.Optimizer):
         a = self.arena
         reuse = getattr(self, "_norm_valid", False)
         if not reuse:
-            a.gather_grads()
+            self._inactive = a.gather_grads()
             self._allreduce()
         g = self.param_groups[0]
         b1, b2 = g["betas"]
-        if self._hip:
+        if self._inactive or self._steps is not None:
+            self._step_partial(g, b1, b2, reuse)
+        elif self._hip:
             ops.clip_adam_step(a.data, a.grad, a.exp_avg, a.exp_avg_sq, self.state_dev, self.partials, lr=g["lr"],
                                beta1=b1, beta2=b2, eps=g["eps"], weight_decay=g["weight_decay"],
                                max_norm=self.max_grad_norm or 0.0, grad_scale=self.grad_scale, do_norm=not reuse)
         else:
             self._step_cpu_plumbing(g, b1, b2)
+        self._norm_valid = False
+
+    def _step_partial(self, g, b1, b2, norm_valid: bool):
+        """A step in which some parameters have no gradient, or after such a step: torch.optim.Adam semantics --
+        parameters without a gradient are left untouched (no moment decay, no weight decay) and every parameter uses
+        the bias corrections of its OWN step count.  The global norm / clip coefficient come from the whole arena (the
+        skipped slices are zero); the update is applied per parameter tensor (one launch each: this is the correctness
+        path of conditional-layer models, not a fast path)."""
+        import numpy as np
+
+        a = self.arena
+        n = len(a.params)
+        if self._steps is None:
+            self._steps = [int(round(float(self.state_dev[0])))] * n
+        skip = set(self._inactive)
+        if self._hip:
+            # norm (unless compute_grad_norm() just produced it) and the clip coefficient for the CURRENT max_grad_norm
+            # (Lightning sets the clip value between the norm logging and the step)
+            ops.clip_adam_step(a.data, a.grad, a.exp_avg, a.exp_avg_sq, self.state_dev, self.partials, beta1=b1,
+                               beta2=b2, max_norm=self.max_grad_norm or 0.0, grad_scale=self.grad_scale,
+                               do_norm=not norm_valid, do_step=False)
+            norm, clip = self.state_dev[1], self.state_dev[2]
+        else:
+            grad = a.grad * self.grad_scale
+            norm = grad.norm()
+            clip = 1.0
+            if self.max_grad_norm:
+                clip = min(1.0, float(self.max_grad_norm) / (float(norm) + 1e-6))
+            self.state_dev[1], self.state_dev[2] = norm, clip
+        groups: Dict[int, List[int]] = {}
+        for i in range(n):
+            if i not in skip:
+                groups.setdefault(self._steps[i] + 1, []).append(i)
+        lib = None
+        if self._hip:
+            from . import _lib
+
+            lib = _lib.load()
+            st = torch.empty_like(self.state_dev)
+            stream = torch.cuda.current_stream().cuda_stream
+        for t, idxs in groups.items():
+            bc1 = float(np.float32(1.0) - np.float32(b1) ** np.float32(t))
+            bc2 = float(np.float32(1.0) - np.float32(b2) ** np.float32(t))
+            if self._hip:
+                st.copy_(self.state_dev)
+                st[0], st[3], st[4] = float(t), bc1, bc2
+            for i in idxs:
+                p, off = a.params[i], a.offsets[i]
+                sl = slice(off, off + p.numel())
+                if self._hip:
+                    rc = lib.mmvae_adam_step(p.numel(), a.data[sl].data_ptr(), a.grad[sl].data_ptr(),
+                                             a.exp_avg[sl].data_ptr(), a.exp_avg_sq[sl].data_ptr(), st.data_ptr(), g["lr"],
+                                             b1, b2, g["eps"], g["weight_decay"], float(self.grad_scale), stream)
+                    _lib.check(rc, "mmvae_adam_step")
+                else:
+                    gr = a.grad[sl] * self.grad_scale * float(clip) + g["weight_decay"] * a.data[sl]
+                    a.exp_avg[sl].lerp_(gr, 1 - b1)
+                    a.exp_avg_sq[sl].mul_(b2).addcmul_(gr, gr, value=1 - b2)
+                    denom = a.exp_avg_sq[sl].sqrt() / (bc2 ** 0.5) + g["eps"]
+                    a.data[sl].addcdiv_(a.exp_avg[sl], denom, value=-g["lr"] / bc1)
+                self._steps[i] = t
+        self.state_dev[0] = float(max(self._steps))
         self._norm_valid = False
 
     def _step_cpu_plumbing(self, g, b1, b2):
@@ -164,18 +238,25 @@ class HipAdam(torch.optim.Optimizer):
     # ---- checkpoint surface compatible with torch.optim.Adam's per-parameter state
     def state_dict(self):
         a = self.arena
-        st = {i: {"step": self.state_dev[0].detach().clone().cpu(), "exp_avg": a.view(a.exp_avg, i).clone(),
+        step_of = (lambda i: torch.tensor(float(self._steps[i]))) if self._steps is not None else (
+            lambda i: self.state_dev[0].detach().clone().cpu())
+        st = {i: {"step": step_of(i), "exp_avg": a.view(a.exp_avg, i).clone(),
                   "exp_avg_sq": a.view(a.exp_avg_sq, i).clone()} for i in range(len(a.params))}
         return {"state": st, "param_groups": [{**{k: v for k, v in self.param_groups[0].items() if k != "params"},
                                                "params": list(range(len(a.params)))}]}
 
     def load_state_dict(self, sd):
         a = self.arena
+        steps = {}
         for i, s in sd["state"].items():
             i = int(i)
             a.view(a.exp_avg, i).copy_(s["exp_avg"])
             a.view(a.exp_avg_sq, i).copy_(s["exp_avg_sq"])
-            self.state_dev[0] = float(s["step"])
+            steps[i] = int(round(float(s["step"])))
+        if steps:
+            self.state_dev[0] = float(max(steps.values()))
+            uniform = len(set(steps.values())) == 1 and len(steps) == len(a.params)
+            self._steps = None if uniform else [steps.get(i, 0) for i in range(len(a.params))]
         for k, v in sd["param_groups"][0].items():
             if k != "params":
                 self.param_groups[0][k] = v

@@ -62,6 +62,31 @@ class AdvSpec:
 
 
 @dataclass
+class CondSpec:
+    """ConditionalLayers of a CLVAE (components.py:466-631, clvae.py:31-111): per key either a shared ConditionalLayer
+    (one FCBlock per condition), a per-species dict of ConditionalLayers, or -- key "species" -- one FCBlock per
+    species.  Condition names are the ModuleDict keys ('.' already replaced by '_', components.py:353-363)."""
+
+    fc: FCSpec  # conditional_config (the same for every block)
+    keys: List[str]  # `conditionals` (incl. "species"); also the order when not parallel
+    shared: Dict[str, List[str]]  # key -> condition names
+    species_specific: Dict[str, Dict[str, List[str]]]  # key -> species -> condition names
+    species_blocks: List[str]  # species that own a block under layers.species
+    parallel: bool = False  # selection_order == ["parallel"]: outputs concatenated, shuffled order
+
+    def block_prefixes(self) -> List[str]:
+        out = []
+        for key, names in self.shared.items():
+            out += [f"vae.conditionals.layers.{key}.conditions.{c}" for c in names]
+        for key, by_species in self.species_specific.items():
+            for sp, names in by_species.items():
+                out += [f"vae.conditionals.layers.{key}.{sp}.conditions.{c}" for c in names]
+        if "species" in self.keys:
+            out += [f"vae.conditionals.layers.species.{sp}" for sp in self.species_blocks]
+        return out
+
+
+@dataclass
 class ModelSpec:
     experts: Dict[str, Tuple[FCSpec, FCSpec]]  # id -> (encoder, decoder)   components.py:812-876
     vae_encoder: FCSpec  # vae.encoder.fc         components.py:726
@@ -70,6 +95,7 @@ class ModelSpec:
     var_eps: float = 1e-4  # components.py:704
     hidden_z: bool = False  # components.py:803-804
     adversarials: List[AdvSpec] = field(default_factory=list)
+    conditionals: Optional[CondSpec] = None  # clvae.py:42-49
 
 
 @dataclass
@@ -121,6 +147,9 @@ def group_param_names(spec: ModelSpec) -> Dict[str, List[Tuple[str, Tuple[int, .
         ]
         + fc_param_names("vae.decoder", spec.vae_decoder)
     )
+    if spec.conditionals is not None:  # registered after super().__init__ (clvae.py:87): last in the vae group
+        for prefix in spec.conditionals.block_prefixes():
+            groups["vae"] += fc_param_names(prefix, spec.conditionals.fc)
     for i, adv in enumerate(spec.adversarials):
         names = fc_param_names(f"adversarials.{i}.encoder", adv.encoder)
         for cond, ncls in adv.heads.items():
@@ -210,9 +239,45 @@ def fcblock_forward(sd, prefix: str, spec: FCSpec, x, training: bool, masks: Opt
     return x, hidden
 
 
-def model_forward(spec: ModelSpec, sd, x, expert_id: str, eps, training: bool, masks, hp: HParams, bn_updates=None):
+def conditional_layer(spec: CondSpec, sd, prefix: str, z, names: List[str], training: bool, hp: HParams):
+    """ConditionalLayer.forward (components.py:365-413): every row goes through the FCBlock of its own condition."""
+    out = torch.empty(z.shape[0], spec.fc.layers[-1], dtype=z.dtype)
+    rows_of: Dict[str, List[int]] = {}
+    for r, n in enumerate(names):
+        rows_of.setdefault(n, []).append(r)
+    parts = []
+    for n, rows in rows_of.items():
+        idx = torch.tensor(rows)
+        y, _ = fcblock_forward(sd, f"{prefix}.conditions.{n}", spec.fc, z.index_select(0, idx), training, None, hp)
+        parts.append((idx, y))
+    for idx, y in parts:
+        out = out.index_copy(0, idx, y)
+    return out
+
+
+def conditional_layers(spec: CondSpec, sd, z, cond: Dict[str, List[str]], species: str, order: List[str],
+                       training: bool, hp: HParams):
+    """ConditionalLayers.forward (components.py:586-631) for a given selection order."""
+    outs = []
+    for key in order:
+        if key == "species":
+            y, _ = fcblock_forward(sd, f"vae.conditionals.layers.species.{species}", spec.fc, z, training, None, hp)
+        elif key in spec.shared:
+            y = conditional_layer(spec, sd, f"vae.conditionals.layers.{key}", z, cond[key], training, hp)
+        else:
+            y = conditional_layer(spec, sd, f"vae.conditionals.layers.{key}.{species}", z, cond[key], training, hp)
+        if spec.parallel:
+            outs.append(y)
+        else:
+            z = y
+    return torch.cat(outs, dim=1) if outs else z
+
+
+def model_forward(spec: ModelSpec, sd, x, expert_id: str, eps, training: bool, masks, hp: HParams, bn_updates=None,
+                  cond: Optional[Dict[str, List[str]]] = None, cond_order: Optional[List[str]] = None):
     """CMMVAE.forward (modules/cmmvae.py:85-113) with BaseVAE.forward (modules/vae.py:98-102) and Encoder.forward
-    (components.py:783-809).  eps: [B,Z] (K = 1, the reference) or [K,B,Z] (extension)."""
+    (components.py:783-809).  eps: [B,Z] (K = 1, the reference) or [K,B,Z] (extension).  cond / cond_order: per-row
+    condition names per key and the selection order of this forward (models with conditional layers)."""
     enc, dec = spec.experts[expert_id]
     shared, _ = fcblock_forward(sd, f"experts.{expert_id}.encoder", enc, x, training, masks, hp, bn_updates)
     q, hidden = fcblock_forward(sd, "vae.encoder.fc", spec.vae_encoder, shared, training, masks, hp, bn_updates)
@@ -222,6 +287,10 @@ def model_forward(spec: ModelSpec, sd, x, expert_id: str, eps, training: bool, m
     z = mu + std * eps  # :801 rsample == loc + eps * scale ; broadcasts over K
     if spec.hidden_z:  # :803-804 (K = 1 sample)
         hidden = hidden + [z if z.dim() == 2 else z[0]]
+    if spec.conditionals is not None:  # vae.py:100 after_reparameterize -> clvae.py:107-111; the returned z is its output
+        assert z.dim() == 2 and cond is not None, "conditional layers: K = 1 and per-row conditions required"
+        z = conditional_layers(spec.conditionals, sd, z, cond, expert_id, cond_order or spec.conditionals.keys,
+                               training, hp)
     zk = z.reshape(-1, z.shape[-1])
     sh, _ = fcblock_forward(sd, "vae.decoder", spec.vae_decoder, zk, training, masks, hp, bn_updates)
     xhat, _ = fcblock_forward(sd, f"experts.{expert_id}.decoder", dec, sh, training, masks, hp, bn_updates)
@@ -281,18 +350,21 @@ def grad_norm(grads: List[torch.Tensor]) -> torch.Tensor:
 def clip_and_adam(names, sd, grads, opt_state, group: str, clip: Optional[float], hp: HParams):
     """clip_grad_norm_(params, clip) (Lightning clip_gradients "norm", cmmvae_model.py:126-129,203-209) followed by
     torch.optim.Adam.step (single-tensor formulas, amsgrad=False, coupled weight decay)."""
+    # parameters without a gradient (conditions absent from the batch) are skipped by clip_grad_norm_ and by
+    # torch.optim.Adam alike, and every parameter counts its own steps (state["step"] is per parameter)
+    names = [n for n in names if grads.get(n) is not None]
     gl = [grads[n] / hp.world_size for n in names]
     norm = grad_norm(gl)
     coef = 1.0
     if clip is not None:
         coef = min(1.0, float(clip) / (float(norm) + 1e-6))
-    st = opt_state.setdefault(group, {"step": 0, "exp_avg": {}, "exp_avg_sq": {}})
-    st["step"] += 1
-    t = st["step"]
-    bc1 = 1 - hp.beta1**t
-    bc2 = 1 - hp.beta2**t
+    st = opt_state.setdefault(group, {"steps": {}, "exp_avg": {}, "exp_avg_sq": {}})
     new = {}
     for n, g in zip(names, gl):
+        t = st["steps"].get(n, 0) + 1
+        st["steps"][n] = t
+        bc1 = 1 - hp.beta1**t
+        bc2 = 1 - hp.beta2**t
         p = sd[n]
         g = g * coef + hp.weight_decay * p
         m = st["exp_avg"].get(n, torch.zeros_like(p))
@@ -308,7 +380,7 @@ def clip_and_adam(names, sd, grads, opt_state, group: str, clip: Optional[float]
 # ------------------------------------------------------------------------------------------------------ the step
 def train_step(spec: ModelSpec, sd: Dict[str, torch.Tensor], opt_state: dict, x: torch.Tensor, expert_id: str,
                eps: torch.Tensor, masks: Optional[dict], labels: Optional[Dict[str, torch.Tensor]], kl_weight: float,
-               hp: HParams):
+               hp: HParams, cond: Optional[Dict[str, List[str]]] = None, cond_order: Optional[List[str]] = None):
     """CMMVAEModel.training_step (models/cmmvae_model.py:138-217).  Returns (outputs, new_sd); opt_state is updated
     in place.  Order: forward, elbo, [D phase: backward/clip/Adam per adversary], [G phase with updated adversaries],
     backward of loss + adv_weight * sum(adv), clip vae, clip expert, Adam vae, Adam expert."""
@@ -316,7 +388,7 @@ def train_step(spec: ModelSpec, sd: Dict[str, torch.Tensor], opt_state: dict, x:
     live = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
     bn_updates: dict = {}
     K = eps.shape[0] if eps.dim() == 3 else 1
-    fwd = model_forward(spec, live, x, expert_id, eps, True, masks, hp, bn_updates)
+    fwd = model_forward(spec, live, x, expert_id, eps, True, masks, hp, bn_updates, cond, cond_order)
     e = elbo(fwd["mu"], fwd["std"], x, fwd["xhat"], kl_weight, K)
     out = {
         "loss": e["loss"].detach(), "recon_loss": e["recon_loss"].detach(), "kl_loss": e["kl_loss"].detach(),
@@ -351,11 +423,11 @@ def train_step(spec: ModelSpec, sd: Dict[str, torch.Tensor], opt_state: dict, x:
     adv_names = [n for i in range(len(spec.adversarials)) for n, _ in groups[f"adversarial_{i + 1}"]]
     all_names = vae_names + exp_names + adv_names
     gl = torch.autograd.grad(total, [live[n] for n in all_names], allow_unused=True)
-    grads = {n: (g if g is not None else torch.zeros_like(live[n])) for n, g in zip(all_names, gl)}
-    out["grads"] = {n: grads[n].detach() for n in vae_names + exp_names}
+    grads = dict(zip(all_names, gl))  # None: the parameter did not take part in this step (an absent condition)
+    out["grads"] = {n: grads[n].detach() for n in vae_names + exp_names if grads[n] is not None}
     for i in range(len(spec.adversarials)):  # logged only (cmmvae_model.py:196-200)
         names = [n for n, _ in groups[f"adversarial_{i + 1}"]]
-        out["grad_norms"][f"generator_{i + 1}"] = grad_norm([grads[n] for n in names])
+        out["grad_norms"][f"generator_{i + 1}"] = grad_norm([grads[n] for n in names if grads[n] is not None])
     upd_v, norm_v = clip_and_adam(vae_names, sd, grads, opt_state, "vae", hp.vae_clip, hp)
     upd_e, norm_e = clip_and_adam(exp_names, sd, grads, opt_state, f"expert_{expert_id}", hp.expert_clip, hp)
     out["grad_norms"]["vae"] = norm_v
@@ -366,10 +438,10 @@ def train_step(spec: ModelSpec, sd: Dict[str, torch.Tensor], opt_state: dict, x:
     return out, new_sd
 
 
-def eval_step(spec: ModelSpec, sd, x, expert_id: str, eps, kl_weight: float, hp: HParams):
+def eval_step(spec: ModelSpec, sd, x, expert_id: str, eps, kl_weight: float, hp: HParams, cond=None, cond_order=None):
     """CMMVAEModel.validation_step (models/cmmvae_model.py:219-248): eval-mode forward + elbo."""
     with torch.no_grad():
-        fwd = model_forward(spec, sd, x, expert_id, eps, False, None, hp)
+        fwd = model_forward(spec, sd, x, expert_id, eps, False, None, hp, None, cond, cond_order)
         e = elbo(fwd["mu"], fwd["std"], x, fwd["xhat"], kl_weight, 1)
     return {**e, "z": fwd["z"], "xhat": fwd["xhat"], "mu": fwd["mu"]}
 

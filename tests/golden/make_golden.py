@@ -16,6 +16,7 @@ Randomness is made explicit so any implementation can replay it:
 """
 import json
 import os
+import random
 import sys
 import tempfile
 import warnings
@@ -48,6 +49,43 @@ def fc_cfg(base, layers, dropout=0.0, bn=False, relu=True, return_hidden=False):
     )
 
 
+def condition_value(key, species, i):
+    """Raw metadata value of condition i of `key` (dots on purpose: ConditionalLayer replaces them, components.py:353-363)."""
+    return f"{key}.{species}.{i}" if species else f"{key}.{i}"
+
+
+def write_condition_files(case, tmpdir):
+    """unique_expression_{key}.csv under shared/ and {species}/ (components.py:420-464)."""
+    root = os.path.join(tmpdir, "conditionals")
+    cond = case["cond"]
+    os.makedirs(os.path.join(root, "shared"), exist_ok=True)
+    for key, n in cond["shared"].items():
+        pd.Series([condition_value(key, None, i) for i in range(n)]).to_csv(
+            os.path.join(root, "shared", f"unique_expression_{key}.csv"), header=False, index=False)
+    for key, by_species in cond["species_specific"].items():
+        for species, n in by_species.items():
+            os.makedirs(os.path.join(root, species), exist_ok=True)
+            pd.Series([condition_value(key, species, i) for i in range(n)]).to_csv(
+                os.path.join(root, species, f"unique_expression_{key}.csv"), header=False, index=False)
+    return root
+
+
+def conditional_kwargs(base, case, tmpdir):
+    cond = case["cond"]
+    root = write_condition_files(case, tmpdir)
+    Z = case["Z"]
+    kw = dict(
+        conditional_config=base.FCBlockConfig(layers=[Z], dropout_rate=0.0, use_batch_norm=False,
+                                              use_layer_norm=cond["layer_norm"], activation_fn=None),
+        conditionals_directory=root, conditionals=list(cond["keys"]),
+        selection_order=["parallel"] if cond["parallel"] else list(cond["keys"]),
+    )
+    if cond["parallel"]:
+        kw["concat_config"] = base.ConcatBlockConfig(dropout_rate=0.0, use_batch_norm=False, use_layer_norm=False,
+                                                     activation_fn=nn.ReLU)
+    return kw
+
+
 def build_reference(case, tmpdir):
     from cmmvae.modules import CMMVAE, CLVAE, base
     from cmmvae.modules.base.init import he_init_weights
@@ -59,13 +97,16 @@ def build_reference(case, tmpdir):
         dec = case["expert_hidden"][::-1] + [G]
         experts.append(base.Expert(eid, fc_cfg(base, enc, dropout=case["dropout"], bn=True),
                                    fc_cfg(base, dec)))
+    cond_kwargs = {}
+    if case.get("cond"):
+        cond_kwargs = conditional_kwargs(base, case, tmpdir)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         vae = CLVAE(
             latent_dim=case["Z"],
             encoder_config=fc_cfg(base, [case["expert_hidden"][-1]] + case["vae_hidden"], bn=True, return_hidden=True),
             decoder_config=fc_cfg(base, [case["Z"]] + case["vae_hidden"][::-1] + [case["expert_hidden"][-1]]),
-            hidden_z=case["hidden_z"],
+            hidden_z=case["hidden_z"], **cond_kwargs,
         )
     advs = None
     if case.get("adversarials"):
@@ -145,6 +186,18 @@ def run_case(case):
                         idx = torch.randint(0, n, (B,), generator=g)
                         meta[cond] = [f"{cond}_{int(i)}" for i in idx]
                         out[f"step{t}/in/labels/{cond}"] = idx.numpy().astype(np.int64)
+                if case.get("cond"):
+                    cond = case["cond"]
+                    for key, n in cond["shared"].items():
+                        idx = torch.randint(0, n, (B,), generator=g)
+                        meta[key] = [condition_value(key, None, int(i)) for i in idx]
+                        out[f"step{t}/in/cond/{key}"] = idx.numpy().astype(np.int64)
+                    for key, by_species in cond["species_specific"].items():
+                        idx = torch.randint(0, by_species[eid], (B,), generator=g)
+                        meta[key] = [condition_value(key, eid, int(i)) for i in idx]
+                        out[f"step{t}/in/cond/{key}"] = idx.numpy().astype(np.int64)
+                    # "parallel" / unordered selection shuffles with Python's random (components.py:601-603)
+                    random.seed(case["seed"] * 100 + t)
                 metadata = pd.DataFrame(meta if meta else {"dummy": [0] * B})
                 for name, ed in drops.items():
                     if name.startswith(f"experts.{eid}."):
@@ -206,7 +259,8 @@ def run_case(case):
                     for i, adv in enumerate(module.adversarials, start=1):
                         res[f"grad_norms/generator_{i}"] = total_norm(list(adv.parameters()))
                 for n_, p in list(module.vae.named_parameters()):
-                    out[f"step{t}/grad/vae.{n_}"] = p.grad.numpy().copy()
+                    if p.grad is not None:  # parameters of conditions absent from the batch have no gradient
+                        out[f"step{t}/grad/vae.{n_}"] = p.grad.numpy().copy()
                 for n_, p in list(module.experts[eid].named_parameters()):
                     out[f"step{t}/grad/experts.{eid}.{n_}"] = p.grad.numpy().copy()
                 torch.nn.utils.clip_grad_norm_(list(module.vae.parameters()), 10.0)  # :203-204
@@ -220,6 +274,8 @@ def run_case(case):
 
             # ---- validation_step (cmmvae_model.py:219-248): eval-mode forward + elbo on the last batch
             module.eval()
+            if case.get("cond"):
+                random.seed(case["seed"] * 100 + 99)
             with torch.no_grad():
                 qz, pz, z, xhats, hidden = module(x, metadata, eid)
                 ld = module.vae.elbo(qz, pz, x, xhats[eid], 1.0)
@@ -231,6 +287,8 @@ def run_case(case):
             out["eval/out/mu"] = qz.loc.numpy().copy()
             # ---- cross-generation (cmmvae.py:95-107; runners/cross_generation.py:87-152): decode the shared latent
             #      through every expert; and the predict path, get_latent_embeddings (cmmvae.py:115-142)
+            if case.get("cond"):
+                random.seed(case["seed"] * 100 + 99)
             with torch.no_grad():
                 _, _, _, xh_all, _ = module(x, metadata, eid, cross_generate=True)
                 emb = module.get_latent_embeddings(x, metadata, eid)
@@ -271,6 +329,19 @@ CASES = {
                         dropout=0.1, hidden_z=True, schedule=["human", "mouse"], kl_weights=[1.0, 1.0],
                         adversarials=[[24, 16, 8], [12, 8]], conditions={"assay": 5, "sex": 2, "donor_id": 37},
                         adv_weight=25),
+    # conditional layers after the reparameterisation: shared and species-specific ConditionalLayers plus
+    # the per-species block, applied in a fixed order / concatenated in shuffled order ("parallel"); some conditions
+    # are absent from a batch, so their parameters have no gradient and torch's Adam skips them (own step counts)
+    "cond_seq": dict(seed=41, experts={"human": 48, "mouse": 40}, expert_hidden=[32, 16], vae_hidden=[12], Z=8, B=12,
+                     dropout=0.1, hidden_z=False, schedule=["human", "mouse", "human"], kl_weights=[1.0, 1.0, 1.0],
+                     cond=dict(keys=["assay", "donor_id", "species", "sex"], shared={"assay": 4, "sex": 2},
+                               species_specific={"donor_id": {"human": 5, "mouse": 3}}, layer_norm=True,
+                               parallel=False)),
+    "cond_par": dict(seed=43, experts={"human": 48, "mouse": 40}, expert_hidden=[32, 16], vae_hidden=[12], Z=8, B=12,
+                     dropout=0.1, hidden_z=True, schedule=["human", "mouse", "human"], kl_weights=[1.0, 0.5, 1.0],
+                     cond=dict(keys=["assay", "donor_id", "species", "sex"], shared={"assay": 4, "sex": 2},
+                               species_specific={"donor_id": {"human": 5, "mouse": 3}}, layer_norm=True,
+                               parallel=True)),
 }
 
 

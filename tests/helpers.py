@@ -9,6 +9,7 @@ from oracle import mmvae_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["c1_small", "two_mod_odd", "adversarial"]
+COND_CASES = ["cond_seq", "cond_par"]  # conditional layers after the reparameterisation
 
 
 def load_case(name):
@@ -27,14 +28,65 @@ def spec_from_case(case) -> O.ModelSpec:
     advs = []
     for enc_layers in case.get("adversarials", []) or []:
         advs.append(O.AdvSpec(O.FCSpec.make(enc_layers, relu=True), dict(case["conditions"])))
+    conds = None
+    dec_layers = [Z] + vh[::-1] + [eh[-1]]
+    if case.get("cond"):
+        c = case["cond"]
+        species = list(case["experts"].keys())
+        conds = O.CondSpec(
+            fc=O.FCSpec.make([Z], use_layer_norm=c["layer_norm"]),
+            keys=list(c["keys"]),
+            shared={k: [cond_name(k, None, i) for i in range(n)] for k, n in c["shared"].items()},
+            species_specific={k: {sp: [cond_name(k, sp, i) for i in range(n)] for sp, n in by.items()}
+                              for k, by in c["species_specific"].items()},
+            species_blocks=species, parallel=c["parallel"])
+        if c["parallel"]:  # clvae.py:55-79: one more decoder layer, concat_dim -> Z, described by concat_config (ReLU)
+            dec_layers = [len(c["keys"]) * Z] + dec_layers
     return O.ModelSpec(
         experts=experts,
         vae_encoder=O.FCSpec.make([eh[-1]] + vh, use_batch_norm=True, relu=True, return_hidden=True),
-        vae_decoder=O.FCSpec.make([Z] + vh[::-1] + [eh[-1]], relu=True),
+        vae_decoder=O.FCSpec.make(dec_layers, relu=True),
         latent_dim=Z,
         hidden_z=case["hidden_z"],
         adversarials=advs,
+        conditionals=conds,
     )
+
+
+def cond_value(key, species, i):
+    """Raw metadata value of condition i (as tests/golden/make_golden.py writes them: dots on purpose)."""
+    return f"{key}.{species}.{i}" if species else f"{key}.{i}"
+
+
+def cond_name(key, species, i):
+    """ModuleDict key of that condition (ConditionalLayer.format_condition_key, components.py:353-363)."""
+    return cond_value(key, species, i).replace(".", "_")
+
+
+def cond_inputs(case, z, t, eid):
+    """Per-row condition indices of step t -> (raw metadata columns, ModuleDict names per key)."""
+    raw, names = {}, {}
+    c = case["cond"]
+    for key in list(c["shared"]) + list(c["species_specific"]):
+        idx = [int(i) for i in np.array(z[f"step{t}/in/cond/{key}"])]
+        sp = None if key in c["shared"] else eid
+        raw[key] = [cond_value(key, sp, i) for i in idx]
+        names[key] = [cond_name(key, sp, i) for i in idx]
+    return raw, names
+
+
+def cond_order(case, t):
+    """Selection order of step t: the configured order, or -- "parallel" -- the shuffle Python's random produces from
+    the seed the generator used (components.py:601-603: random.sample(selection_order, len))."""
+    import random
+
+    c = case["cond"]
+    if not c["parallel"]:
+        return list(c["keys"])
+    # ConditionalLayers.__init__ removes "species" from the list and appends it again (components.py:509-511), so the
+    # list that is shuffled has it last
+    base = [k for k in c["keys"] if k != "species"] + ["species"]
+    return random.Random(case["seed"] * 100 + t).sample(base, len(base))
 
 
 def hparams_from_case(case) -> O.HParams:

@@ -24,10 +24,31 @@ def build_mirror(case, device, tmpdir, use_engine=False):
     eh, vh, Z = case["expert_hidden"], case["vae_hidden"], case["Z"]
     experts = [base.Expert(eid, cfg([G] + eh, dropout=case["dropout"], bn=True), cfg(eh[::-1] + [G]))
                for eid, G in case["experts"].items()]
+    cond_kwargs = {}
+    if case.get("cond"):
+        c = case["cond"]
+        root = os.path.join(tmpdir, "conditionals")
+        os.makedirs(os.path.join(root, "shared"), exist_ok=True)
+        for key, n in c["shared"].items():
+            pd.Series([H.cond_value(key, None, i) for i in range(n)]).to_csv(
+                os.path.join(root, "shared", f"unique_expression_{key}.csv"), header=False, index=False)
+        for key, by_species in c["species_specific"].items():
+            for species, n in by_species.items():
+                os.makedirs(os.path.join(root, species), exist_ok=True)
+                pd.Series([H.cond_value(key, species, i) for i in range(n)]).to_csv(
+                    os.path.join(root, species, f"unique_expression_{key}.csv"), header=False, index=False)
+        cond_kwargs = dict(
+            conditional_config=base.FCBlockConfig(layers=[Z], dropout_rate=0.0, use_batch_norm=False,
+                                                  use_layer_norm=c["layer_norm"], activation_fn=None),
+            conditionals_directory=root, conditionals=list(c["keys"]),
+            selection_order=["parallel"] if c["parallel"] else list(c["keys"]))
+        if c["parallel"]:
+            cond_kwargs["concat_config"] = base.ConcatBlockConfig(dropout_rate=0.0, use_batch_norm=False,
+                                                                  use_layer_norm=False, activation_fn=nn.ReLU)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         vae = CLVAE(latent_dim=Z, encoder_config=cfg([eh[-1]] + vh, bn=True, return_hidden=True),
-                    decoder_config=cfg([Z] + vh[::-1] + [eh[-1]]), hidden_z=case["hidden_z"])
+                    decoder_config=cfg([Z] + vh[::-1] + [eh[-1]]), hidden_z=case["hidden_z"], **cond_kwargs)
     advs = None
     if case.get("adversarials"):
         os.makedirs(os.path.join(tmpdir, "human"), exist_ok=True)
@@ -72,6 +93,12 @@ def replay_training(name, device, use_engine=False, check=True, prepare=None):
                 if k.startswith(f"experts.{eid}.encoder.fc_layers."):
                     enc.explicit_masks[int(k.split(".")[4])] = m.to(device)
             meta = {cond: [f"{cond}_{int(i)}" for i in idx] for cond, idx in labels.items()}
+            if case.get("cond"):
+                import random
+
+                raw, _ = H.cond_inputs(case, z, t, eid)
+                meta.update(raw)
+                random.seed(case["seed"] * 100 + t)  # the shuffle of "parallel" selection (components.py:601-603)
             metadata = pd.DataFrame(meta if meta else {"dummy": [0] * x.shape[0]})
             model.logged.clear()
             model.training_step((x.to(device), metadata, eid), t)

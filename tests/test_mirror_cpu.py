@@ -9,7 +9,7 @@ from tests import helpers as H
 from tests import mirror_utils as MU
 
 
-@pytest.mark.parametrize("name", H.CASES)
+@pytest.mark.parametrize("name", H.CASES + H.COND_CASES)
 def test_training_steps_on_cpu_plumbing_match_reference(name):
     case, z, results = MU.replay_training(name, "cpu")
     MU.check_against_golden(case, z, results)
@@ -32,7 +32,7 @@ def test_state_dict_keys_match_reference_checkpoint():
     import tempfile
     from mmvae_amd import backend
 
-    for name in H.CASES:
+    for name in H.CASES + H.COND_CASES:
         case, z = H.load_case(name)
         with tempfile.TemporaryDirectory() as d, backend.cpu_plumbing():
             model = MU.build_mirror(case, "cpu", d)

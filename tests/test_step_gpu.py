@@ -10,7 +10,7 @@ from tests import helpers as H  # noqa: E402
 from tests import mirror_utils as MU  # noqa: E402
 
 
-@pytest.mark.parametrize("name", H.CASES)
+@pytest.mark.parametrize("name", H.CASES + H.COND_CASES)
 def test_module_path_matches_reference(name):
     case, z, results = MU.replay_training(name, "cuda", use_engine=False)
     MU.check_against_golden(case, z, results)
