@@ -30,8 +30,10 @@ def parse():
     ap.add_argument("--no-engine", action="store_true", help="module (autograd) path instead of the captured engine")
     ap.add_argument("--mode", default="train", choices=["train", "validate", "predict"],
                     help="train = the headline metric; validate / predict = the forward-only programs (SURVEY 8 f3)")
-    ap.add_argument("--input", default="dense", choices=["dense", "csr"],
-                    help="csr: batches arrive as torch.sparse_csr (resident in HBM) and are densified per step (8 f1)")
+    ap.add_argument("--input", default="dense", choices=["dense", "csr", "npz"],
+                    help="csr: batches arrive as torch.sparse_csr (resident in HBM) and are densified per step (8 f1); "
+                         "npz: batches stream from npz-CSR / pkl chunk files on disk through mmvae_amd.data (8 f4: host "
+                         "feed and PCIe transfer inside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample")
     return ap.parse_args()
@@ -151,13 +153,41 @@ def main():
 
     if a.input == "csr":
         data = {eid: [(x.to_sparse_csr(), m) for x, m in v] for eid, v in data.items()}
+    feed = None
+    if a.input == "npz":  # synthetic chunks on disk -> the reference's on-disk format -> CSR batches staged to the GPU
+        import tempfile
+
+        import pandas as pd
+        import scipy.sparse as sp
+
+        from mmvae_amd import data as mdata
+        from mmvae_amd.trainer import MultiModalBatches
+
+        tmp = tempfile.mkdtemp(prefix="mmvae_bench_")
+        feeds = {}
+        for i, (eid, G) in enumerate(cfg["experts"].items()):
+            rows = torch.cat([synthetic.synthetic_counts(B, G, seed=77 + 31 * i + j, device="cpu") for j in range(8)])
+            meta = pd.concat([synthetic.synthetic_metadata(B, seed=9 + j) for j in range(8)], ignore_index=True)
+            mdata.write_chunks(os.path.join(tmp, eid), eid, sp.csr_matrix(rows.numpy()), meta, chunk_rows=4 * B)
+            feeds[eid] = mdata.SpeciesChunks(os.path.join(tmp, eid), f"{eid}_train_counts_*.npz",
+                                             f"{eid}_train_metadata_*.pkl", B, eid, seed=i, device=device,
+                                             rank=0, world=1)
+
+        def endless():
+            while True:
+                yield from MultiModalBatches(feeds, seed=0, round_robin=True)
+
+        feed = endless()
     if a.mode != "train":
         model.eval()
         model.trainer.set_stage("validation" if a.mode == "validate" else "predict")
 
     def step(i):
-        eid = eids[i % len(eids)]  # rank-synchronous round-robin schedule
-        x, meta = data[eid][(i // len(eids)) % n_res]
+        if feed is not None:
+            x, meta, eid = next(feed)
+        else:
+            eid = eids[i % len(eids)]  # rank-synchronous round-robin schedule
+            x, meta = data[eid][(i // len(eids)) % n_res]
         if a.mode == "train":
             model.training_step((x, meta, eid), i)
         elif a.mode == "validate":
@@ -201,10 +231,11 @@ def main():
             "metric": {"train": "cells/sec per MMVAE train step", "validate": "cells/sec per MMVAE validation step",
                        "predict": "cells/sec per MMVAE predict step (latent embeddings)"}[a.mode], "value": cells_per_s, "unit": "cells/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if a.input != "npz" else "synthetic, streamed from npz-CSR / pkl chunk files",
             "config": {"workload": f"{a.config}: {len(eids)}-modality MMVAE train step, {G} genes each, latent 128, "
                                    f"K={K}, batch {B}/GPU, adversarial={cfg['adversarial']}"
-                                   + (", CSR input densified per step" if a.input == "csr" else ""),
+                                   + (", CSR input densified per step" if a.input == "csr" else "")
+                                   + (", npz-CSR chunks streamed from disk" if a.input == "npz" else ""),
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "path": "module" if (a.no_engine or not model._engine) else "engine(hipGraph)"},
             "step_flops_per_cell": synthetic.flops_per_cell(G, K),

@@ -1,0 +1,87 @@
+"""the chunked npz-CSR / pickled-metadata feed against the on-disk format and batch semantics of the
+reference's local datapipes (data/local/cellxgene_datapipe.py:31-193, cellxgene_manager.py:76-88).  Host logic: CPU."""
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sp
+import torch
+
+from mmvae_amd import data as D
+from mmvae_amd.trainer import MultiModalBatches
+
+
+def _dataset(n, g, seed):
+    rng = np.random.default_rng(seed)
+    dense = rng.random((n, g), dtype=np.float32) * (rng.random((n, g)) < 0.1)
+    dense[:, 0] = np.arange(n, dtype=np.float32) + 1.0  # column 0 identifies the row
+    meta = pd.DataFrame({"row": np.arange(n), "assay": [f"a{i % 3}" for i in range(n)]})
+    return sp.csr_matrix(dense), meta
+
+
+def test_chunks_are_listed_sorted_and_paired(tmp_path):
+    m, meta = _dataset(50, 16, 0)
+    D.write_chunks(str(tmp_path), "human", m, meta, chunk_rows=20)
+    D.write_chunks(str(tmp_path), "human", m[:10], meta.iloc[:10], chunk_rows=20, split="val")
+    pairs = D.list_chunks(str(tmp_path), "human_train_counts_*.npz", "human_train_metadata_*.pkl")
+    assert [p[0].rsplit("_", 1)[1] for p in pairs] == ["1.npz", "2.npz", "3.npz"]
+    assert all(a.replace("counts", "metadata").replace(".npz", ".pkl") == b for a, b in pairs)
+    with pytest.raises(RuntimeError, match="No files found"):
+        D.list_chunks(str(tmp_path), "mouse_*.npz", "mouse_*.pkl")
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+@pytest.mark.parametrize("return_dense", [False, True])
+def test_batches_keep_rows_and_metadata_index_matched(tmp_path, shuffle, return_dense):
+    m, meta = _dataset(70, 24, 1)
+    D.write_chunks(str(tmp_path), "human", m, meta, chunk_rows=32)  # chunks of 32, 32, 6 rows
+    feed = D.SpeciesChunks(str(tmp_path), "human_train_counts_*.npz", ["human_train_metadata_*.pkl"], batch_size=8,
+                           name="human", shuffle=shuffle, return_dense=return_dense, seed=3, prefetch=True)
+    seen = []
+    for x, md, eid in feed:
+        assert eid == "human" and len(md) == 8 and list(md.index) == list(range(8))
+        if return_dense:
+            assert x.layout == torch.strided and x.shape == (8, 24)
+            dense = x
+        else:
+            assert x.layout == torch.sparse_csr and x.dtype == torch.float32
+            assert x.crow_indices().dtype == torch.int64 and x.col_indices().dtype == torch.int64
+            dense = x.to_dense()
+        rows = (dense[:, 0] - 1).long().tolist()  # column 0 carries the original row number
+        assert rows == md["row"].tolist(), "matrix rows and metadata rows must stay index-matched"
+        assert torch.equal(dense, torch.from_numpy(m[rows].toarray()))
+        seen += rows
+    # partial batches are dropped per chunk: 32 -> 4 batches, 32 -> 4, 6 -> 0
+    assert len(seen) == 64 and len(set(seen)) == 64
+    if not shuffle:
+        assert seen == list(range(32)) + list(range(32, 64))
+    else:
+        assert seen != sorted(seen)
+        again = [r for x, md, _ in D.SpeciesChunks(str(tmp_path), "human_train_counts_*.npz",
+                                                   "human_train_metadata_*.pkl", 8, "human", seed=3)
+                 for r in md["row"].tolist()]
+        assert again == seen, "same seed, same epoch -> same order"
+
+
+def test_partial_batches_and_rank_sharding(tmp_path):
+    m, meta = _dataset(45, 8, 2)
+    D.write_chunks(str(tmp_path), "mouse", m, meta, chunk_rows=45)
+    full = list(D.SpeciesChunks(str(tmp_path), "mouse_*counts*.npz", "mouse_*metadata*.pkl", 10, "mouse",
+                                allow_partials=True, shuffle=False))
+    assert [len(b[1]) for b in full] == [10, 10, 10, 10, 5]
+    shards = [list(D.SpeciesChunks(str(tmp_path), "mouse_*counts*.npz", "mouse_*metadata*.pkl", 10, "mouse", seed=5,
+                                   rank=r, world=2)) for r in range(2)]
+    assert [len(s) for s in shards] == [2, 2]
+    rows = [set(r for _, md, _ in s for r in md["row"].tolist()) for s in shards]
+    assert not (rows[0] & rows[1]) and len(rows[0] | rows[1]) == 40
+
+
+def test_multi_modal_interleave_feeds_the_trainer(tmp_path):
+    feeds = {}
+    for k, (name, g) in enumerate((("human", 12), ("mouse", 9))):
+        m, meta = _dataset(32, g, 10 + k)
+        D.write_chunks(str(tmp_path / name), name, m, meta, chunk_rows=16)
+        feeds[name] = D.SpeciesChunks(str(tmp_path / name), f"{name}_train_counts_*.npz", f"{name}_train_metadata_*.pkl",
+                                      8, name, seed=k)
+    batches = list(MultiModalBatches(feeds, seed=1))
+    assert sorted(b[2] for b in batches) == ["human"] * 4 + ["mouse"] * 4
+    assert all(b[0].shape[1] == (12 if b[2] == "human" else 9) for b in batches)
