@@ -168,7 +168,8 @@ def main():
         for i, (eid, G) in enumerate(cfg["experts"].items()):
             rows = torch.cat([synthetic.synthetic_counts(B, G, seed=77 + 31 * i + j, device="cpu") for j in range(8)])
             meta = pd.concat([synthetic.synthetic_metadata(B, seed=9 + j) for j in range(8)], ignore_index=True)
-            mdata.write_chunks(os.path.join(tmp, eid), eid, sp.csr_matrix(rows.numpy()), meta, chunk_rows=4 * B)
+            mdata.write_chunks(os.path.join(tmp, eid), eid, sp.csr_matrix(rows.numpy()), meta, chunk_rows=4 * B,
+                               compressed=False)  # stored members: the feed memory-maps them
             feeds[eid] = mdata.SpeciesChunks(os.path.join(tmp, eid), f"{eid}_train_counts_*.npz",
                                              f"{eid}_train_metadata_*.pkl", B, eid, seed=i, device=device,
                                              rank=0, world=1)

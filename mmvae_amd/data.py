@@ -49,12 +49,51 @@ def list_chunks(directory_path: str, npz_masks: Union[str, Sequence[str]],
     return pairs
 
 
+def _mapped_npz_csr(npz_path: str):
+    """Memory-mapped CSR matrix of an UNCOMPRESSED scipy npz (`save_npz(..., compressed=False)`): the .npy members of
+    a stored zip are plain byte ranges of the file, so indptr / indices / data become page-cache-backed views instead
+    of being read and copied through zipfile (0.29 s -> ~1 ms per 2048-cell chunk).  Returns None when the archive is
+    compressed or is not a CSR matrix: the caller falls back to scipy.sparse.load_npz."""
+    import struct
+    import zipfile
+
+    import scipy.sparse as sp
+
+    arrays = {}
+    with zipfile.ZipFile(npz_path) as zf, open(npz_path, "rb") as f:
+        for info in zf.infolist():
+            if info.compress_type != zipfile.ZIP_STORED:
+                return None
+            f.seek(info.header_offset)
+            hdr = f.read(30)
+            n_name, n_extra = struct.unpack("<HH", hdr[26:30])
+            start = info.header_offset + 30 + n_name + n_extra
+            f.seek(start)
+            version = np.lib.format.read_magic(f)
+            shape, fortran, dtype = (np.lib.format.read_array_header_1_0(f) if version == (1, 0)
+                                     else np.lib.format.read_array_header_2_0(f))
+            name = info.filename[:-4] if info.filename.endswith(".npy") else info.filename
+            if dtype.hasobject or fortran:
+                return None
+            if int(np.prod(shape)) * dtype.itemsize <= 4096:  # format / shape scalars: just read them
+                arrays[name] = np.fromfile(f, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+            else:
+                arrays[name] = np.memmap(npz_path, dtype=dtype, mode="r", offset=f.tell(), shape=shape)
+    fmt = arrays.get("format")
+    fmt = fmt.item() if fmt is not None else b""
+    if (fmt.decode() if isinstance(fmt, bytes) else str(fmt)) != "csr":
+        return None
+    return sp.csr_matrix((arrays["data"], arrays["indices"], arrays["indptr"]), shape=tuple(arrays["shape"]), copy=False)
+
+
 def load_chunk(npz_path: str, metadata_path: str):
     """One chunk: scipy CSR matrix + its index-matched metadata DataFrame (cellxgene_datapipe.py:60-86)."""
     import scipy.sparse as sp
 
-    with open(npz_path, "rb") as f:
-        matrix = sp.load_npz(f).tocsr()
+    matrix = _mapped_npz_csr(npz_path)
+    if matrix is None:
+        with open(npz_path, "rb") as f:
+            matrix = sp.load_npz(f).tocsr()
     with open(metadata_path, "rb") as f:
         metadata = pickle.load(f)
     if matrix.shape[0] != len(metadata):
@@ -83,6 +122,8 @@ class SpeciesChunks:
         self.prefetch = prefetch
         self.rank, self.world = rank, world
         self.epoch = 0
+        self._stage: dict = {}
+        self._stage_flip = 0
 
     # ---- one chunk -> permuted scipy matrix + DataFrame
     def _prepared_chunks(self, rng: np.random.Generator) -> Iterator:
@@ -119,14 +160,37 @@ class SpeciesChunks:
                 raise item
             yield item
 
-    def _tensor(self, batch) -> torch.Tensor:
-        """scipy CSR rows -> torch.sparse_csr (int64 indices as torch stores them, fp32 values), optionally on the device."""
-        crow = torch.from_numpy(batch.indptr.astype(np.int64))
-        col = torch.from_numpy(batch.indices.astype(np.int64))
-        val = torch.from_numpy(batch.data.astype(np.float32))
+    def _pinned(self, key: str, like: np.ndarray, dtype) -> torch.Tensor:
+        """A reusable page-locked staging tensor per CSR component (grown on demand): allocating pinned memory per batch
+        costs more than the copy.  Two alternating sets, so that the asynchronous H2D copy of batch i is not overwritten
+        while batch i + 1 is being staged."""
+        slot = self._stage_flip
+        buf = self._stage.get((key, slot))
+        if buf is None or buf.numel() < like.size:
+            buf = torch.empty(max(int(like.size * 1.25), 16), dtype=dtype).pin_memory()
+            self._stage[(key, slot)] = buf
+        out = buf[:like.size]
+        out.numpy()[...] = like  # converts the dtype on the way (int32 -> int64 indices)
+        return out
+
+    def _tensor(self, matrix, i: int) -> torch.Tensor:
+        """Rows i .. i + batch_size of a scipy CSR chunk -> torch.sparse_csr (int64 indices as torch stores them, fp32
+        values), optionally on the device.  Consecutive rows of a CSR matrix are one contiguous run of its index and
+        value arrays: the batch is three views (plus the dtype conversion), not a scipy row slice."""
+        j = min(i + self.batch_size, matrix.shape[0])
+        lo, hi = int(matrix.indptr[i]), int(matrix.indptr[j])
+        indptr, indices, data = matrix.indptr[i:j + 1] - lo, matrix.indices[lo:hi], matrix.data[lo:hi]
+        shape = (j - i, matrix.shape[1])
         if self.device is not None and self.device.type == "cuda":
-            crow, col, val = (t.pin_memory().to(self.device, non_blocking=True) for t in (crow, col, val))
-        t = torch.sparse_csr_tensor(crow, col, val, size=batch.shape)
+            self._stage_flip ^= 1
+            crow = self._pinned("crow", indptr, torch.int64).to(self.device, non_blocking=True)
+            col = self._pinned("col", indices, torch.int64).to(self.device, non_blocking=True)
+            val = self._pinned("val", data, torch.float32).to(self.device, non_blocking=True)
+        else:
+            crow = torch.from_numpy(indptr.astype(np.int64))
+            col = torch.from_numpy(indices.astype(np.int64))
+            val = torch.from_numpy(data.astype(np.float32))
+        t = torch.sparse_csr_tensor(crow, col, val, size=shape)
         if self.return_dense:
             from . import backend
 
@@ -142,18 +206,18 @@ class SpeciesChunks:
         for matrix, metadata in chunks:
             n = matrix.shape[0]
             for b, i in enumerate(range(0, n, self.batch_size)):
-                rows = matrix[i:i + self.batch_size]
-                if rows.shape[0] != self.batch_size and not self.allow_partials:
+                if i + self.batch_size > n and not self.allow_partials:
                     continue
                 if b % self.world != self.rank:
                     continue
-                yield self._tensor(rows), metadata.iloc[i:i + self.batch_size].reset_index(drop=True), self.name
+                yield self._tensor(matrix, i), metadata.iloc[i:i + self.batch_size].reset_index(drop=True), self.name
 
     def __len__(self) -> int:
         raise TypeError("SpeciesChunks streams chunk files: its length is not known without reading them")
 
 
-def write_chunks(directory: str, name: str, matrix, metadata: pd.DataFrame, chunk_rows: int, split: str = "train") -> List[str]:
+def write_chunks(directory: str, name: str, matrix, metadata: pd.DataFrame, chunk_rows: int, split: str = "train",
+                 compressed: bool = True) -> List[str]:
     """Write `{name}_{split}_counts_{i}.npz` / `{name}_{split}_metadata_{i}.pkl` chunk pairs (the layout the
     reference's preprocessing produces, scripts/data-preprocessing/: `scipy.sparse.save_npz` + pickled DataFrame).
     Used by the tests and by bench.py's npz leg to put synthetic data on disk."""
@@ -165,7 +229,7 @@ def write_chunks(directory: str, name: str, matrix, metadata: pd.DataFrame, chun
     for k, i in enumerate(range(0, matrix.shape[0], chunk_rows), start=1):
         npz = os.path.join(directory, f"{name}_{split}_counts_{k}.npz")
         pkl = os.path.join(directory, f"{name}_{split}_metadata_{k}.pkl")
-        sp.save_npz(npz, matrix[i:i + chunk_rows])
+        sp.save_npz(npz, matrix[i:i + chunk_rows], compressed=compressed)
         metadata.iloc[i:i + chunk_rows].reset_index(drop=True).to_pickle(pkl)
         out += [npz, pkl]
     return out
