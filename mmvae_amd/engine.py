@@ -700,10 +700,24 @@ class _Plan:
             if early and j == self.n_expert_enc:  # the last VAE layer is done: what remains is the expert's encoder
                 self._begin_exchange(self.opt_vae)
         # ---- clip + Adam (reference order: clip vae, clip expert, step vae, step expert)
+        # Logged scalars: the step's metrics words (and the pre-clip gradient norms) are copied into a buffer of this
+        # plan's own as the last node(s) of the captured program -- the logged tensors are views of it, valid until
+        # this plan's next step -- instead of three D2D copies issued by the host behind every replay (~24 us).
+        self.log_buf = torch.zeros(256, dtype=torch.float32, device=eng.device)
+
+        def emit_log_copy():
+            self._emit(lib.mmvae_axpby, 256, 1.0, _p(self.metrics), 0.0, _p(self.log_buf))
+
         self.optimizer(self.opt_vae, self.clip_vae, exchange="wait" if early else "inline")
+        self.copy_scalar(self.opt_vae.state_dev.data_ptr() + 4, "grad_norms/vae")
+        if early:  # the expert's exchange + update leave the main stream: its norm is logged from the comm stream
+            emit_log_copy()
         self.optimizer(self.opt_exp, self.clip_exp, exchange="deferred" if early else "inline")
         if early:
             self.exp_norm_log = torch.zeros(1, dtype=torch.float32, device=eng.device)
+        else:
+            self.copy_scalar(self.opt_exp.state_dev.data_ptr() + 4, "grad_norms/expert")
+            emit_log_copy()
         self.segments.append(self._cur)
         self._cur = []
         # noise: Philox fills (production) or explicit buffers (parity mode), at the head of the program
@@ -908,7 +922,9 @@ class _Plan:
         return self._run_program(self._graphs, lambda g: g.replay())
 
     def log(self, model, eid: str):
-        m = self.metrics.clone()  # one small D2D copy; logged scalars are views of it (no host sync)
+        m = self.log_buf  # filled by the captured program itself; logged scalars are views of it (no copy, no host sync)
+        if os.environ.get("MMVAE_LOG_COPY", "") == "host":  # diagnostics: the former host-issued copy
+            m = self.log_buf.clone()
         stage = model.stage_name
         main = {RK.LOSS: m[self.slot("total_loss")], RK.RECON_LOSS: m[1], RK.KL_LOSS: m[2], RK.KL_WEIGHT: m[3],
                 "Mean": m[4], "Variance": m[5]}
@@ -918,9 +934,9 @@ class _Plan:
                 for c in self.conditions + ["summed"]:
                     model.auto_log({c: m[self.slot(f"{phase}_{i}/{c}")]}, tags=tags, key_pos="last")
                 model.log(f"grad_norms/{phase}_{i}", m[self.slot(f"grad_norms/{phase}_{i}")])
-        model.log("grad_norms/vae", self.opt_vae.state_dev[1].clone())
+        model.log("grad_norms/vae", m[self.slot("grad_norms/vae")])
         # overlapped mode: the norm is produced on the communication stream; the logged tensor is filled when that
         # stream gets there (read it after engine.flush() / a device synchronisation)
         model.log(f"grad_norms/expert_{eid}", self.exp_norm_log[0] if self.exp_norm_log is not None
-                  else self.opt_exp.state_dev[1].clone())
+                  else m[self.slot("grad_norms/expert")])
         model.auto_log(main, tags=[stage, eid])
