@@ -35,9 +35,6 @@ namespace {
 #ifndef MMVAE_X3_STAMPS
 #define MMVAE_X3_STAMPS 0  // diagnostic build: per-phase cycle sums of the bf16x3 loop (block 0, one lane per wave)
 #endif
-#ifndef MMVAE_X3_ABLATE
-#define MMVAE_X3_ABLATE 0  // timing-only ablations of the bf16x3 loop (results are wrong when != 0)
-#endif
 #ifndef MMVAE_GEMM_PRELOAD
 #define MMVAE_GEMM_PRELOAD 0
 #endif
@@ -537,7 +534,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_batch_kernel(const mmvae_gemm_job
 // fp32, so the result has fp32-GEMM accuracy (measured 1.5e-7 rel-L2 vs fp64 at K = 20000, plain fp32 GEMM 3.5e-7),
 // while v_mfma_f32_32x32x16_bf16 runs at 16x the rate of v_mfma_f32_32x32x2_f32: 6 MFMAs replace 8 -> 2.67x the
 // matrix-core throughput of the exact-f32 path.  The split happens once per element while a tile is staged into LDS
-// (VALU work that overlaps the partner wave's MFMAs); LDS holds three bf16 planes per operand, [plane][row][32 k]
+// (its VALU instructions are interleaved with the wave's own MFMAs, 4 behind each: see X3Stage); LDS holds three bf16
+// planes per operand, [plane][row][32 k]
 // with 80-byte rows (64 B data + 16 B pad: conflict-free ds_read_b128 fragments).  Operands whose contiguous axis is
 // not K (the "RC" images of the NN / TN layouts) are transposed in registers on the way to LDS (each thread owns a
 // 4 k x 4 row patch), so the MFMA loop is identical for all three layouts.
@@ -669,22 +667,6 @@ __device__ __forceinline__ void x3_store(char* S, const f32x4 (&reg)[NV], const 
     }
 }
 
-// ---- unit-level split / write: a "unit" is 4 consecutive-k fp32 values of one tile row = three uint2 of packed bf16.
-// KC operand: unit u = the thread's u-th 16-byte group.  RC operand: unit u = column u of the thread's 4k x 4row patch.
-__device__ __forceinline__ void x3_pack4(float v0, float v1, float v2, float v3, uint2 (&pk)[3]) {
-    unsigned a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
-    x3_split(v0, a0, a1, a2);
-    x3_split(v1, b0, b1, b2);
-    x3_split(v2, c0, c1, c2);
-    x3_split(v3, d0, d1, d2);
-    pk[0].x = (a0 >> 16) | b0;
-    pk[0].y = (c0 >> 16) | d0;
-    pk[1].x = (a1 >> 16) | b1;
-    pk[1].y = (c1 >> 16) | d1;
-    pk[2].x = (a2 >> 16) | (b2 & 0xFFFF0000u);
-    pk[2].y = (c2 >> 16) | (d2 & 0xFFFF0000u);
-}
-
 // Lean split for the pipelined loop: 4.5 VALU instructions per element (VALU and MFMA instructions of one SIMD do not
 // overlap on gfx950 -- tools/ubench/overlap.hip -- so every instruction here is paid for in matrix-core time):
 // 2 ANDs + 2 halves of a packed subtract per element, one v_perm_b32 per bf16 pair and plane.
@@ -770,11 +752,6 @@ template <int NU>
 __device__ __forceinline__ void x3p_load(f32x4 (&reg)[NU], const char* __restrict__ base, const unsigned (&off)[NU]) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) reg[u] = *reinterpret_cast<const f32x4*>(base + off[u]);
-}
-
-template <int J>
-__device__ __forceinline__ float x3_quad_bcast(float v) {  // value of lane J of this lane's quad
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), J * 0x55, 0xF, 0xF, true));
 }
 
 template <int FORM, int R, bool TAILCHK>
@@ -904,9 +881,6 @@ __device__ __forceinline__ void x3s_phase(X3Stage& s, uint2 (&pk)[3]) {
 #ifndef MMVAE_X3_PRIO_TOGGLE
 #define MMVAE_X3_PRIO_TOGGLE 0  // 1: alternate the wave priority per k-tile, opposite phase per wave slot (measured: the
                                 // two workgroups of a CU finish closer together, the kernel does not get shorter)
-#endif
-#ifndef MMVAE_X3_INTERLEAVE
-#define MMVAE_X3_INTERLEAVE 1  // 1: hand-interleaved steady-state k-step; 0: compiler-scheduled
 #endif
 #define X3_SB() __builtin_amdgcn_sched_barrier(0)
 
@@ -1300,9 +1274,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
             }
         }
     }
-#if MMVAE_X3_ABLATE == 5  // no epilogue (accumulators kept alive through a never-taken branch)
-    if (g.alpha != 123.456f) continue;
-#endif
     gemm_epilogue<BM, BN, WGM, WGN, EPI>(acc, g, bm, bn, z, reinterpret_cast<float*>(lds));
     if (EPI == EPI_RECON) __syncthreads();  // the epilogue's LDS scratch is overwritten by the next item's prologue
     }  // work items
