@@ -131,6 +131,8 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     rank = mdist.rank()
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MMVAE_SINGLE_DEVICE", "0") != "0":  # rehearsal: every rank on GPU 0 (with MMVAE_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     cfg = synthetic.CONFIGS[a.config]

@@ -28,8 +28,8 @@ def init_from_env(backend: Optional[str] = None) -> int:
             os.environ.setdefault("WORLD_SIZE", "1")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # MMVAE_DIST_BACKEND=gloo: rehearse several ranks on one GPU (gloo stages CUDA tensors)
+            backend = os.environ.get("MMVAE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group(backend=backend)
