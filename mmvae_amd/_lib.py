@@ -120,6 +120,11 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # The library works on torch's streams and device memory, so it must share torch's HIP runtime: torch ships its own
+    # libamdhip64, and whichever copy is loaded first serves the whole process.  Loading this library before torch binds
+    # its code objects to the system runtime, and every launch on a torch stream then fails (MMVAE_ERR_LAUNCH).
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise HipLibraryError(
             f"{LIB_PATH} not found: build it with `make -C mmvae_amd/csrc` (or __graft_entry__.build()). "

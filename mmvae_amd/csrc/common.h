@@ -7,6 +7,15 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Launch with the runtime's sticky last-error word cleared first: MMVAE_LAUNCH_CHECK must report THIS launch, not an
+// error some earlier, unrelated HIP call of the process left behind (e.g. a probe made by the host framework while it
+// initialises the device after this library was already loaded).
+#define MMVAE_LAUNCH(...)                  \
+    do {                                   \
+        (void)hipGetLastError();           \
+        hipLaunchKernelGGL(__VA_ARGS__);   \
+    } while (0)
+
 #define MMVAE_LAUNCH_CHECK()                                   \
     do {                                                       \
         hipError_t e__ = hipGetLastError();                    \

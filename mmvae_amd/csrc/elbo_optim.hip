@@ -493,7 +493,7 @@ extern "C" int mmvae_reparam_kl_fwd(int B, int Z, int K, const float* mu, const 
                                     mmvae_stream_t stream) {
     if (B <= 0 || Z <= 0 || K < 1 || !mu || !a_raw) return MMVAE_ERR_ARG;
     if (z_out && !eps) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, Z, K, mu,
+    MMVAE_LAUNCH(reparam_kl_fwd_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, Z, K, mu,
                        a_raw, eps, var_eps, std_out, z_out, kl_row, stat_row);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
@@ -506,7 +506,7 @@ extern "C" int mmvae_reparam_kl_bwd(int B, int Z, int K, const float* mu, const 
     if (B <= 0 || Z <= 0 || K < 1 || !mu || !sd || !dmu || !da_raw) return MMVAE_ERR_ARG;
     if (dz && !eps) return MMVAE_ERR_ARG;
     const int64_t n = (int64_t)B * Z;
-    hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, B, Z, K,
+    MMVAE_LAUNCH(reparam_kl_bwd_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, B, Z, K,
                        mu, sd, eps, dz, dmu_extra, dstd_extra, dkl_row, kl_scale_dev, kl_scale_host, var_eps, dmu,
                        da_raw);
     MMVAE_LAUNCH_CHECK();
@@ -519,7 +519,7 @@ extern "C" int mmvae_mse_sum_fwd_bwd(int B, int G, const float* xhat, int64_t ld
     if (B <= 0 || G <= 0 || !xhat || !x || ldxhat < G || ldx < G) return MMVAE_ERR_ARG;
     if (!se_row && !dxhat) return MMVAE_ERR_ARG;
     if (dxhat && lddx < G) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(mse_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, B, G, xhat, ldxhat, x, ldx, se_row,
+    MMVAE_LAUNCH(mse_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, B, G, xhat, ldxhat, x, ldx, se_row,
                        dxhat, lddx, gscale_dev, gscale_host);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
@@ -529,10 +529,10 @@ extern "C" int mmvae_elbo_finalize(int B, int K, int T, const float* se_part, co
                                    const float* stat_row, int Z, const float* kl_weight_dev, float kl_weight_host,
                                    float* out6, float* w_out, float* recon_row, mmvae_stream_t stream) {
     if (B <= 0 || K < 1 || K > ELBO_MAXK || T < 1 || !se_part || !out6 || !recon_row) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(elbo_rows_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, K, T, se_part,
+    MMVAE_LAUNCH(elbo_rows_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, K, T, se_part,
                        recon_row, w_out);
     MMVAE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(elbo_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, recon_row, kl_row, stat_row, Z,
+    MMVAE_LAUNCH(elbo_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, recon_row, kl_row, stat_row, Z,
                        kl_weight_dev, kl_weight_host, out6);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
@@ -544,7 +544,7 @@ extern "C" int mmvae_cross_entropy_sum(int B, int C, const float* logits, int64_
     if (B <= 0 || C <= 0 || !logits || !labels || ld < C) return MMVAE_ERR_ARG;
     if (!loss_rows && !dlogits) return MMVAE_ERR_ARG;
     if (dlogits && ldd < C) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(ce_rows_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, C, logits, ld,
+    MMVAE_LAUNCH(ce_rows_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, C, logits, ld,
                        labels, loss_rows, dlogits, ldd, gscale_dev, gscale_host);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
@@ -552,7 +552,7 @@ extern "C" int mmvae_cross_entropy_sum(int B, int C, const float* logits, int64_
 
 extern "C" int mmvae_sum_f32(int64_t n, const float* v, float* out, int accumulate, mmvae_stream_t stream) {
     if (n < 0 || (n > 0 && !v) || !out) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, v, out, accumulate);
+    MMVAE_LAUNCH(sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, v, out, accumulate);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }
@@ -561,7 +561,7 @@ extern "C" int64_t mmvae_sqnorm_partials(int64_t n) { return n > 0 ? ceil_div_l(
 
 extern "C" int mmvae_grad_sqnorm(int64_t n, const float* grad, float* partials, mmvae_stream_t stream) {
     if (n <= 0 || !grad || !partials) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)mmvae_sqnorm_partials(n)), dim3(256), 0, (hipStream_t)stream, n,
+    MMVAE_LAUNCH(sqnorm_kernel, dim3((unsigned)mmvae_sqnorm_partials(n)), dim3(256), 0, (hipStream_t)stream, n,
                        grad, partials);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
@@ -571,7 +571,7 @@ extern "C" int mmvae_adam_prepare(int64_t n_partials, const float* partials, flo
                                   float beta1, float beta2, float* state, unsigned flags, mmvae_stream_t stream) {
     if (n_partials < 0 || !state) return MMVAE_ERR_ARG;
     if ((flags & MMVAE_PREPARE_NORM) && n_partials > 0 && !partials) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n_partials, partials, max_norm,
+    MMVAE_LAUNCH(adam_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n_partials, partials, max_norm,
                        grad_scale, beta1, beta2, state, flags);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
@@ -582,7 +582,7 @@ extern "C" int mmvae_adam_step(int64_t n, float* param, const float* grad, float
                                float grad_scale, mmvae_stream_t stream) {
     if (n <= 0 || !param || !grad || !exp_avg || !exp_avg_sq || !state) return MMVAE_ERR_ARG;
     const int vec = aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq);
-    hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream, n, param,
+    MMVAE_LAUNCH(adam_step_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream, n, param,
                        grad, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps, weight_decay, grad_scale, vec);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
@@ -591,11 +591,11 @@ extern "C" int mmvae_adam_step(int64_t n, float* param, const float* grad, float
 extern "C" int mmvae_philox_keep_mask(int64_t n, float p_drop, uint8_t* mask, uint64_t* rng_state, uint64_t stream_id,
                                       int advance, mmvae_stream_t stream) {
     if (n <= 0 || !mask || !rng_state || p_drop < 0.f || p_drop >= 1.f) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(philox_mask_kernel, dim3(grid_for((n + 3) / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, n,
+    MMVAE_LAUNCH(philox_mask_kernel, dim3(grid_for((n + 3) / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, n,
                        p_drop, mask, rng_state, stream_id);
     MMVAE_LAUNCH_CHECK();
     if (advance) {
-        hipLaunchKernelGGL(philox_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state,
+        MMVAE_LAUNCH(philox_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state,
                            (uint64_t)((n + 3) / 4));
         MMVAE_LAUNCH_CHECK();
     }
@@ -605,11 +605,11 @@ extern "C" int mmvae_philox_keep_mask(int64_t n, float p_drop, uint8_t* mask, ui
 extern "C" int mmvae_philox_normal(int64_t n, float* out, uint64_t* rng_state, uint64_t stream_id, int advance,
                                    mmvae_stream_t stream) {
     if (n <= 0 || !out || !rng_state) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(philox_normal_kernel, dim3(grid_for((n + 3) / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+    MMVAE_LAUNCH(philox_normal_kernel, dim3(grid_for((n + 3) / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
                        n, out, rng_state, stream_id);
     MMVAE_LAUNCH_CHECK();
     if (advance) {
-        hipLaunchKernelGGL(philox_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state,
+        MMVAE_LAUNCH(philox_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state,
                            (uint64_t)((n + 3) / 4));
         MMVAE_LAUNCH_CHECK();
     }
@@ -618,7 +618,7 @@ extern "C" int mmvae_philox_normal(int64_t n, float* out, uint64_t* rng_state, u
 
 extern "C" int mmvae_philox_advance(uint64_t* rng_state, uint64_t by, mmvae_stream_t stream) {
     if (!rng_state) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(philox_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state, by);
+    MMVAE_LAUNCH(philox_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state, by);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }
@@ -662,7 +662,7 @@ extern "C" int mmvae_csr_to_dense_f32(int B, int G, int64_t nnz, const int64_t* 
     if (nnz > 0 && (!col_indices || !values)) return MMVAE_ERR_ARG;
     if (B > 65535) return MMVAE_ERR_ARG;
     const int vec = aligned16(out) && (ldo % 4 == 0) ? 1 : 0;
-    hipLaunchKernelGGL(csr_to_dense_kernel, dim3(ceil_div_i(G, CSR_CHUNK), B), dim3(256), 0, (hipStream_t)stream, G,
+    MMVAE_LAUNCH(csr_to_dense_kernel, dim3(ceil_div_i(G, CSR_CHUNK), B), dim3(256), 0, (hipStream_t)stream, G,
                        nnz, crow_indices, col_indices, values, out, ldo, vec);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
@@ -671,10 +671,10 @@ extern "C" int mmvae_csr_to_dense_f32(int B, int G, int64_t nnz, const int64_t* 
 extern "C" int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, float* y, mmvae_stream_t stream) {
     if (n <= 0 || !x || !y) return MMVAE_ERR_ARG;
     if (n % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
-        hipLaunchKernelGGL(axpby4_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, n / 4,
+        MMVAE_LAUNCH(axpby4_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, n / 4,
                            alpha, reinterpret_cast<const float4*>(x), beta, reinterpret_cast<float4*>(y));
     else
-        hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, n, alpha, x,
+        MMVAE_LAUNCH(axpby_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, n, alpha, x,
                            beta, y);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
@@ -682,7 +682,7 @@ extern "C" int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, f
 
 extern "C" int mmvae_sum_parts_batch(int n_jobs, const mmvae_sum_job* jobs, mmvae_stream_t stream) {
     if (n_jobs <= 0 || n_jobs > 65535 || !jobs) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(sum_parts_batch_kernel, dim3(64, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    MMVAE_LAUNCH(sum_parts_batch_kernel, dim3(64, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }
@@ -690,7 +690,7 @@ extern "C" int mmvae_sum_parts_batch(int n_jobs, const mmvae_sum_job* jobs, mmva
 extern "C" int mmvae_scale_rows(int B, int N, const float* x, int64_t ldx, const float* row_scale, float* y,
                                 int64_t ldy, mmvae_stream_t stream) {
     if (B <= 0 || N <= 0 || !x || !row_scale || !y || ldx < N || ldy < N) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for((int64_t)B * N, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+    MMVAE_LAUNCH(scale_rows_kernel, dim3(grid_for((int64_t)B * N, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
                        B, N, x, ldx, row_scale, y, ldy);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;

@@ -417,13 +417,13 @@ extern "C" int mmvae_fc_epilogue_fwd(int B, int N, const float* in, int64_t ld_i
     const dim3 grid(ceil_div_i(N, CW), a.RC);
     hipStream_t s = (hipStream_t)stream;
     if (stats) {
-        hipLaunchKernelGGL(fc_fwd_stats_kernel, grid, dim3(CT), 0, s, a);
+        MMVAE_LAUNCH(fc_fwd_stats_kernel, grid, dim3(CT), 0, s, a);
         MMVAE_LAUNCH_CHECK();
     }
     if (bn)
-        hipLaunchKernelGGL(fc_fwd_apply_kernel<true>, grid, dim3(CT), 0, s, a);
+        MMVAE_LAUNCH(fc_fwd_apply_kernel<true>, grid, dim3(CT), 0, s, a);
     else
-        hipLaunchKernelGGL(fc_fwd_apply_kernel<false>, grid, dim3(CT), 0, s, a);
+        MMVAE_LAUNCH(fc_fwd_apply_kernel<false>, grid, dim3(CT), 0, s, a);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }
@@ -468,14 +468,14 @@ extern "C" int mmvae_fc_epilogue_bwd(int B, int N, const float* din, int64_t ld_
     const dim3 grid(ceil_div_i(N, CW), a.RC);
     hipStream_t s = (hipStream_t)stream;
     if (has_bn) {
-        hipLaunchKernelGGL(fc_bwd_stats_kernel<true>, grid, dim3(CT), 0, s, a);
+        MMVAE_LAUNCH(fc_bwd_stats_kernel<true>, grid, dim3(CT), 0, s, a);
         MMVAE_LAUNCH_CHECK();
-        hipLaunchKernelGGL(fc_bwd_apply_kernel, grid, dim3(CT), 0, s, a);
+        MMVAE_LAUNCH(fc_bwd_apply_kernel, grid, dim3(CT), 0, s, a);
     } else {
-        hipLaunchKernelGGL(fc_bwd_stats_kernel<false>, grid, dim3(CT), 0, s, a);
+        MMVAE_LAUNCH(fc_bwd_stats_kernel<false>, grid, dim3(CT), 0, s, a);
         MMVAE_LAUNCH_CHECK();
         if (dbias)
-            hipLaunchKernelGGL(fc_colsum_finish_kernel, dim3(ceil_div_i(N, 256)), dim3(256), 0, s, workspace, a.RC, N,
+            MMVAE_LAUNCH(fc_colsum_finish_kernel, dim3(ceil_div_i(N, 256)), dim3(256), 0, s, workspace, a.RC, N,
                                dbias);
     }
     MMVAE_LAUNCH_CHECK();
@@ -485,7 +485,7 @@ extern "C" int mmvae_fc_epilogue_bwd(int B, int N, const float* din, int64_t ld_
 extern "C" int mmvae_layernorm_fwd(int B, int N, const float* x, int64_t ldx, float eps, float* y, int64_t ldy,
                                    float* save_mean, float* save_invstd, mmvae_stream_t stream) {
     if (B <= 0 || N <= 0 || !x || !y || ldx < N || ldy < N) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, N, x, ldx,
+    MMVAE_LAUNCH(layernorm_fwd_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, N, x, ldx,
                        eps, y, ldy, save_mean, save_invstd);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
@@ -494,7 +494,7 @@ extern "C" int mmvae_layernorm_fwd(int B, int N, const float* x, int64_t ldx, fl
 extern "C" int mmvae_layernorm_bwd(int B, int N, const float* dy, int64_t lddy, const float* y, int64_t ldy,
                                    const float* save_invstd, float* dx, int64_t lddx, mmvae_stream_t stream) {
     if (B <= 0 || N <= 0 || !dy || !y || !save_invstd || !dx || lddy < N || ldy < N || lddx < N) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, N, dy,
+    MMVAE_LAUNCH(layernorm_bwd_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, N, dy,
                        lddy, y, ldy, save_invstd, dx, lddx);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;

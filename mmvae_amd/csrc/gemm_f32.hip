@@ -1321,20 +1321,20 @@ TileShape tile_shape(int layout, int id) {
 template <int AFORM, int BFORM, bool VEC, int EPI>
 int launch_gemm_vec(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) {
     if (tile_id == 0)
-        hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, 128, 128, MMVAE_GEMM_BK0, 2, 2, VEC, EPI>), dim3(nblocks),
+        MMVAE_LAUNCH((gemm_f32_kernel<AFORM, BFORM, 128, 128, MMVAE_GEMM_BK0, 2, 2, VEC, EPI>), dim3(nblocks),
                            dim3(NT), 0, s, g);
     else if (tile_id == 1) {
         if (AFORM == FORM_KC && BFORM == FORM_KC)  // BK = 16 keeps two workgroups resident per CU
-            hipLaunchKernelGGL((gemm_f32_kernel<FORM_KC, FORM_KC, 128, 160, 16, 4, 1, VEC, EPI>), dim3(nblocks),
+            MMVAE_LAUNCH((gemm_f32_kernel<FORM_KC, FORM_KC, 128, 160, 16, 4, 1, VEC, EPI>), dim3(nblocks),
                                dim3(NT), 0, s, g);
         else if (AFORM == FORM_RC)
-            hipLaunchKernelGGL((gemm_f32_kernel<FORM_RC, FORM_RC, 128, 160, 32, 4, 1, VEC, EPI>), dim3(nblocks),
+            MMVAE_LAUNCH((gemm_f32_kernel<FORM_RC, FORM_RC, 128, 160, 32, 4, 1, VEC, EPI>), dim3(nblocks),
                                dim3(NT), 0, s, g);
         else
             return MMVAE_ERR_ARG;
     }
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<AFORM, BFORM, 64, 64, 32, 2, 2, VEC, EPI>), dim3(nblocks), dim3(NT), 0, s,
+        MMVAE_LAUNCH((gemm_f32_kernel<AFORM, BFORM, 64, 64, 32, 2, 2, VEC, EPI>), dim3(nblocks), dim3(NT), 0, s,
                            g);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
@@ -1352,12 +1352,12 @@ int launch_gemm_x3(int tile_id, const GemmArgs& g0, int nwork, hipStream_t s) {
     const int nblocks = nwork;
 #endif
     if (VEC && tile_id == 4)
-        hipLaunchKernelGGL((gemm_x3_kernel<AFORM, BFORM, 128, 160, 4, 1, true, EPI>), dim3(nblocks), dim3(NT), 0, s, g);
+        MMVAE_LAUNCH((gemm_x3_kernel<AFORM, BFORM, 128, 160, 4, 1, true, EPI>), dim3(nblocks), dim3(NT), 0, s, g);
     else if (VEC && tile_id == 5 && EPI == EPI_STD)
-        hipLaunchKernelGGL((gemm_x3_kernel<AFORM, BFORM, 160, 128, 1, 4, true, EPI_STD>), dim3(nblocks), dim3(NT), 0, s,
+        MMVAE_LAUNCH((gemm_x3_kernel<AFORM, BFORM, 160, 128, 1, 4, true, EPI_STD>), dim3(nblocks), dim3(NT), 0, s,
                            g);
     else if (tile_id == 3)
-        hipLaunchKernelGGL((gemm_x3_kernel<AFORM, BFORM, 128, 128, 2, 2, VEC, EPI>), dim3(nblocks), dim3(NT), 0, s, g);
+        MMVAE_LAUNCH((gemm_x3_kernel<AFORM, BFORM, 128, 128, 2, 2, VEC, EPI>), dim3(nblocks), dim3(NT), 0, s, g);
     else
         return MMVAE_ERR_ARG;
     MMVAE_LAUNCH_CHECK();
@@ -1535,7 +1535,7 @@ extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, cons
         const int64_t total = (int64_t)M * N;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, workspace, splitk, (int64_t)M * N, M,
+        MMVAE_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, workspace, splitk, (int64_t)M * N, M,
                            N, alpha, bias, flags, C, ldc);
         MMVAE_LAUNCH_CHECK();
     }
@@ -1574,7 +1574,7 @@ extern "C" int mmvae_gemm_batch_prepare(int n_jobs, mmvae_gemm_job* jobs, int* t
 extern "C" int mmvae_gemm_batch_f32(int n_jobs, const mmvae_gemm_job* jobs_dev, int total_blocks,
                                     mmvae_stream_t stream) {
     if (n_jobs <= 0 || !jobs_dev || total_blocks <= 0) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(gemm_f32_batch_kernel, dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, jobs_dev, n_jobs);
+    MMVAE_LAUNCH(gemm_f32_batch_kernel, dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, jobs_dev, n_jobs);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }
