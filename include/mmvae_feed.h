@@ -1,0 +1,44 @@
+/*
+ * mmvae_feed.h -- C-ABI of libmmvae_feed.so: host-side helpers of the data feed.
+ *
+ * The reference builds every batch in Python: a row permutation of the chunk's scipy CSR matrix
+ * (data/local/cellxgene_datapipe.py:110-122) followed by a row slice and torch.sparse_csr_tensor(...)
+ * (:169-193).  This library does the one memory-bound step of that chain natively and without the interpreter
+ * lock: gather B rows of a CSR chunk (given by index, i.e. the permutation is never materialised) into three
+ * caller-owned staging arrays in the layout torch.sparse_csr uses (int64 row pointers and column indices, fp32
+ * values) -- typically page-locked buffers that are then copied to the GPU asynchronously.
+ *
+ * Plain C, host pointers only, no allocation, no global state; thread-safe (distinct output buffers per call).
+ */
+#ifndef MMVAE_FEED_H
+#define MMVAE_FEED_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMVAE_FEED_OK 0
+#define MMVAE_FEED_ERR_ARG 1
+#define MMVAE_FEED_ERR_CAPACITY 2 /* the gathered rows hold more stored elements than `capacity` */
+
+int mmvae_feed_abi_version(void);
+
+/* Stored elements of the selected rows: sum over rows[i] of (indptr[r + 1] - indptr[r]).
+ * index_bytes: 4 or 8 = width of the chunk's indptr / indices arrays (scipy uses int32 while they fit). */
+int64_t mmvae_feed_rows_nnz(const void* indptr, int index_bytes, int64_t n_chunk_rows, const int64_t* rows,
+                            int64_t n_rows);
+
+/* Gather rows `rows[0..n_rows)` of a CSR chunk (indptr [n_chunk_rows + 1], indices / data [nnz]) into
+ *   out_crow [n_rows + 1] int64 (starts at 0), out_col [capacity] int64, out_val [capacity] fp32.
+ * n_threads <= 1: single-threaded; > 1: the rows are split over that many threads (disjoint output ranges).
+ * Returns MMVAE_FEED_OK and the element count in *out_nnz. */
+int mmvae_feed_gather_rows(const void* indptr, const void* indices, int index_bytes, const float* data,
+                           int64_t n_chunk_rows, const int64_t* rows, int64_t n_rows, int64_t* out_crow,
+                           int64_t* out_col, float* out_val, int64_t capacity, int n_threads, int64_t* out_nnz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMVAE_FEED_H */

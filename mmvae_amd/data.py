@@ -101,8 +101,61 @@ def load_chunk(npz_path: str, metadata_path: str):
     return matrix, metadata
 
 
+_FEED = None
+
+
+def feed_lib():
+    """libmmvae_feed.so (include/mmvae_feed.h): the native row gather.  Built by `make -C mmvae_amd/csrc` together with
+    the HIP library; built on demand here (g++, one file) when it is missing -- it is host code, not the HIP path."""
+    global _FEED
+    if _FEED is None:
+        import ctypes as C
+        import subprocess
+
+        here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+        path = os.path.join(here, "libmmvae_feed.so")
+        if not os.path.exists(path):
+            subprocess.run(["make", "-C", here, "libmmvae_feed.so"], check=True, capture_output=True)
+        lib = C.CDLL(path)
+        lib.mmvae_feed_rows_nnz.restype = C.c_int64
+        lib.mmvae_feed_rows_nnz.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64]
+        lib.mmvae_feed_gather_rows.restype = C.c_int
+        lib.mmvae_feed_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                               C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                               C.c_void_p]
+        assert lib.mmvae_feed_abi_version() == 1
+        _FEED = lib
+    return _FEED
+
+
+class _Slot:
+    """Staging arrays of one batch in flight: int64 row pointers / column indices and fp32 values in the layout
+    torch.sparse_csr uses.  Page-locked when the batches go to a GPU; reused once the asynchronous H2D copies that
+    read it have completed (`event`)."""
+
+    def __init__(self, n_rows: int, pinned: bool):
+        self.pinned = pinned
+        self.crow = self._alloc(n_rows + 1, torch.int64)
+        self.col = self._alloc(16, torch.int64)
+        self.val = self._alloc(16, torch.float32)
+        self.event = None
+
+    def _alloc(self, n: int, dtype) -> torch.Tensor:
+        t = torch.empty(n, dtype=dtype)
+        return t.pin_memory() if self.pinned else t
+
+    def reserve(self, nnz: int) -> None:
+        if self.col.numel() < nnz:
+            cap = (int(nnz * 1.25) + 16) if self.pinned else max(nnz, 1)  # pinned buffers are reused: leave headroom
+            self.col, self.val = self._alloc(cap, torch.int64), self._alloc(cap, torch.float32)
+
+
 class SpeciesChunks:
     """Iterable over the batches of one modality's chunk files: `(x, metadata, name)`.
+
+    A batch is gathered row by row out of the (memory-mapped) chunk by the native helper -- the row permutation is an
+    index list, the chunk itself is never permuted or sliced in Python -- into a ring of staging slots, `workers`
+    batches ahead of the consumer and off the interpreter lock.
 
     `rank` / `world`: data-parallel sharding -- every rank walks the same (seeded) chunk order and row permutations
     and keeps batches rank, rank + world, ... of each chunk, so that all ranks see the same number of batches of the
@@ -110,7 +163,8 @@ class SpeciesChunks:
 
     def __init__(self, directory_path: str, npz_masks, metadata_masks, batch_size: int, name: str,
                  allow_partials: bool = False, shuffle: bool = True, return_dense: bool = False, seed: int = 0,
-                 device: Optional[Union[str, torch.device]] = None, prefetch: bool = True, rank: int = 0, world: int = 1):
+                 device: Optional[Union[str, torch.device]] = None, prefetch: bool = True, rank: int = 0, world: int = 1,
+                 workers: int = 3, gather_threads: int = 2):
         self.chunks = list_chunks(directory_path, npz_masks, metadata_masks)
         self.batch_size = int(batch_size)
         self.name = name
@@ -121,25 +175,23 @@ class SpeciesChunks:
         self.device = torch.device(device) if device is not None else None
         self.prefetch = prefetch
         self.rank, self.world = rank, world
+        self.workers = max(1, int(workers))
+        self.gather_threads = max(1, int(gather_threads))
         self.epoch = 0
-        self._stage: dict = {}
-        self._stage_flip = 0
+        self._slots: List[_Slot] = []
 
-    # ---- one chunk -> permuted scipy matrix + DataFrame
+    # ---- chunks: (scipy CSR over the mapped file, metadata, row order)
     def _prepared_chunks(self, rng: np.random.Generator) -> Iterator:
         order = list(range(len(self.chunks)))
         if self.shuffle:
             order = [int(i) for i in rng.permutation(len(order))]
         for ci in order:
             matrix, metadata = load_chunk(*self.chunks[ci])
-            if self.shuffle:
-                perm = rng.permutation(matrix.shape[0])
-                metadata = metadata.iloc[perm].reset_index(drop=True)
-                matrix = matrix[perm]
-            yield matrix, metadata
+            rows = rng.permutation(matrix.shape[0]) if self.shuffle else np.arange(matrix.shape[0])
+            yield matrix, metadata, rows.astype(np.int64)
 
     def _background(self, gen: Iterator) -> Iterator:
-        """Run `gen` in a thread, one item ahead (loading + permuting a chunk overlaps the training on the last one)."""
+        """Run `gen` in a thread, one item ahead (loading a chunk overlaps the training on the last one)."""
         q: "queue.Queue" = queue.Queue(maxsize=1)
         done = object()
 
@@ -160,37 +212,40 @@ class SpeciesChunks:
                 raise item
             yield item
 
-    def _pinned(self, key: str, like: np.ndarray, dtype) -> torch.Tensor:
-        """A reusable page-locked staging tensor per CSR component (grown on demand): allocating pinned memory per batch
-        costs more than the copy.  Two alternating sets, so that the asynchronous H2D copy of batch i is not overwritten
-        while batch i + 1 is being staged."""
-        slot = self._stage_flip
-        buf = self._stage.get((key, slot))
-        if buf is None or buf.numel() < like.size:
-            buf = torch.empty(max(int(like.size * 1.25), 16), dtype=dtype).pin_memory()
-            self._stage[(key, slot)] = buf
-        out = buf[:like.size]
-        out.numpy()[...] = like  # converts the dtype on the way (int32 -> int64 indices)
-        return out
+    # ---- one batch: native gather into a staging slot (worker thread), tensors + H2D (consumer thread)
+    def _gather(self, slot: _Slot, matrix, rows: np.ndarray):
+        lib = feed_lib()
+        ib = matrix.indptr.dtype.itemsize
+        if matrix.indices.dtype.itemsize != ib or ib not in (4, 8) or matrix.data.dtype != np.float32:
+            matrix = matrix.astype(np.float32) if matrix.data.dtype != np.float32 else matrix
+            matrix.indices = matrix.indices.astype(matrix.indptr.dtype)
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        nnz = lib.mmvae_feed_rows_nnz(matrix.indptr.ctypes.data, ib, matrix.shape[0], rows.ctypes.data, len(rows))
+        if nnz < 0:
+            raise ValueError("row index outside the chunk")
+        slot.reserve(nnz)
+        import ctypes as C
 
-    def _tensor(self, matrix, i: int) -> torch.Tensor:
-        """Rows i .. i + batch_size of a scipy CSR chunk -> torch.sparse_csr (int64 indices as torch stores them, fp32
-        values), optionally on the device.  Consecutive rows of a CSR matrix are one contiguous run of its index and
-        value arrays: the batch is three views (plus the dtype conversion), not a scipy row slice."""
-        j = min(i + self.batch_size, matrix.shape[0])
-        lo, hi = int(matrix.indptr[i]), int(matrix.indptr[j])
-        indptr, indices, data = matrix.indptr[i:j + 1] - lo, matrix.indices[lo:hi], matrix.data[lo:hi]
-        shape = (j - i, matrix.shape[1])
+        got = C.c_int64(0)
+        rc = lib.mmvae_feed_gather_rows(matrix.indptr.ctypes.data, matrix.indices.ctypes.data if nnz else None, ib,
+                                        matrix.data.ctypes.data if nnz else None, matrix.shape[0], rows.ctypes.data,
+                                        len(rows), slot.crow.data_ptr(), slot.col.data_ptr(), slot.val.data_ptr(),
+                                        slot.col.numel(), self.gather_threads, C.byref(got))
+        if rc != 0 or got.value != nnz:
+            raise RuntimeError(f"mmvae_feed_gather_rows failed with code {rc}")
+        return slot, int(nnz), len(rows)
+
+    def _tensor(self, slot: _Slot, nnz: int, n_rows: int, n_cols: int) -> torch.Tensor:
+        """Staging slot -> torch.sparse_csr (int64 indices as torch stores them, fp32 values), on the device when one
+        was given (three non-blocking copies out of page-locked memory; the slot is reusable once they are done)."""
+        crow, col, val = slot.crow[:n_rows + 1], slot.col[:nnz], slot.val[:nnz]
         if self.device is not None and self.device.type == "cuda":
-            self._stage_flip ^= 1
-            crow = self._pinned("crow", indptr, torch.int64).to(self.device, non_blocking=True)
-            col = self._pinned("col", indices, torch.int64).to(self.device, non_blocking=True)
-            val = self._pinned("val", data, torch.float32).to(self.device, non_blocking=True)
-        else:
-            crow = torch.from_numpy(indptr.astype(np.int64))
-            col = torch.from_numpy(indices.astype(np.int64))
-            val = torch.from_numpy(data.astype(np.float32))
-        t = torch.sparse_csr_tensor(crow, col, val, size=shape)
+            crow, col, val = (t.to(self.device, non_blocking=True) for t in (crow, col, val))
+            slot.event = torch.cuda.Event()
+            slot.event.record()
+        else:  # host batches own their arrays: the slot was allocated for this batch alone (see __iter__)
+            slot.crow, slot.col, slot.val = slot.crow.new_empty(0), slot.col.new_empty(0), slot.val.new_empty(0)
+        t = torch.sparse_csr_tensor(crow, col, val, size=(n_rows, n_cols))
         if self.return_dense:
             from . import backend
 
@@ -198,19 +253,51 @@ class SpeciesChunks:
         return t
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, pd.DataFrame, str]]:
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+
         rng = np.random.default_rng([self.seed, self.epoch])
         self.epoch += 1
         chunks = self._prepared_chunks(rng)
         if self.prefetch:
             chunks = self._background(chunks)
-        for matrix, metadata in chunks:
-            n = matrix.shape[0]
-            for b, i in enumerate(range(0, n, self.batch_size)):
-                if i + self.batch_size > n and not self.allow_partials:
-                    continue
-                if b % self.world != self.rank:
-                    continue
-                yield self._tensor(matrix, i), metadata.iloc[i:i + self.batch_size].reset_index(drop=True), self.name
+        pinned = self.device is not None and self.device.type == "cuda"
+        depth = self.workers + 1
+        if len(self._slots) != depth or (self._slots and self._slots[0].pinned != pinned):
+            self._slots = [_Slot(self.batch_size, pinned) for _ in range(depth)]
+        free = deque(self._slots)
+        inflight: deque = deque()
+
+        def jobs():
+            for matrix, metadata, order in chunks:
+                n = matrix.shape[0]
+                for b, i in enumerate(range(0, n, self.batch_size)):
+                    if i + self.batch_size > n and not self.allow_partials:
+                        continue
+                    if b % self.world != self.rank:
+                        continue
+                    yield matrix, metadata, order[i:i + self.batch_size]
+
+        with ThreadPoolExecutor(max_workers=self.workers) as pool:
+            def finish():
+                fut, matrix, metadata, rows = inflight.popleft()
+                slot, nnz, n_rows = fut.result()
+                x = self._tensor(slot, nnz, n_rows, matrix.shape[1])
+                free.append(slot)
+                return x, metadata.iloc[rows].reset_index(drop=True), self.name
+
+            for matrix, metadata, rows in jobs():
+                if not free:
+                    yield finish()
+                slot = free.popleft()
+                if not pinned:  # host batches keep the arrays they were gathered into
+                    slot.crow = torch.empty(self.batch_size + 1, dtype=torch.int64)
+                if slot.event is not None:  # the H2D copies that read this slot (depth batches ago) must be done
+                    slot.event.synchronize()
+                    slot.event = None
+                inflight.append((pool.submit(self._gather, slot, matrix, rows), matrix, metadata, rows))
+            while inflight:
+                yield finish()
 
     def __len__(self) -> int:
         raise TypeError("SpeciesChunks streams chunk files: its length is not known without reading them")

@@ -85,3 +85,42 @@ def test_multi_modal_interleave_feeds_the_trainer(tmp_path):
     batches = list(MultiModalBatches(feeds, seed=1))
     assert sorted(b[2] for b in batches) == ["human"] * 4 + ["mouse"] * 4
     assert all(b[0].shape[1] == (12 if b[2] == "human" else 9) for b in batches)
+
+
+def test_native_row_gather_matches_scipy_and_validates():
+    """libmmvae_feed.so (include/mmvae_feed.h): bit-exact row gather into torch's CSR layout for int32 and int64 chunk
+    indices, single- and multi-threaded; bad row indices and short staging buffers are refused."""
+    import ctypes as C
+    import re
+
+    lib = D.feed_lib()
+    header = open(__import__("os").path.join(__import__("os").path.dirname(D.__file__), "..", "include", "mmvae_feed.h")).read()
+    for sym in set(re.findall(r"\b(mmvae_feed_[a-z_]+)\s*\(", header)):
+        assert hasattr(lib, sym), f"{sym} declared in include/mmvae_feed.h but not exported"
+    m, _ = _dataset(300, 40, 7)
+    m = m.tocsr()
+    rng = np.random.default_rng(0)
+    rows = rng.permutation(300)[:97].astype(np.int64)
+    ref = m[rows]
+    for idx_dtype in (np.int32, np.int64):
+        indptr, indices = m.indptr.astype(idx_dtype), m.indices.astype(idx_dtype)
+        for threads in (1, 4):
+            crow = np.empty(len(rows) + 1, np.int64)
+            col = np.full(ref.nnz + 5, -1, np.int64)
+            val = np.full(ref.nnz + 5, -1, np.float32)
+            got = C.c_int64(0)
+            rc = lib.mmvae_feed_gather_rows(indptr.ctypes.data, indices.ctypes.data, indptr.itemsize, m.data.ctypes.data,
+                                            m.shape[0], rows.ctypes.data, len(rows), crow.ctypes.data, col.ctypes.data,
+                                            val.ctypes.data, len(col), threads, C.byref(got))
+            assert rc == 0 and got.value == ref.nnz
+            assert np.array_equal(crow, ref.indptr) and np.array_equal(col[:ref.nnz], ref.indices)
+            assert np.array_equal(val[:ref.nnz], ref.data) and (col[ref.nnz:] == -1).all()
+            assert lib.mmvae_feed_rows_nnz(indptr.ctypes.data, indptr.itemsize, m.shape[0], rows.ctypes.data, len(rows)) == ref.nnz
+    bad = np.array([5, 300], np.int64)
+    crow = np.empty(3, np.int64)
+    assert lib.mmvae_feed_gather_rows(m.indptr.ctypes.data, m.indices.ctypes.data, 4, m.data.ctypes.data, 300,
+                                      bad.ctypes.data, 2, crow.ctypes.data, col.ctypes.data, val.ctypes.data, len(col), 1,
+                                      None) == 1
+    assert lib.mmvae_feed_gather_rows(m.indptr.ctypes.data, m.indices.ctypes.data, 4, m.data.ctypes.data, 300,
+                                      rows.ctypes.data, len(rows), np.empty(98, np.int64).ctypes.data, col.ctypes.data,
+                                      val.ctypes.data, 3, 1, None) == 2
