@@ -282,6 +282,18 @@ typedef struct {
 } mmvae_sum_job;
 int mmvae_sum_parts_batch(int n_jobs, const mmvae_sum_job* jobs, mmvae_stream_t stream);
 
+/* Unsplit GEMM that also leaves the sum of squares of everything it stores, one partial per output tile, in
+ * sq_partials[0 .. sq_capacity) (slots beyond the tiles it uses are zeroed): the weight-gradient GEMMs of the G-wide
+ * layers write 82 MB each, and the gradient-norm pass of clip_grad_norm_ (cmmvae_model.py:126-129,203-209) would read
+ * them all back.  The partials are summed with the other norm partials of the optimiser by mmvae_adam_prepare (fp64,
+ * fixed order: bitwise reproducible).  mmvae_gemm_sq_partials: slots to reserve (0 = the shape would be split-K:
+ * use mmvae_gemm_f32 and the norm pass); operands_regular != 0: A and B are 16-byte aligned with leading dimensions
+ * that are multiples of 4 -- the count is then exact and the launch zero-fills nothing. */
+int mmvae_gemm_sq_partials(int layout, int M, int N, int K, int operands_regular);
+int mmvae_gemm_f32_sq(int layout, int M, int N, int K, float alpha, const float* A, int64_t lda, const float* B,
+                      int64_t ldb, float* C, int64_t ldc, const float* bias, unsigned flags, float* sq_partials,
+                      int64_t sq_capacity, mmvae_stream_t stream);
+
 /* Grouped launch of independent small GEMMs (same math and layouts as mmvae_gemm_f32, exact-f32 MFMA, 64x64 tiles,
  * unsplit, alpha / bias / relu / accumulate epilogue): ONE grid covers the tiles of every job.  Used for the
  * weight-gradient GEMMs of the core (<= 1024-wide) layers of a backward pass -- replaces the per-parameter

@@ -81,6 +81,7 @@ struct GemmArgs {
     int se_tiles;  // rows of se_part the caller reads (>= nt); the last column tile zeroes rows nt .. se_tiles-1
     int c_vec;     // C (or the slabs) 16-byte regular: aligned base, ldc % 4 == 0, N % 4 == 0 -> 16-byte epilogue stores
     int nwork;     // bf16x3 kernel: work items (output tiles x split-K slices), looped over by <= 512 workgroups
+    float* sq_part;  // optional [mt * nt]: sum of squares of the C values this tile stores (unsplit launches only)
 };
 
 // HBM -> registers.  r0: first row (KC) / column (RC) of this tile along the non-K axis, Rtot its extent.
@@ -171,6 +172,16 @@ __device__ __forceinline__ float quad_perm(float v) {
         __builtin_amdgcn_update_dpp(0, __float_as_int(v), S0 | (S1 << 2) | (S2 << 4) | (S3 << 6), 0xF, 0xF, true));
 }
 
+// Sum of `v` over the 256 threads of the workgroup in a fixed order (wave shuffles, then the 4 wave sums in wave order)
+// -> *dst.  `lds` is free: the operand tiles are dead after the k-loop's final barrier.
+__device__ __forceinline__ void tile_sum_to(float* dst, float v, float* lds) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) *dst = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+    __syncthreads();  // a persistent workgroup's next item reuses the LDS
+}
+
 // Epilogue shared by the fp32-MFMA and the bf16x3-MFMA kernels (the C/D register layout of the 32x32 MFMAs is
 // dtype-independent): col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
 template <int BM, int BN, int WGM, int WGN, int EPI, int TM, int TN>
@@ -188,6 +199,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
         const bool accum = !raw && (g.flags & MMVAE_GEMM_ACCUMULATE);
         const bool relu = !raw && (g.flags & MMVAE_GEMM_RELU);
         const float alpha = raw ? 1.f : g.alpha;
+        float sq = 0.f;  // sum of squares of what this thread stores (feeds the fused gradient-norm partial)
         if (g.c_vec) {
             // 16-byte stores: the 4 lanes of a quad hold a 4 row x 4 column patch column-wise (one column each, rows
             // e = 4 gq .. 4 gq + 3); a quad transpose (2 DPP exchange stages) gives every lane one row x 4 columns.
@@ -226,9 +238,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
                                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                             }
                             *reinterpret_cast<f32x4*>(cp) = v;
+                            sq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                         }
                     }
                 }
+            if (g.sq_part) tile_sum_to(g.sq_part + ((int64_t)bn * g.mt + bm), sq, lds);
             return;
         }
 #pragma unroll
@@ -247,8 +261,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
                     if (accum) v += *cp;
                     if (relu) v = fmaxf(v, 0.f);
                     *cp = v;
+                    sq += v * v;
                 }
             }
+        if (g.sq_part) tile_sum_to(g.sq_part + ((int64_t)bn * g.mt + bm), sq, lds);
     } else {
         // bias + ReLU + squared error + dP; per-cell SE reduced over the 32 lanes that share a row.
         float* rowsum = lds;  // [WGN][BM] scratch: the operand tiles are dead after the final barrier
@@ -1462,9 +1478,51 @@ extern "C" size_t mmvae_gemm_workspace_bytes(int layout, int M, int N, int K, in
     return splitk > 1 ? (size_t)splitk * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
+static int gemm_f32_impl(int layout, int M, int N, int K, float alpha, const float* A, int64_t lda, const float* B,
+                         int64_t ldb, float* C, int64_t ldc, const float* bias, unsigned flags, int splitk,
+                         float* workspace, size_t workspace_bytes, float* sq_partials, int64_t sq_capacity,
+                         mmvae_stream_t stream);
+
 extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, const float* A, int64_t lda,
                               const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, unsigned flags,
                               int splitk, float* workspace, size_t workspace_bytes, mmvae_stream_t stream) {
+    return gemm_f32_impl(layout, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, flags, splitk, workspace,
+                         workspace_bytes, nullptr, 0, stream);
+}
+
+// Tiles of the unsplit launch the library would make for this shape (= partial sums mmvae_gemm_f32_sq writes).
+static int sq_tiles(int layout, int M, int N, int K, bool aligned2) {
+    int tile_id, sk;
+    plan(layout, M, N, K, &tile_id, &sk);
+    if (sk != 1) return 0;
+    if (g_precision == MMVAE_GEMM_PRECISION_BF16X3 && tile_id != 2)
+        tile_id = (aligned2 && K % X3_BK == 0) ? x3_tile_for(M, N, true) : 3;
+    const TileShape ts = tile_shape(layout, tile_id);
+    return ceil_div_i(M, ts.bm) * ceil_div_i(N, ts.bn);
+}
+
+extern "C" int mmvae_gemm_sq_partials(int layout, int M, int N, int K, int operands_regular) {
+    if (layout < 0 || layout > 2 || M <= 0 || N <= 0 || K <= 0) return 0;
+    // the tile shape depends on operand alignment: exact when the caller vouches for 16-byte-regular operands
+    // (aligned bases, leading dimensions and M, N, K multiples of 4), otherwise the larger of the two counts (the
+    // launch zero-fills the slots it does not use)
+    const int a = sq_tiles(layout, M, N, K, true), b = sq_tiles(layout, M, N, K, false);
+    if (operands_regular && (M | N | K) % 4 == 0) return a;
+    return a > b ? a : b;
+}
+
+extern "C" int mmvae_gemm_f32_sq(int layout, int M, int N, int K, float alpha, const float* A, int64_t lda,
+                                 const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, unsigned flags,
+                                 float* sq_partials, int64_t sq_capacity, mmvae_stream_t stream) {
+    if (!sq_partials || sq_capacity <= 0 || (flags & MMVAE_GEMM_RAW_SLABS)) return MMVAE_ERR_ARG;
+    return gemm_f32_impl(layout, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, flags, 1, nullptr, 0, sq_partials,
+                         sq_capacity, stream);
+}
+
+static int gemm_f32_impl(int layout, int M, int N, int K, float alpha, const float* A, int64_t lda, const float* B,
+                         int64_t ldb, float* C, int64_t ldc, const float* bias, unsigned flags, int splitk,
+                         float* workspace, size_t workspace_bytes, float* sq_partials, int64_t sq_capacity,
+                         mmvae_stream_t stream) {
     if (layout < 0 || layout > 2 || M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return MMVAE_ERR_ARG;
     if (splitk < 0 || ldc < N) return MMVAE_ERR_ARG;
     // leading-dimension sanity: contiguous axis extent must fit in the stride
@@ -1522,6 +1580,14 @@ extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, cons
     }
     g.c_vec = aligned16(g.C) && g.ldc % 4 == 0 && N % 4 == 0 && (g.slab_stride % 4 == 0) &&
               (!bias || aligned16(bias)) ? 1 : 0;
+    if (sq_partials) {  // fused sum of squares: one partial per output tile, the rest of the caller's slots zeroed
+        if (splitk != 1 || (int64_t)g.mt * g.nt > sq_capacity) return MMVAE_ERR_ARG;
+        g.sq_part = sq_partials;
+        if ((int64_t)g.mt * g.nt < sq_capacity &&
+            hipMemsetAsync(sq_partials + (int64_t)g.mt * g.nt, 0, (size_t)(sq_capacity - (int64_t)g.mt * g.nt) * sizeof(float),
+                           s) != hipSuccess)
+            return MMVAE_ERR_LAUNCH;
+    }
     const int nblocks = g.mt * g.nt * splitk;
     int rc;
     if (layout == MMVAE_GEMM_NT)

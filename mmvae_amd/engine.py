@@ -114,6 +114,7 @@ class StepEngine:
         # weight-gradient GEMMs run on a side stream inside the captured graph (fork/join edges)
         self.batch_finish = os.environ.get("MMVAE_BATCH_FINISH", "1") != "0"
         self.batch_gemms = os.environ.get("MMVAE_BATCH_GEMMS", "1") != "0"
+        self.fuse_sqnorm = os.environ.get("MMVAE_FUSE_SQNORM", "1") != "0"
         if os.environ.get("MMVAE_SIDE_STREAM", "0") != "0":
             side_stream = True
         self.side_stream = torch.cuda.Stream(device=self.device) if side_stream else None
@@ -148,6 +149,21 @@ class StepEngine:
 
     def grad_of(self, p: torch.Tensor) -> torch.Tensor:
         return self._grad_of[id(p)]
+
+    def locate_grad(self, t: torch.Tensor):
+        """(optimiser, element offset) of a gradient-arena view, or None."""
+        for opt in self.model.optimizers():
+            g = opt.arena.grad
+            d = t.data_ptr() - g.data_ptr()
+            if 0 <= d < 4 * g.numel():
+                return opt, d // 4
+        return None
+
+    def sq_buffer(self, opt) -> torch.Tensor:
+        """Norm-partial slots of one optimiser when GEMM epilogues contribute (fused partials first, then the norm
+        pass's chunk partials of the uncovered ranges)."""
+        n = int(self.lib.mmvae_sqnorm_partials(opt.arena.numel)) + 4096 + 64
+        return self.buf(f"sqparts.{id(opt)}", (n,))
 
     def flush(self) -> None:
         """Make the current stream wait for every deferred expert update (before parameters are read elsewhere)."""
@@ -302,6 +318,8 @@ class _Plan:
         self.metric_slots: Dict[str, int] = {}
         self.segments: List = []  # list of closure lists, separated by ("allreduce", opt) markers
         self._cur: List = []
+        self._sq_used: Dict[int, int] = {}    # per optimiser: norm-partial slots taken by fused GEMM epilogues
+        self._sq_cover: Dict[int, list] = {}  # per optimiser: (offset, length) of the arena ranges they cover
         self._gemm_jobs: List = []     # small weight-gradient GEMMs queued for the next mmvae_gemm_batch_f32 launch
         self._sum_jobs: List = []      # reductions queued for the next mmvae_sum_parts_batch launch
         self._sum_keep: List = []
@@ -345,6 +363,40 @@ class _Plan:
         self.lib.mmvae_gemm_plan(layout, M, N, K, C.byref(tile), C.byref(sk))
         return sk.value
 
+    def _fuse_sqnorm(self, layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags) -> bool:
+        """Unsplit weight-gradient GEMM straight into a gradient arena: let its epilogue also leave the partial sums of
+        squares of what it stores (mmvae_gemm_f32_sq), so that the clip's norm pass does not read the 82 MB back.  Only
+        without a gradient exchange: under data parallelism the norm is that of the REDUCED gradients."""
+        eng = self.eng
+        if not eng.fuse_sqnorm or eng.overlap or eng.world > 1 or ldc != N or (flags & ~ACC):
+            return False
+        regular = int(_p(A) % 16 == 0 and _p(Bm) % 16 == 0 and lda % 4 == 0 and ldb % 4 == 0)
+        n_part = self.lib.mmvae_gemm_sq_partials(layout, M, N, K, regular)
+        if n_part <= 0:
+            return False
+        hit = eng.locate_grad(Cm)
+        if hit is None:
+            return False
+        opt, off = hit
+        if opt.reducer is not None:
+            return False
+        buf = eng.sq_buffer(opt)
+        base = self._sq_used.get(id(opt), 0)
+        if base + n_part > 4096:
+            return False
+        self._sq_used[id(opt)] = base + n_part
+        self._sq_cover.setdefault(id(opt), []).append((off, M * N))
+        plan = self
+
+        def call():
+            rc = plan.lib.mmvae_gemm_f32_sq(layout, M, N, K, alpha, _p(A), lda, _p(Bm), ldb, _p(Cm), ldc, _p(bias), flags,
+                                            buf.data_ptr() + 4 * base, n_part, _s())
+            if rc != 0:
+                raise _lib.HipLibraryError(f"mmvae_gemm_f32_sq failed with code {rc} (layout {layout}, {M}x{N}x{K})")
+
+        self._cur.append(call)
+        return True
+
     def _queue_gemm(self, layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags) -> bool:
         """Weight-gradient GEMMs of the core layers (the planner's 64x64-tile class) are independent of each other and
         only feed the optimiser: queue them for ONE grouped launch (_flush_gemms) instead of a launch each."""
@@ -384,6 +436,8 @@ class _Plan:
             slabs = self.eng.buf(f"dwslabs.{self._next_defer_id()}", (sk, M, N))
             self._emit_gemm(layout, M, N, K, 1.0, A, lda, Bm, ldb, slabs, N, None, RAW, sk, False)
             self._defer_sum(slabs, sk, M * N, M, N, N, Cm, ldc, alpha, flags & ACC)
+            return
+        if side and sk == 1 and self._fuse_sqnorm(layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags):
             return
         nbytes = self.lib.mmvae_gemm_workspace_bytes(layout, M, N, K, sk)
         if side and self.eng.side_stream is not None and M * N <= self.eng.side_max_elems:
@@ -576,9 +630,24 @@ class _Plan:
         npart = self.lib.mmvae_sqnorm_partials(a.numel)
         if opt.reducer is not None or self.eng.overlap:
             self._cut(("ar_" + exchange, opt))
-        self._emit(self.lib.mmvae_grad_sqnorm, a.numel, _p(a.grad), _p(opt.partials))
+        cover = sorted(self._sq_cover.pop(id(opt), []))
+        if cover:
+            # the fused GEMM epilogues have left the partials of the ranges they wrote; the norm pass runs over the
+            # rest of the arena only, into the slots behind them; adam_prepare sums them all (fp64, slot order)
+            buf = self.eng.sq_buffer(opt)
+            slot, pos = self._sq_used.pop(id(opt)), 0
+            for off, n in cover + [(a.numel, 0)]:
+                if off > pos:
+                    self._emit(self.lib.mmvae_grad_sqnorm, off - pos, a.grad.data_ptr() + 4 * pos, buf.data_ptr() + 4 * slot)
+                    slot += self.lib.mmvae_sqnorm_partials(off - pos)
+                pos = max(pos, off + n)
+            assert slot <= buf.numel()
+            npart, partials = slot, buf
+        else:
+            self._emit(self.lib.mmvae_grad_sqnorm, a.numel, _p(a.grad), _p(opt.partials))
+            partials = opt.partials
         flags = _lib.PREPARE_NORM | (_lib.PREPARE_ADVANCE if (advance and step) else 0)
-        self._emit(self.lib.mmvae_adam_prepare, npart, _p(opt.partials), max_norm, gs, b1, b2, _p(opt.state_dev), flags)
+        self._emit(self.lib.mmvae_adam_prepare, npart, _p(partials), max_norm, gs, b1, b2, _p(opt.state_dev), flags)
         if step:
             self._emit(self.lib.mmvae_adam_step, a.numel, _p(a.data), _p(a.grad), _p(a.exp_avg), _p(a.exp_avg_sq),
                        _p(opt.state_dev), g["lr"], b1, b2, g["eps"], g["weight_decay"], gs)

@@ -121,6 +121,28 @@ def gemm(
     return out
 
 
+def gemm_sq(layout: int, a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None,
+            bias: Optional[torch.Tensor] = None, alpha: float = 1.0, accumulate: bool = False):
+    """Unsplit GEMM (as gemm()) that also returns the per-tile partial sums of squares of what it stored
+    (mmvae_gemm_f32_sq): (out, partials) with partials.sum() == (out ** 2).sum() up to fp32 rounding."""
+    lib = _lib.load()
+    _chk(a, "a"), _chk(b, "b"), _chk(bias, "bias")
+    ar, ac, lda = _mat(a, "a")
+    br, bc, ldb = _mat(b, "b")
+    M, K, N = (ar, ac, br) if layout == GEMM_NT else (ar, ac, bc) if layout == GEMM_NN else (ac, ar, bc)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _chk(out, "out")
+    n = lib.mmvae_gemm_sq_partials(layout, M, N, K, 0)
+    if n <= 0:
+        raise ValueError("gemm_sq: this shape is planned as a split-K launch")
+    partials = torch.empty(n, dtype=torch.float32, device=a.device)
+    flags = GEMM_ACCUMULATE if accumulate else 0
+    _lib.check(lib.mmvae_gemm_f32_sq(layout, M, N, K, alpha, _ptr(a), lda, _ptr(b), ldb, _ptr(out), _mat(out, "out")[2],
+                                     _ptr(bias), flags, _ptr(partials), n, _stream()), "mmvae_gemm_f32_sq")
+    return out, partials
+
+
 def gemm_slabs(layout: int, a: torch.Tensor, b: torch.Tensor, splitk: int = 0) -> torch.Tensor:
     """Raw split-K partial products [S, M, N] (no epilogue), to be summed by fc_epilogue_fwd / _bwd."""
     lib = _lib.load()

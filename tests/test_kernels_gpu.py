@@ -441,3 +441,21 @@ def test_csr_to_dense(ops, B, G, density):
     base = torch.full((B, G + 3), 7.0, device="cuda")
     ops.csr_to_dense(x.cuda(), out=base[:, :G])  # unaligned leading dimension: scalar zero fill
     assert torch.equal(base[:, :G].cpu(), d) and bool((base[:, G:] == 7.0).all())
+
+
+@pytest.mark.parametrize("layout,M,N,K", [(2, 1024, 20000, 64), (2, 20000, 1024, 32), (0, 512, 20000, 96),
+                                           (2, 2048, 2004, 40), (1, 640, 20000, 64)])
+def test_gemm_with_fused_sum_of_squares(ops, layout, M, N, K):
+    """mmvae_gemm_f32_sq: same product as mmvae_gemm_f32 (bitwise) plus per-tile partial sums of squares of the stored
+    values whose total is the squared Frobenius norm (rtol 1e-5: fp32 partials, any tile shape the planner picks)."""
+    a, b = rnd(M, K, seed=11), rnd(K, N, seed=12)
+    A = a if layout != 2 else a.t().contiguous()
+    Bm = b.t().contiguous() if layout == 0 else b
+    ref = ops.gemm(layout, dev(A), dev(Bm), alpha=0.5, splitk=1)
+    out, parts = ops.gemm_sq(layout, dev(A), dev(Bm), alpha=0.5)
+    assert torch.equal(out, ref)
+    total = float(parts.double().sum())
+    want = float((ref.double() ** 2).sum())
+    assert abs(total - want) <= 1e-5 * want, (total, want)
+    out2, parts2 = ops.gemm_sq(layout, dev(A), dev(Bm), alpha=0.5)
+    assert torch.equal(parts, parts2), "partials must be bitwise reproducible"
