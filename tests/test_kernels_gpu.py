@@ -288,7 +288,7 @@ def test_elbo_finalize(ops, K):
     torch.testing.assert_close(w.cpu().double(), wref.double(), rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("B,C", [(16, 2), (33, 8), (64, 273), (32, 4644)])
+@pytest.mark.parametrize("B,C", [(16, 2), (33, 8), (64, 273), (32, 4644), (512, 4644), (33, 1027), (16, 8192), (7, 8193)])
 def test_cross_entropy(ops, B, C):
     logits = rnd(B, C, seed=1, scale=2.0).requires_grad_(True)
     y = torch.randint(0, C, (B,), generator=torch.Generator().manual_seed(2))
