@@ -253,6 +253,23 @@ int mmvae_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, 
                     float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                     mmvae_stream_t stream);
 
+/* Adam over a list of arena segments in ONE launch (one workgroup per job): the update of a conditional-layer model
+ * touches only the parameter tensors that took part in the step -- torch.optim.Adam skips parameters whose .grad is
+ * None and keeps a step count per parameter (cmmvae_model.py:309-318 with ConditionalLayer parameters, components.py:
+ * 346-351).  A job = up to MMVAE_ADAM_JOB_ELEMS consecutive elements of one tensor with that tensor's own bias
+ * corrections bc1 = 1 - beta1^t, bc2 = 1 - beta2^t; `jobs_dev` is a DEVICE array; the clip coefficient is read from
+ * `state` (mmvae_adam_prepare without MMVAE_PREPARE_ADVANCE). */
+#define MMVAE_ADAM_JOB_ELEMS 16384
+typedef struct {
+    int64_t offset; /* first element (arena index) */
+    int32_t len;    /* elements, <= MMVAE_ADAM_JOB_ELEMS */
+    float bc1, bc2;
+    int32_t reserved;
+} mmvae_adam_job;
+int mmvae_adam_step_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, float* param, const float* grad, float* exp_avg,
+                         float* exp_avg_sq, const float* state, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, float grad_scale, mmvae_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Device RNG (k15): Philox4x32-10 streams for production mode (parity mode passes explicit masks / eps).
  * replaces: nn.Dropout mask draw (components.py:288) and Normal.rsample noise (components.py:801).
@@ -327,6 +344,29 @@ int mmvae_gemm_batch_f32(int n_jobs, const mmvae_gemm_job* jobs_dev, int total_b
  * path densifies straight into the step's input buffer: one pass, 4*B*G bytes written, 16*nnz bytes read. */
 int mmvae_csr_to_dense_f32(int B, int G, int64_t nnz, const int64_t* crow_indices, const int64_t* col_indices,
                            const float* values, float* out, int64_t ldo, mmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Conditional layers: y[b] = W[c_b] x[b] + bias[c_b], the Linear of each cell's OWN condition.
+ * replaces: ConditionalLayer.forward (components.py:365-413: per present condition index_select -> Linear ->
+ * index_copy_) and its autograd, for conditional blocks that are one Linear (LayerNorm: mmvae_layernorm_fwd/bwd).
+ * The condition blocks live in one parameter arena `params` (and `grads` of the same layout); w_off / b_off [C] are
+ * DEVICE int64 element offsets of block c's weight [n_out, n_in] and bias [n_out]; cond [B] is the DEVICE int32
+ * condition index of every cell.
+ *   _fwd      one workgroup per cell.
+ *   _bwd_dx   dx[b] = W[c_b]^T dy[b].
+ *   _bwd_dw   dW[c] = sum_{b in c} dy[b] (x) x[b], db[c] = sum dy[b] for the n_groups conditions PRESENT in the batch:
+ *             group g covers cells rows[group_start[g] .. group_start[g+1]) (DEVICE int32 arrays; cells in batch order
+ *             -> bitwise reproducible, no atomics) of condition group_cond[g]; the block's gradient is overwritten.
+ *             Absent conditions are not touched (their parameters have no gradient this step).
+ * ------------------------------------------------------------------------------------------------------------ */
+int mmvae_cond_linear_fwd(int B, int n_in, int n_out, const float* x, int64_t ldx, const float* params,
+                          const int64_t* w_off, const int64_t* b_off, const int32_t* cond, float* y, int64_t ldy,
+                          mmvae_stream_t stream);
+int mmvae_cond_linear_bwd_dx(int B, int n_in, int n_out, const float* dy, int64_t lddy, const float* params,
+                             const int64_t* w_off, const int32_t* cond, float* dx, int64_t lddx, mmvae_stream_t stream);
+int mmvae_cond_linear_bwd_dw(int n_groups, const int32_t* group_cond, const int32_t* group_start, const int32_t* rows,
+                             int n_in, int n_out, const float* dy, int64_t lddy, const float* x, int64_t ldx,
+                             float* grads, const int64_t* w_off, const int64_t* b_off, mmvae_stream_t stream);
 
 /* Small utilities used by the step engine: y = alpha*x (+ y), fill. */
 int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, float* y, mmvae_stream_t stream);

@@ -411,6 +411,49 @@ __global__ __launch_bounds__(256) void adam_step_kernel(int64_t n, float* __rest
     }
 }
 
+// Adam over a LIST of arena segments, one workgroup per job (a job = at most ADAM_JOB_ELEMS consecutive elements of
+// one parameter tensor, with that tensor's own bias corrections): the optimiser of a conditional-layer model updates
+// only the condition blocks that took part in the step (torch.optim.Adam skips parameters without a gradient and counts
+// steps per parameter) -- hundreds of 128 x 128 blocks out of thousands -- in ONE launch.
+__global__ __launch_bounds__(256) void adam_step_jobs_kernel(const mmvae_adam_job* __restrict__ jobs, float* __restrict__ p,
+                                                             const float* __restrict__ g, float* __restrict__ m,
+                                                             float* __restrict__ v, const float* __restrict__ state,
+                                                             float lr, float b1, float b2, float eps, float wd,
+                                                             float grad_scale) {
+    const mmvae_adam_job job = jobs[blockIdx.x];
+    const float gmul = state[2] * grad_scale;
+    const float step_size = lr / job.bc1;
+    const float inv_bc2_sqrt = 1.f / sqrtf(job.bc2);
+    const int64_t o = job.offset;
+    const int n = job.len;
+    if ((o & 3) == 0) {  // arena tensors start on 16-byte boundaries: 16-byte accesses, scalar tail
+        const int nv = n >> 2;
+        f32x4* pv = reinterpret_cast<f32x4*>(p + o);
+        const f32x4* gv = reinterpret_cast<const f32x4*>(g + o);
+        f32x4* mv = reinterpret_cast<f32x4*>(m + o);
+        f32x4* vv = reinterpret_cast<f32x4*>(v + o);
+        for (int i = threadIdx.x; i < nv; i += 256) {
+            f32x4 pp = pv[i], gg = gv[i], mm = mv[i], vw = vv[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pe = pp[e], me = mm[e], ve = vw[e];
+                adam_one(pe, gg[e], me, ve, gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+                pp[e] = pe;
+                mm[e] = me;
+                vw[e] = ve;
+            }
+            pv[i] = pp;
+            mv[i] = mm;
+            vv[i] = vw;
+        }
+        for (int i = 4 * nv + threadIdx.x; i < n; i += 256)
+            adam_one(p[o + i], g[o + i], m[o + i], v[o + i], gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256)
+            adam_one(p[o + i], g[o + i], m[o + i], v[o + i], gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+    }
+}
+
 // ---------------------------------------------------------------- Philox4x32-10
 struct u32x4 {
     uint32_t x, y, z, w;
@@ -652,6 +695,16 @@ extern "C" int mmvae_adam_step(int64_t n, float* param, const float* grad, float
     const int vec = aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq);
     MMVAE_LAUNCH(adam_step_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream, n, param,
                        grad, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps, weight_decay, grad_scale, vec);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_adam_step_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, float* param, const float* grad,
+                                    float* exp_avg, float* exp_avg_sq, const float* state, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, float grad_scale, mmvae_stream_t stream) {
+    if (n_jobs <= 0 || !jobs_dev || !param || !grad || !exp_avg || !exp_avg_sq || !state) return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(adam_step_jobs_kernel, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, param, grad, exp_avg,
+                 exp_avg_sq, state, lr, beta1, beta2, eps, weight_decay, grad_scale);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }

@@ -95,6 +95,35 @@ class LayerNormFn(torch.autograd.Function):
         return ops.layernorm_bwd(gy.contiguous(), y, invstd), None
 
 
+class CondLinearFn(torch.autograd.Function):
+    """Per-cell conditional Linear, y[b] = W[c_b] x[b] + bias[c_b] (ConditionalLayer.forward, components.py:365-413,
+    for single-Linear condition blocks), on the grouped HIP kernels.  The thousands of condition blocks are not autograd
+    inputs: they are addressed through their offsets in the optimiser's arena (`bank`), and backward writes the
+    gradients of the conditions PRESENT in the batch straight into the gradient arena and tells the optimiser which
+    parameters took part (the others keep "no gradient", like under torch autograd)."""
+
+    @staticmethod
+    def forward(ctx, x, bank, cond_dev, group_cond, group_start, rows, present_params):
+        x2 = x if x.is_contiguous() else x.contiguous()
+        a = bank["opt"].arena
+        y = ops.cond_linear_fwd(x2, a.data, bank["w_off"], bank["b_off"], cond_dev, bank["n_out"])
+        ctx.save_for_backward(x2, cond_dev, group_cond, group_start, rows)
+        ctx.bank, ctx.present_params = bank, present_params
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, cond_dev, group_cond, group_start, rows = ctx.saved_tensors
+        bank = ctx.bank
+        opt = bank["opt"]
+        a = opt.arena
+        gy = gy if gy.is_contiguous() else gy.contiguous()
+        dx = ops.cond_linear_bwd(gy, x, a.data, a.grad, bank["w_off"], bank["b_off"], cond_dev, group_cond, group_start,
+                                 rows)
+        opt.note_direct_grads(ctx.present_params)
+        return dx, None, None, None, None, None, None
+
+
 class ReparamKLFn(torch.autograd.Function):
     """Encoder tail (components.py:795-801) fused with the Gaussian KL of BaseVAE.elbo (modules/vae.py:136-137).
 

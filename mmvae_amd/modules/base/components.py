@@ -14,6 +14,7 @@ import random
 from collections import OrderedDict, defaultdict
 from typing import Callable, List, Literal, Optional, Type, Union
 
+import numpy as np
 import pandas as pd
 import torch
 import torch.nn as nn
@@ -21,6 +22,7 @@ from torch.distributions import Normal
 
 from ... import backend
 from ... import functional as HF
+from ... import optim
 
 GradientReversalFunction = HF.GradientReversalFunction  # components.py:879-899
 
@@ -272,10 +274,61 @@ class ConditionalLayer(nn.Module):
     def format_condition_key(self, condition: str) -> str:
         return condition.replace(".", "_")
 
+    # ---- grouped HIP path (one launch per layer instead of a Python loop over the conditions of the batch)
+    def _bank(self):
+        """Offsets of every condition's weight / bias in the optimiser arena they live in, or None when the blocks are
+        not single Linears (+ LayerNorm) or do not (yet) live in one arena (no optimiser configured: eval-only use)."""
+        bank = getattr(self, "_bank_cache", None)
+        if bank is not None and optim.arena_of(bank["probe"]) is not None and bank["probe"].data_ptr() == bank["probe_ptr"]:
+            return bank
+        blocks = list(self.conditions.values())
+        lins = []
+        for blk in blocks:
+            if len(blk.fc_layers) != 1 or any(n not in ("lin", "ln") for n, _ in blk.fc_layers[0].named_children()):
+                return None
+            lins.append(blk.fc_layers[0].lin)
+        hits = [(optim.arena_of(l.weight), optim.arena_of(l.bias)) for l in lins]
+        if any(h[0] is None or h[1] is None for h in hits):
+            return None
+        opt = hits[0][0][0]
+        if any(h[0][0] is not opt or h[1][0] is not opt for h in hits) or not opt._hip:
+            return None
+        a = opt.arena
+        w_idx = np.array([h[0][1] for h in hits], dtype=np.int64)
+        b_idx = np.array([h[1][1] for h in hits], dtype=np.int64)
+        dev = a.device
+        bank = dict(opt=opt, w_idx=w_idx, b_idx=b_idx, n_in=lins[0].in_features, n_out=lins[0].out_features,
+                    w_off=torch.tensor([a.offsets[i] for i in w_idx], dtype=torch.int64, device=dev),
+                    b_off=torch.tensor([a.offsets[i] for i in b_idx], dtype=torch.int64, device=dev),
+                    index={k: i for i, k in enumerate(self.conditions.keys())},
+                    ln_eps=(blocks[0].fc_layers[0].ln.eps if hasattr(blocks[0].fc_layers[0], "ln") else None),
+                    probe=lins[0].weight, probe_ptr=lins[0].weight.data_ptr())
+        self._bank_cache = bank
+        return bank
+
+    def _forward_grouped(self, bank, x: torch.Tensor, keys: list) -> torch.Tensor:
+        cond = np.fromiter((bank["index"][k] for k in keys), dtype=np.int32, count=len(keys))
+        order = np.argsort(cond, kind="stable").astype(np.int32)  # cells of a condition stay in batch order
+        present, start = np.unique(cond[order], return_index=True)
+        start = np.append(start, len(keys)).astype(np.int32)
+        dev = x.device
+        packed = torch.from_numpy(np.concatenate([cond, order, present.astype(np.int32), start])).to(dev, non_blocking=True)
+        B, P = len(keys), len(present)
+        cond_dev, rows, group_cond, group_start = packed[:B], packed[B:2 * B], packed[2 * B:2 * B + P], packed[2 * B + P:]
+        present_params = np.concatenate([bank["w_idx"][present], bank["b_idx"][present]])
+        y = HF.CondLinearFn.apply(x, bank, cond_dev, group_cond, group_start, rows, present_params)
+        if bank["ln_eps"] is not None:
+            y = HF.LayerNormFn.apply(y, bank["ln_eps"])
+        return y
+
     def forward(self, x: torch.Tensor, metadata: pd.DataFrame, condition: Optional[str] = None):
         if condition:
             return self.conditions[self.format_condition_key(condition)](x)
         keys = metadata[self.batch_key].astype(str).apply(self.format_condition_key).tolist()
+        if x.is_cuda and os.environ.get("MMVAE_COND_GROUPED", "1") != "0":
+            bank = self._bank()
+            if bank is not None:
+                return self._forward_grouped(bank, x, keys)
         groups: "OrderedDict[str, list]" = OrderedDict()
         for row, key in enumerate(keys):
             groups.setdefault(key, []).append(row)

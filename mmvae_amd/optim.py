@@ -58,19 +58,37 @@ class ParamArena:
     def grad_view(self, i: int) -> torch.Tensor:
         return self.view(self.grad, i)
 
-    def gather_grads(self) -> List[int]:
+    def gather_grads(self, direct=(), zeroed: bool = False) -> List[int]:
         """Bring autograd-produced .grad tensors into the gradient arena (D2D copies; no-ops for arena views).
         Returns the indices of the parameters WITHOUT a gradient (their arena slice is zeroed, so the global norm is
         right, and the optimiser skips them like torch.optim.Adam skips `p.grad is None`)."""
         inactive = []
         for i, p in enumerate(self.params):
-            gv = self.grad_view(i)
+            if i in direct:  # written in place by a kernel
+                continue
             if p.grad is None:
-                gv.zero_()
+                if not zeroed:  # `zeroed`: the whole gradient arena was cleared by zero_grad()
+                    self.grad_view(i).zero_()
                 inactive.append(i)
-            elif p.grad.data_ptr() != gv.data_ptr():
+                continue
+            gv = self.grad_view(i)
+            if p.grad.data_ptr() != gv.data_ptr():
                 gv.copy_(p.grad)
         return inactive
+
+
+# parameter -> (optimiser, index in its arena): lets kernels that address parameters through arena offsets (the grouped
+# conditional layers) find the arena a parameter lives in.  Keyed by id(); entries are validated against the live
+# object on lookup.
+_ARENA_OF: Dict[int, tuple] = {}
+
+
+def arena_of(p: torch.nn.Parameter):
+    """(HipAdam, index) of a parameter that lives in a flat arena, else None."""
+    hit = _ARENA_OF.get(id(p))
+    if hit is None or hit[0].arena.params[hit[1]] is not p:
+        return None
+    return hit
 
 
 class HipAdam(torch.optim.Optimizer):
@@ -83,6 +101,9 @@ class HipAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.arena = ParamArena(params)
+        for i, p in enumerate(self.arena.params):
+            _ARENA_OF[id(p)] = (self, i)
+        self._direct: set = set()  # parameters whose gradient a kernel wrote straight into the arena this step
         self.max_grad_norm = max_grad_norm
         self.grad_scale = 1.0  # 1 / world_size under DDP (gradient averaging)
         self.reducer = None  # mmvae_amd.dist.GradAllReducer under DDP
@@ -112,7 +133,7 @@ class HipAdam(torch.optim.Optimizer):
     def compute_grad_norm(self) -> torch.Tensor:
         """Gather grads into the arena and compute their global L2 norm (device scalar).  step() reuses it."""
         a = self.arena
-        self._inactive = a.gather_grads()
+        self._inactive = a.gather_grads(self._direct, getattr(self, "_zeroed", False))
         self._allreduce()
         if self._hip:
             b1, b2 = self.param_groups[0]["betas"]
@@ -129,11 +150,22 @@ class HipAdam(torch.optim.Optimizer):
             self.reducer.launch(self.arena.grad)
             self.reducer.wait()
 
+    def note_direct_grads(self, indices) -> None:
+        """The gradients of these parameters (arena indices) were written straight into the gradient arena by a kernel
+        (no autograd .grad tensor exists): they count as present in this step."""
+        self._direct.update(int(i) for i in indices)
+
     def zero_grad(self, set_to_none: bool = True) -> None:
         self._norm_valid = False
+        self._direct.clear()
         for p in self.arena.params:
             p.grad = None
-        # the arena itself needs no clearing: every live gradient is overwritten before it is read
+        # Arenas of conditional-layer models hold thousands of tensors of which a step touches a few: one memset of the
+        # gradient arena here replaces a zeroing launch per untouched tensor in gather_grads.  Plain arenas need no
+        # clearing: every live gradient is overwritten before it is read.
+        self._zeroed = len(self.arena.params) > 64
+        if self._zeroed:
+            self.arena.grad.zero_()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -142,7 +174,7 @@ class HipAdam(torch.optim.Optimizer):
         a = self.arena
         reuse = getattr(self, "_norm_valid", False)
         if not reuse:
-            self._inactive = a.gather_grads()
+            self._inactive = a.gather_grads(self._direct, getattr(self, "_zeroed", False))
             self._allreduce()
         g = self.param_groups[0]
         b1, b2 = g["betas"]
@@ -160,14 +192,14 @@ class HipAdam(torch.optim.Optimizer):
         """A step in which some parameters have no gradient, or after such a step: torch.optim.Adam semantics --
         parameters without a gradient are left untouched (no moment decay, no weight decay) and every parameter uses
         the bias corrections of its OWN step count.  The global norm / clip coefficient come from the whole arena (the
-        skipped slices are zero); the update is applied per parameter tensor (one launch each: this is the correctness
-        path of conditional-layer models, not a fast path)."""
+        skipped slices are zero); the update runs over a job table of the tensors that took part, in one launch
+        (mmvae_adam_step_jobs)."""
         import numpy as np
 
         a = self.arena
         n = len(a.params)
         if self._steps is None:
-            self._steps = [int(round(float(self.state_dev[0])))] * n
+            self._steps = np.full(n, int(round(float(self.state_dev[0]))), dtype=np.int64)
         skip = set(self._inactive)
         if self._hip:
             # norm (unless compute_grad_norm() just produced it) and the clip coefficient for the CURRENT max_grad_norm
@@ -183,39 +215,48 @@ class HipAdam(torch.optim.Optimizer):
             if self.max_grad_norm:
                 clip = min(1.0, float(self.max_grad_norm) / (float(norm) + 1e-6))
             self.state_dev[1], self.state_dev[2] = norm, clip
-        groups: Dict[int, List[int]] = {}
-        for i in range(n):
-            if i not in skip:
-                groups.setdefault(self._steps[i] + 1, []).append(i)
-        lib = None
+        active = np.setdiff1d(np.arange(n), np.fromiter(skip, dtype=np.int64, count=len(skip)), assume_unique=True)
+        steps = np.asarray(self._steps, dtype=np.int64)
+        t_act = steps[active] + 1
+        bc1 = (np.float32(1.0) - np.power(np.float32(b1), t_act.astype(np.float32))).astype(np.float32)
+        bc2 = (np.float32(1.0) - np.power(np.float32(b2), t_act.astype(np.float32))).astype(np.float32)
         if self._hip:
+            # one launch for every tensor that took part: a job per <= 16384-element chunk, carrying the tensor's own
+            # bias corrections (mmvae_adam_step_jobs)
             from . import _lib
 
+            off = np.asarray(a.offsets, dtype=np.int64)[active]
+            num = np.fromiter((a.params[i].numel() for i in active), dtype=np.int64, count=len(active))
+            J = 16384
+            nchunk = (num + J - 1) // J
+            owner = np.repeat(np.arange(len(active)), nchunk)
+            first = np.cumsum(nchunk) - nchunk
+            k = np.arange(int(nchunk.sum())) - first[owner]
+            jobs = np.zeros(len(owner), dtype=np.dtype([("offset", "<i8"), ("len", "<i4"), ("bc1", "<f4"), ("bc2", "<f4"),
+                                                        ("reserved", "<i4")]))
+            jobs["offset"] = off[owner] + k * J
+            jobs["len"] = np.minimum(num[owner] - k * J, J)
+            jobs["bc1"], jobs["bc2"] = bc1[owner], bc2[owner]
+            jobs_dev = torch.from_numpy(jobs.view(np.uint8)).to(a.device, non_blocking=False)
             lib = _lib.load()
-            st = torch.empty_like(self.state_dev)
-            stream = torch.cuda.current_stream().cuda_stream
-        for t, idxs in groups.items():
-            bc1 = float(np.float32(1.0) - np.float32(b1) ** np.float32(t))
-            bc2 = float(np.float32(1.0) - np.float32(b2) ** np.float32(t))
-            if self._hip:
-                st.copy_(self.state_dev)
-                st[0], st[3], st[4] = float(t), bc1, bc2
-            for i in idxs:
-                p, off = a.params[i], a.offsets[i]
-                sl = slice(off, off + p.numel())
-                if self._hip:
-                    rc = lib.mmvae_adam_step(p.numel(), a.data[sl].data_ptr(), a.grad[sl].data_ptr(),
-                                             a.exp_avg[sl].data_ptr(), a.exp_avg_sq[sl].data_ptr(), st.data_ptr(), g["lr"],
-                                             b1, b2, g["eps"], g["weight_decay"], float(self.grad_scale), stream)
-                    _lib.check(rc, "mmvae_adam_step")
-                else:
-                    gr = a.grad[sl] * self.grad_scale * float(clip) + g["weight_decay"] * a.data[sl]
-                    a.exp_avg[sl].lerp_(gr, 1 - b1)
-                    a.exp_avg_sq[sl].mul_(b2).addcmul_(gr, gr, value=1 - b2)
-                    denom = a.exp_avg_sq[sl].sqrt() / (bc2 ** 0.5) + g["eps"]
-                    a.data[sl].addcdiv_(a.exp_avg[sl], denom, value=-g["lr"] / bc1)
-                self._steps[i] = t
-        self.state_dev[0] = float(max(self._steps))
+            rc = lib.mmvae_adam_step_jobs(len(jobs), jobs_dev.data_ptr(), a.data.data_ptr(), a.grad.data_ptr(),
+                                          a.exp_avg.data_ptr(), a.exp_avg_sq.data_ptr(), self.state_dev.data_ptr(),
+                                          g["lr"], b1, b2, g["eps"], g["weight_decay"], float(self.grad_scale),
+                                          torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "mmvae_adam_step_jobs")
+            self._keep_jobs = jobs_dev  # outlives the launch
+        else:
+            for j, i in enumerate(active):
+                p, o = a.params[i], a.offsets[i]
+                sl = slice(o, o + p.numel())
+                gr = a.grad[sl] * self.grad_scale * float(clip) + g["weight_decay"] * a.data[sl]
+                a.exp_avg[sl].lerp_(gr, 1 - b1)
+                a.exp_avg_sq[sl].mul_(b2).addcmul_(gr, gr, value=1 - b2)
+                denom = a.exp_avg_sq[sl].sqrt() / (float(bc2[j]) ** 0.5) + g["eps"]
+                a.data[sl].addcdiv_(a.exp_avg[sl], denom, value=-g["lr"] / float(bc1[j]))
+        steps[active] = t_act
+        self._steps = steps
+        self.state_dev[0] = float(self._steps.max())
         self._norm_valid = False
 
     def _step_cpu_plumbing(self, g, b1, b2):
@@ -256,7 +297,7 @@ class HipAdam(torch.optim.Optimizer):
         if steps:
             self.state_dev[0] = float(max(steps.values()))
             uniform = len(set(steps.values())) == 1 and len(steps) == len(a.params)
-            self._steps = None if uniform else [steps.get(i, 0) for i in range(len(a.params))]
+            self._steps = None if uniform else np.array([steps.get(i, 0) for i in range(len(a.params))], dtype=np.int64)
         for k, v in sd["param_groups"][0].items():
             if k != "params":
                 self.param_groups[0][k] = v

@@ -459,3 +459,50 @@ def test_gemm_with_fused_sum_of_squares(ops, layout, M, N, K):
     assert abs(total - want) <= 1e-5 * want, (total, want)
     out2, parts2 = ops.gemm_sq(layout, dev(A), dev(Bm), alpha=0.5)
     assert torch.equal(parts, parts2), "partials must be bitwise reproducible"
+
+
+# ------------------------------------------------------------------------------------------ conditional layers (f2)
+@pytest.mark.parametrize("B,n_in,n_out,C", [(512, 128, 128, 37), (33, 8, 8, 5), (64, 24, 40, 200), (16, 300, 260, 3)])
+def test_cond_linear_fwd_bwd(ops, B, n_in, n_out, C):
+    """Per-cell conditional Linear against a per-condition torch loop (the reference's ConditionalLayer.forward):
+    forward / dx to 1e-5, dW / db of the present conditions to 1e-5, absent conditions untouched."""
+    g = torch.Generator().manual_seed(B + C)
+    x = torch.randn(B, n_in, generator=g)
+    dy = torch.randn(B, n_out, generator=g)
+    cond = torch.randint(0, C, (B,), generator=g)
+    # arena: blocks in shuffled order with gaps, weight and bias of a block not adjacent
+    sizes = n_out * n_in + 12, n_out + 4
+    perm = torch.randperm(C, generator=g).tolist()
+    w_off, b_off, pos = [0] * C, [0] * C, 8
+    for c in perm:
+        w_off[c] = pos
+        pos += sizes[0]
+    for c in perm:
+        b_off[c] = pos
+        pos += sizes[1]
+    params = torch.randn(pos, generator=g) * 0.3
+    W = torch.stack([params[w_off[c]:w_off[c] + n_out * n_in].view(n_out, n_in) for c in range(C)])
+    bias = torch.stack([params[b_off[c]:b_off[c] + n_out] for c in range(C)])
+    y_ref = torch.einsum("boi,bi->bo", W[cond], x) + bias[cond]
+    dx_ref = torch.einsum("boi,bo->bi", W[cond], dy)
+    order = torch.argsort(cond, stable=True)
+    present, counts = torch.unique_consecutive(cond[order], return_counts=True)
+    start = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)])
+    dv = lambda t, dt: t.to(dt).cuda()
+    P, G = params.cuda(), torch.full((pos,), 7.0, device="cuda")
+    wo, bo, cd = dv(torch.tensor(w_off), torch.int64), dv(torch.tensor(b_off), torch.int64), dv(cond, torch.int32)
+    y = ops.cond_linear_fwd(dev(x), P, wo, bo, cd, n_out)
+    assert rel_l2(y, y_ref) < 1e-5
+    dx = ops.cond_linear_bwd(dev(dy), dev(x), P, G, wo, bo, cd, dv(present, torch.int32), dv(start, torch.int32),
+                             dv(order, torch.int32))
+    assert rel_l2(dx, dx_ref) < 1e-5
+    Gc = G.cpu()
+    touched = torch.zeros(pos, dtype=torch.bool)
+    for c in present.tolist():
+        rows = (cond == c).nonzero().flatten()
+        dW_ref = dy[rows].t() @ x[rows]
+        assert rel_l2(Gc[w_off[c]:w_off[c] + n_out * n_in].view(n_out, n_in), dW_ref) < 1e-5
+        assert rel_l2(Gc[b_off[c]:b_off[c] + n_out], dy[rows].sum(0)) < 1e-5
+        touched[w_off[c]:w_off[c] + n_out * n_in] = True
+        touched[b_off[c]:b_off[c] + n_out] = True
+    assert bool((Gc[~touched] == 7.0).all()), "gradients of absent conditions (and the gaps) must not be written"
