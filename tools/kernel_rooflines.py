@@ -22,7 +22,9 @@ TABLE = [
     ("gemm_x3_kernel<0; 1; 128; 128", "dX dec-L2 split-K 16 (NN 128x128, bf16x3)", "x3", GF),
     ("adam_step_kernel", "clip + Adam over the flat arenas (expert 41 M + VAE 0.36 M params, 28 B each)", "hbm",
      28.0 * (P_EXP + 0.36e6) / 2),  # two launches per step: averaged
-    ("sqnorm_kernel", "gradient sum of squares (4 B per parameter)", "hbm", 4.0 * (P_EXP + 0.36e6) / 2),
+    # since r1c the G-wide weight gradients leave their norm partials in the GEMM epilogue: the pass covers the rest
+    ("sqnorm_kernel", "gradient sum of squares of the ranges no GEMM epilogue covers (~1.5 M floats, 3 launches)",
+     "hbm", None),
     ("gemm_f32_batch_kernel", "7 core-layer weight-gradient GEMMs in one grid (exact f32)", "f32",
      2.0 * B * (2 * H1 * H2 + 2 * H2 * V + 2 * V * Z + 2 * V * Z)),
     ("fc_bwd_stats_kernel<false>", "column sums / bias gradients (largest: dP 512 x 20000)", "hbm", None),
