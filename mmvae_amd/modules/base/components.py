@@ -300,14 +300,25 @@ class ConditionalLayer(nn.Module):
         bank = dict(opt=opt, w_idx=w_idx, b_idx=b_idx, n_in=lins[0].in_features, n_out=lins[0].out_features,
                     w_off=torch.tensor([a.offsets[i] for i in w_idx], dtype=torch.int64, device=dev),
                     b_off=torch.tensor([a.offsets[i] for i in b_idx], dtype=torch.int64, device=dev),
-                    index={k: i for i, k in enumerate(self.conditions.keys())},
+                    index={k: i for i, k in enumerate(self.conditions.keys())}, raw_index={},
                     ln_eps=(blocks[0].fc_layers[0].ln.eps if hasattr(blocks[0].fc_layers[0], "ln") else None),
                     probe=lins[0].weight, probe_ptr=lins[0].weight.data_ptr())
+        opt.managed.update(int(i) for i in w_idx)  # gradients of these never arrive as autograd .grad tensors
+        opt.managed.update(int(i) for i in b_idx)
         self._bank_cache = bank
         return bank
 
-    def _forward_grouped(self, bank, x: torch.Tensor, keys: list) -> torch.Tensor:
-        cond = np.fromiter((bank["index"][k] for k in keys), dtype=np.int32, count=len(keys))
+    def _forward_grouped(self, bank, x: torch.Tensor, column: pd.Series) -> torch.Tensor:
+        # raw metadata value -> condition index, through a cache (formatting + ModuleDict lookup once per distinct value)
+        raw_index = bank["raw_index"]
+        values = column.tolist()
+        try:
+            cond = np.fromiter((raw_index[v] for v in values), dtype=np.int32, count=len(values))
+        except KeyError:
+            for v in set(values) - raw_index.keys():
+                raw_index[v] = bank["index"][self.format_condition_key(str(v))]  # KeyError: unknown condition, as before
+            cond = np.fromiter((raw_index[v] for v in values), dtype=np.int32, count=len(values))
+        keys = values
         order = np.argsort(cond, kind="stable").astype(np.int32)  # cells of a condition stay in batch order
         present, start = np.unique(cond[order], return_index=True)
         start = np.append(start, len(keys)).astype(np.int32)
@@ -324,11 +335,11 @@ class ConditionalLayer(nn.Module):
     def forward(self, x: torch.Tensor, metadata: pd.DataFrame, condition: Optional[str] = None):
         if condition:
             return self.conditions[self.format_condition_key(condition)](x)
-        keys = metadata[self.batch_key].astype(str).apply(self.format_condition_key).tolist()
         if x.is_cuda and os.environ.get("MMVAE_COND_GROUPED", "1") != "0":
             bank = self._bank()
             if bank is not None:
-                return self._forward_grouped(bank, x, keys)
+                return self._forward_grouped(bank, x, metadata[self.batch_key])
+        keys = metadata[self.batch_key].astype(str).apply(self.format_condition_key).tolist()
         groups: "OrderedDict[str, list]" = OrderedDict()
         for row, key in enumerate(keys):
             groups.setdefault(key, []).append(row)

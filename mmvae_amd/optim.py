@@ -58,12 +58,13 @@ class ParamArena:
     def grad_view(self, i: int) -> torch.Tensor:
         return self.view(self.grad, i)
 
-    def gather_grads(self, direct=(), zeroed: bool = False) -> List[int]:
+    def gather_grads(self, direct=(), zeroed: bool = False, only=None) -> List[int]:
         """Bring autograd-produced .grad tensors into the gradient arena (D2D copies; no-ops for arena views).
         Returns the indices of the parameters WITHOUT a gradient (their arena slice is zeroed, so the global norm is
         right, and the optimiser skips them like torch.optim.Adam skips `p.grad is None`)."""
         inactive = []
-        for i, p in enumerate(self.params):
+        for i in (range(len(self.params)) if only is None else only):
+            p = self.params[i]
             if i in direct:  # written in place by a kernel
                 continue
             if p.grad is None:
@@ -104,6 +105,8 @@ class HipAdam(torch.optim.Optimizer):
         for i, p in enumerate(self.arena.params):
             _ARENA_OF[id(p)] = (self, i)
         self._direct: set = set()  # parameters whose gradient a kernel wrote straight into the arena this step
+        self.managed: set = set()  # parameters only ever written that way (condition blocks of the grouped kernels)
+        self._walk = None
         self.max_grad_norm = max_grad_norm
         self.grad_scale = 1.0  # 1 / world_size under DDP (gradient averaging)
         self.reducer = None  # mmvae_amd.dist.GradAllReducer under DDP
@@ -133,7 +136,7 @@ class HipAdam(torch.optim.Optimizer):
     def compute_grad_norm(self) -> torch.Tensor:
         """Gather grads into the arena and compute their global L2 norm (device scalar).  step() reuses it."""
         a = self.arena
-        self._inactive = a.gather_grads(self._direct, getattr(self, "_zeroed", False))
+        self._inactive = self._gather()
         self._allreduce()
         if self._hip:
             b1, b2 = self.param_groups[0]["betas"]
@@ -149,6 +152,21 @@ class HipAdam(torch.optim.Optimizer):
         if self.reducer is not None:
             self.reducer.launch(self.arena.grad)
             self.reducer.wait()
+
+    def _gather(self) -> List[int]:
+        """Autograd gradients into the arena; returns the parameters without a gradient this step.  Parameters managed
+        by the grouped kernels are not walked one by one (thousands of condition blocks): those written this step are
+        present, the rest absent."""
+        zeroed = getattr(self, "_zeroed", False)
+        if not self.managed:
+            return self.arena.gather_grads(self._direct, zeroed)
+        if self._walk is None or len(self._walk) + len(self.managed) != len(self.arena.params):
+            self._walk = [i for i in range(len(self.arena.params)) if i not in self.managed]
+        inactive = self.arena.gather_grads(self._direct, zeroed, only=self._walk)
+        if not zeroed:
+            for i in self.managed - self._direct:
+                self.arena.grad_view(i).zero_()
+        return inactive + sorted(self.managed - self._direct)
 
     def note_direct_grads(self, indices) -> None:
         """The gradients of these parameters (arena indices) were written straight into the gradient arena by a kernel
@@ -174,7 +192,7 @@ class HipAdam(torch.optim.Optimizer):
         a = self.arena
         reuse = getattr(self, "_norm_valid", False)
         if not reuse:
-            self._inactive = a.gather_grads(self._direct, getattr(self, "_zeroed", False))
+            self._inactive = self._gather()
             self._allreduce()
         g = self.param_groups[0]
         b1, b2 = g["betas"]
