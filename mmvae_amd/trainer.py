@@ -99,7 +99,15 @@ class Trainer:
         self.history.append({"stage": "validation", **self._snapshot(model)})
 
     @torch.no_grad()
-    def predict(self, model, batches: Iterable) -> list:
+    def predict(self, model, batches: Iterable, writer=None) -> list:
+        """`predict_step` over the batches; with a `mmvae_amd.predictions.PredictionWriter` every batch is appended
+        to `predictions.h5` as it is produced (the reference's write_interval="batch" callback) and nothing is kept."""
         model.eval()
         model.trainer.set_stage("prediction")
-        return [model.predict_step(batch, i) for i, batch in enumerate(batches)]
+        if writer is None:
+            return [model.predict_step(batch, i) for i, batch in enumerate(batches)]
+        writer.on_predict_start(self, model)
+        for i, batch in enumerate(batches):
+            writer.write_on_batch_end(self, model, model.predict_step(batch, i), None, batch, i, 0)
+        writer.on_predict_epoch_end(self, model)
+        return []

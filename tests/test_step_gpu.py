@@ -102,6 +102,23 @@ def test_eval_and_predict_paths_match_reference(name, use_engine, tmp_path):
         assert H.rel_l2(zz, z["eval/out/z"]) < 2e-5
 
 
+def test_predictions_file_holds_the_reference_embeddings(tmp_path):
+    """SURVEY 8(f4), writer side, end to end: Trainer.predict -> engine predict_step -> predictions.h5; the stored
+    embeddings are the reference's (rel-L2 <= 2e-5) and the metadata rows carry the species written by predict_step."""
+    from mmvae_amd import predictions as P
+    from mmvae_amd.trainer import Trainer
+
+    case, z, model, x, metadata, eid = _trained_mirror("two_mod_odd", str(tmp_path), True)
+    writer = P.PredictionWriter(str(tmp_path), "exp", "run")
+    Trainer().predict(model, [(x, metadata.copy(), eid), (x, metadata.copy(), eid)], writer=writer)
+    data, meta, _ = P.load_from_hdf5(writer.hdf5_filepath, "z")
+    B = x.shape[0]
+    assert data.shape[0] == 2 * B and len(meta) == 2 * B
+    assert H.rel_l2(torch.from_numpy(data[:B]), z["eval/out/embedding_z"]) < 2e-5
+    assert (data[:B] == data[B:]).all()
+    assert set(meta["species"]) == {eid.encode()}
+
+
 @pytest.mark.parametrize("use_engine", [False, True])
 def test_csr_batches_train_like_dense_ones(use_engine, monkeypatch):
     """a `torch.sparse_csr` batch (what the datapipes yield with return_dense: false) is densified by
