@@ -269,6 +269,11 @@ typedef struct {
 int mmvae_adam_step_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, float* param, const float* grad, float* exp_avg,
                          float* exp_avg_sq, const float* state, float lr, float beta1, float beta2, float eps,
                          float weight_decay, float grad_scale, mmvae_stream_t stream);
+/* partials[j] = sum of squares of job j's segment of `grad` (0 for len == 0): the norm pass of such a step, over the
+ * tensors that took part only.  A captured program launches a FIXED n_jobs and pads the table with empty jobs (both
+ * job kernels return at once for them); mmvae_adam_prepare then sums the n_jobs partials. */
+int mmvae_grad_sqnorm_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, const float* grad, float* partials,
+                           mmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Device RNG (k15): Philox4x32-10 streams for production mode (parity mode passes explicit masks / eps).
@@ -352,18 +357,21 @@ int mmvae_csr_to_dense_f32(int B, int G, int64_t nnz, const int64_t* crow_indice
  * The condition blocks live in one parameter arena `params` (and `grads` of the same layout); w_off / b_off [C] are
  * DEVICE int64 element offsets of block c's weight [n_out, n_in] and bias [n_out]; cond [B] is the DEVICE int32
  * condition index of every cell.
- *   _fwd      one workgroup per cell.
+ *   _fwd      one workgroup per cell; with `rows` (DEVICE int32 [B]: the cells sorted by condition, NULL = none) and
+ *             n_in <= 256, one workgroup per 8 sorted cells, which reads a block shared by them once.  Same results.
  *   _bwd_dx   dx[b] = W[c_b]^T dy[b].
  *   _bwd_dw   dW[c] = sum_{b in c} dy[b] (x) x[b], db[c] = sum dy[b] for the n_groups conditions PRESENT in the batch:
  *             group g covers cells rows[group_start[g] .. group_start[g+1]) (DEVICE int32 arrays; cells in batch order
- *             -> bitwise reproducible, no atomics) of condition group_cond[g]; the block's gradient is overwritten.
+ *             -> bitwise reproducible, no atomics) of condition group_cond[g] (< 0: padding, skipped); the block's gradient is
+ *             overwritten; a block is sliced over several workgroups.  n_in + n_out <= 2048.
  *             Absent conditions are not touched (their parameters have no gradient this step).
  * ------------------------------------------------------------------------------------------------------------ */
 int mmvae_cond_linear_fwd(int B, int n_in, int n_out, const float* x, int64_t ldx, const float* params,
-                          const int64_t* w_off, const int64_t* b_off, const int32_t* cond, float* y, int64_t ldy,
-                          mmvae_stream_t stream);
+                          const int64_t* w_off, const int64_t* b_off, const int32_t* cond, const int32_t* rows, float* y,
+                          int64_t ldy, mmvae_stream_t stream);
 int mmvae_cond_linear_bwd_dx(int B, int n_in, int n_out, const float* dy, int64_t lddy, const float* params,
-                             const int64_t* w_off, const int32_t* cond, float* dx, int64_t lddx, mmvae_stream_t stream);
+                             const int64_t* w_off, const int32_t* cond, float* dx, int64_t lddx, int accumulate,
+                             mmvae_stream_t stream);
 int mmvae_cond_linear_bwd_dw(int n_groups, const int32_t* group_cond, const int32_t* group_start, const int32_t* rows,
                              int n_in, int n_out, const float* dy, int64_t lddy, const float* x, int64_t ldx,
                              float* grads, const int64_t* w_off, const int64_t* b_off, mmvae_stream_t stream);

@@ -81,6 +81,7 @@ PROTOTYPES = {
     "mmvae_adam_prepare": (_i, [_l, _p, _f, _f, _f, _f, _p, _u, _p]),
     "mmvae_adam_step": (_i, [_l, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _f, _p]),
     "mmvae_adam_step_jobs": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _f, _p]),
+    "mmvae_grad_sqnorm_jobs": (_i, [_i, _p, _p, _p, _p]),
     "mmvae_philox_keep_mask": (_i, [_l, _f, _p, _p, _u64, _i, _p]),
     "mmvae_philox_normal": (_i, [_l, _p, _p, _u64, _i, _p]),
     "mmvae_philox_advance": (_i, [_p, _u64, _p]),
@@ -90,8 +91,8 @@ PROTOTYPES = {
     "mmvae_gemm_sq_partials": (_i, [_i, _i, _i, _i, _i]),
     "mmvae_gemm_f32_sq": (_i, [_i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _u, _p, _l, _p]),
     "mmvae_csr_to_dense_f32": (_i, [_i, _i, _l, _p, _p, _p, _p, _l, _p]),
-    "mmvae_cond_linear_fwd": (_i, [_i, _i, _i, _p, _l, _p, _p, _p, _p, _p, _l, _p]),
-    "mmvae_cond_linear_bwd_dx": (_i, [_i, _i, _i, _p, _l, _p, _p, _p, _p, _l, _p]),
+    "mmvae_cond_linear_fwd": (_i, [_i, _i, _i, _p, _l, _p, _p, _p, _p, _p, _p, _l, _p]),
+    "mmvae_cond_linear_bwd_dx": (_i, [_i, _i, _i, _p, _l, _p, _p, _p, _p, _l, _i, _p]),
     "mmvae_cond_linear_bwd_dw": (_i, [_i, _p, _p, _p, _i, _i, _p, _l, _p, _l, _p, _p, _p, _p]),
     "mmvae_gemm_batch_job_ok": (_i, [_p]),
     "mmvae_gemm_batch_prepare": (_i, [_i, _p, C.POINTER(_i)]),

@@ -454,6 +454,38 @@ __global__ __launch_bounds__(256) void adam_step_jobs_kernel(const mmvae_adam_jo
     }
 }
 
+// Sum of squares of one job's arena segment -> partials[job] (0 for an empty job): the global norm of a step in which
+// only the listed tensors have a gradient, without reading (or zeroing) the rest of the arena.  Fixed order: thread-
+// strided partial sums, then the wave / workgroup reduction in a fixed tree.
+__global__ __launch_bounds__(256) void sqnorm_jobs_kernel(const mmvae_adam_job* __restrict__ jobs,
+                                                          const float* __restrict__ g, float* __restrict__ partials) {
+    __shared__ float red[4];
+    const mmvae_adam_job job = jobs[blockIdx.x];
+    const int64_t o = job.offset;
+    const int n = job.len;
+    float s = 0.f;
+    if ((o & 3) == 0) {
+        const int nv = n >> 2;
+        const f32x4* gv = reinterpret_cast<const f32x4*>(g + o);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int i = threadIdx.x; i < nv; i += 256) {
+            const f32x4 v = gv[i];
+            s0 += v.x * v.x;
+            s1 += v.y * v.y;
+            s2 += v.z * v.z;
+            s3 += v.w * v.w;
+        }
+        s = (s0 + s1) + (s2 + s3);
+        for (int i = 4 * nv + threadIdx.x; i < n; i += 256) s += g[o + i] * g[o + i];
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) s += g[o + i] * g[o + i];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // ---------------------------------------------------------------- Philox4x32-10
 struct u32x4 {
     uint32_t x, y, z, w;
@@ -705,6 +737,14 @@ extern "C" int mmvae_adam_step_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, 
     if (n_jobs <= 0 || !jobs_dev || !param || !grad || !exp_avg || !exp_avg_sq || !state) return MMVAE_ERR_ARG;
     MMVAE_LAUNCH(adam_step_jobs_kernel, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, param, grad, exp_avg,
                  exp_avg_sq, state, lr, beta1, beta2, eps, weight_decay, grad_scale);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_grad_sqnorm_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, const float* grad, float* partials,
+                                      mmvae_stream_t stream) {
+    if (n_jobs <= 0 || !jobs_dev || !grad || !partials) return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(sqnorm_jobs_kernel, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, grad, partials);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }

@@ -14,7 +14,11 @@ The program is run eagerly once (a real step; loads the code objects), then capt
 no tracing compiler, no per-step allocation, no host read-back (loss scalars stay in a device metrics buffer).
 Per-step host values (KL weight) live in device scalars the kernels read, so the captured graph stays valid.
 Under data parallelism the program is cut at the gradient all-reduce points (RCCL over the flat arenas) into several
-graphs.  Configurations outside this shape (conditional layers, LayerNorm, non-ReLU activations) use the module path.
+graphs.  Conditional layers (CLVAE) run inside the program through the grouped kernels: the per-cell
+condition indices, the per-condition row groups and the optimiser's job table of the blocks that took part are
+per-step HOST values, uploaded into static device tables before the replay (_CondProgram).  Configurations outside this
+shape (LayerNorm / non-ReLU activations in the FC blocks, conditional blocks that are not one Linear, conditional
+layers under data parallelism) use the module path.
 """
 from __future__ import annotations
 
@@ -27,8 +31,8 @@ import torch.nn as nn
 
 from . import _lib, dist as mdist, rng
 from .constants import REGISTRY_KEYS as RK
-from .modules.base.components import Adversarial, FCBlock, _identity
-from .optim import HipAdam
+from .modules.base.components import Adversarial, ConditionalLayer, FCBlock, _identity
+from .optim import HipAdam, arena_of
 
 NT, NN, TN = _lib.GEMM_NT, _lib.GEMM_NN, _lib.GEMM_TN
 RAW = _lib.GEMM_RAW_SLABS
@@ -43,6 +47,32 @@ def _p(t):
 
 def _s():
     return torch.cuda.current_stream().cuda_stream
+
+
+class _PinnedRing:
+    """Page-locked staging slots for per-step host tables.  Pinning a fresh tensor per step costs 0.2-0.8 ms on this
+    runtime (measured; the copy itself is ~4 us to enqueue), so the slots are allocated once and reused round-robin;
+    a slot is rewritten only after the copy that last read it has completed (event)."""
+
+    def __init__(self, numel: int, dtype=torch.int32, slots: int = 4):
+        self.slots = [torch.zeros(numel, dtype=dtype).pin_memory() for _ in range(slots)]
+        self.views = [t.numpy() for t in self.slots]
+        self.events = [None] * slots
+        self.i = 0
+
+    def take(self):
+        """The next slot as a numpy array (its previous upload has completed)."""
+        self.i = (self.i + 1) % len(self.slots)
+        ev = self.events[self.i]
+        if ev is not None:
+            ev.synchronize()
+        return self.views[self.i]
+
+    def upload(self, dst: torch.Tensor) -> None:
+        dst.copy_(self.slots[self.i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[self.i] = ev
 
 
 class _LayerRef:
@@ -77,7 +107,8 @@ class StepEngine:
     @staticmethod
     def try_build(model) -> Optional["StepEngine"]:
         m = model.module
-        if getattr(m.vae, "conditionals", None) is not None:
+        cl = getattr(m.vae, "conditionals", None)
+        if cl is not None and os.environ.get("MMVAE_ENGINE_CONDITIONALS", "1") == "0":
             return None
         if m.vae.encoder.z_transformation is not _identity:
             return None
@@ -94,6 +125,12 @@ class StepEngine:
         opts = model.optimizers()
         if not all(isinstance(o, HipAdam) and o._hip for o in opts):
             return None
+        if cl is not None:
+            # ranks see different conditions: which blocks step is a per-rank fact, the flat exchange is not built for it
+            if mdist.collectives_active() or os.environ.get("MMVAE_DP_OVERLAP", "") == "1":
+                return None
+            if not _CondProgram.supported(cl, model.get_optimizers()["vae"], m.vae.encoder.mean_encoder.out_features):
+                return None
         return StepEngine(model)
 
     def __init__(self, model, side_stream: bool = False, defer_expert_adam: Optional[bool] = None):
@@ -216,7 +253,7 @@ class StepEngine:
             self._klw_host = klw
 
     # ------------------------------------------------------------------------------------- eval / predict (f3)
-    def _forward_only(self, mode: str, x: torch.Tensor, expert_id: str):
+    def _forward_only(self, mode: str, x: torch.Tensor, expert_id: str, metadata=None):
         """Forward-only plan (no autograd, no gradients, no optimiser): eval-mode BatchNorm (running statistics), no
         dropout, one rsample.  mode "validate": + fused reconstruction / ELBO; mode "embed": stops at z."""
         x = self._dense_f32(x)
@@ -234,13 +271,15 @@ class StepEngine:
         self._set_kl_weight()
         if explicit:
             plan.eps.copy_(enc_mod.explicit_eps.reshape(plan.eps.shape))
+        if plan.cond is not None:
+            plan.cond.load(metadata)
         plan.run()
         return plan
 
     def validation_step(self, x: torch.Tensor, metadata, expert_id: str) -> dict:
         """`CMMVAEModel.validation_step` (models/cmmvae_model.py:219-248) as one captured forward program.  Returns the
         loss dict of `BaseVAE.elbo` (device scalars)."""
-        plan = self._forward_only("validate", x, expert_id)
+        plan = self._forward_only("validate", x, expert_id, metadata)
         m = plan.metrics.clone()
         return {RK.LOSS: m[0], RK.RECON_LOSS: m[1], RK.KL_LOSS: m[2], RK.KL_WEIGHT: m[3]}
 
@@ -270,12 +309,16 @@ class StepEngine:
             plan.load_explicit_noise(enc_mod, expert)
         if plan.has_adv:
             plan.load_labels(metadata)
+        if plan.cond is not None:
+            plan.cond.load(metadata)
         ev = self._pending.pop(expert_id, None)
         if ev is not None:  # this expert's previous (deferred) update must land before its parameters are read
             torch.cuda.current_stream().wait_event(ev)
         ev = plan.run()
         if ev is not None:
             self._pending[expert_id] = ev
+        if plan.cond is not None:
+            plan.cond.commit()
         model.kl_annealing_fn.step()
         plan.log(model, expert_id)
 
@@ -331,6 +374,12 @@ class _Plan:
         self.exp_norm_log = None  # overlapped mode: the expert's pre-clip gradient norm, copied on the comm stream
         self.metrics = eng.buf("metrics", (256,))
         self.rng_state = rng.state(eng.device)
+        cl = getattr(m.vae, "conditionals", None)
+        self.cond = None
+        if cl is not None and mode != "embed":  # the embedding is z BEFORE the conditional layers (cmmvae.py:115-142)
+            if K != 1:
+                raise _lib.HipLibraryError("engine: conditional layers with the K-sample extension are not supported")
+            self.cond = _CondProgram(self, cl, eid, train=(mode == "train"))
         self._build()
 
     # ------------------------------------------------------------------------------------------- program building
@@ -378,7 +427,7 @@ class _Plan:
         if hit is None:
             return False
         opt, off = hit
-        if opt.reducer is not None:
+        if opt.reducer is not None or (self.cond is not None and opt is self.opt_vae):
             return False
         buf = eng.sq_buffer(opt)
         base = self._sq_used.get(id(opt), 0)
@@ -630,6 +679,17 @@ class _Plan:
         npart = self.lib.mmvae_sqnorm_partials(a.numel)
         if opt.reducer is not None or self.eng.overlap:
             self._cut(("ar_" + exchange, opt))
+        if self.cond is not None and opt is self.opt_vae:
+            # only the tensors that took part: the dense parameters + the condition blocks present in the batch, from
+            # the job table uploaded for this step (fixed launch size, empty jobs return at once)
+            c = self.cond
+            self._emit(self.lib.mmvae_grad_sqnorm_jobs, c.max_jobs, c.jobs_ptr, _p(a.grad), _p(c.partials))
+            flags = _lib.PREPARE_NORM | (_lib.PREPARE_ADVANCE if (advance and step) else 0)
+            self._emit(self.lib.mmvae_adam_prepare, c.max_jobs, _p(c.partials), max_norm, gs, b1, b2, _p(opt.state_dev), flags)
+            if step:
+                self._emit(self.lib.mmvae_adam_step_jobs, c.max_jobs, c.jobs_ptr, _p(a.data), _p(a.grad), _p(a.exp_avg),
+                           _p(a.exp_avg_sq), _p(opt.state_dev), g["lr"], b1, b2, g["eps"], g["weight_decay"], gs)
+            return
         cover = sorted(self._sq_cover.pop(id(opt), []))
         if cover:
             # the fused GEMM epilogues have left the partials of the ranges they wrote; the norm pass runs over the
@@ -690,6 +750,8 @@ class _Plan:
             return self._finish_forward_only()
         # ---- forward, decoder side (rows R = K*B)
         cur, ld = self.z, Z
+        if self.cond is not None:  # CLVAE.after_reparameterize: the sample passes through the conditional layers
+            cur, ld = self.cond.emit_forward(self.z)
         for i, l in enumerate(self.dec_layers[:-1]):
             cur = self.fwd_layer(f"{self.eid}.dec{i}.K{K}", l, cur, ld, R, training=train)
             ld = l.n_out
@@ -737,7 +799,10 @@ class _Plan:
             if j > 0:
                 S = self.bwd_layer(l, None, S, need_dx="raw")
             else:
-                self.bwd_layer(l, None, S, need_dx="full", dx_out=self.dz_lat)
+                self.bwd_layer(l, None, S, need_dx="full",
+                               dx_out=self.dz_lat if self.cond is None else self.cond.d_out)
+        if self.cond is not None:
+            self.cond.emit_backward(self.dz_lat)
         if not rest:
             raise _lib.HipLibraryError("engine: decoder needs at least two layers")
         # gradient-reversed adversary gradient on z (first sample) joins here
@@ -839,7 +904,8 @@ class _Plan:
 
     def _build_adversaries(self, hidden):
         eng, lib, B = self.eng, self.lib, self.B
-        self.labels_dev = {c: eng.buf(f"labels.{c}", (B,), torch.int64) for c in self.conditions}
+        self._labels_all = eng.buf("labels.all", (len(self.conditions), B), torch.int64)
+        self.labels_dev = {c: self._labels_all[i] for i, c in enumerate(self.conditions)}  # one upload per step
         self.n_adv = min(len(hidden), len(self.advs))
         for i, (h, adv) in enumerate(zip(hidden, self.advs), start=1):
             g = eng.grad_of
@@ -909,14 +975,19 @@ class _Plan:
     def load_labels(self, metadata):
         cache = metadata.attrs.get("_mmvae_labels") if hasattr(metadata, "attrs") else None
         if cache is None:
-            cache = {c: torch.tensor([Adversarial.labels[c][v] for v in metadata[c].values], dtype=torch.int64).pin_memory()
+            cache = {c: torch.tensor([Adversarial.labels[c][v] for v in metadata[c].values], dtype=torch.int64)
                      for c in self.conditions}
             try:
                 metadata.attrs["_mmvae_labels"] = cache
             except Exception:  # noqa: BLE001
                 pass
-        for c in self.conditions:
-            self.labels_dev[c].copy_(cache[c], non_blocking=True)
+        if getattr(self, "_label_ring", None) is None:
+            self._label_ring = _PinnedRing(len(self.conditions) * self.B, torch.int64)
+            self._labels_all = self.eng.buf("labels.all", (len(self.conditions), self.B), torch.int64)
+        slot = self._label_ring.take()
+        for i, c in enumerate(self.conditions):
+            slot[i * self.B:(i + 1) * self.B] = cache[c].numpy()
+        self._label_ring.upload(self._labels_all.view(-1))
 
     def _exchange(self, marker, tail):
         """One data-parallel exchange point between two captured segments.  Returns the stream the rest of the
@@ -1009,3 +1080,237 @@ class _Plan:
         model.log(f"grad_norms/expert_{eid}", self.exp_norm_log[0] if self.exp_norm_log is not None
                   else m[self.slot("grad_norms/expert")])
         model.auto_log(main, tags=[stage, eid])
+
+
+class _CondProgram:
+    """The conditional layers of a CLVAE (reference `ConditionalLayers.forward`, components.py:586-631, over
+    `ConditionalLayer.forward` :365-413) inside a captured program.
+
+    Every layer is a bank of Linear(Z, Z) (+ LayerNorm without affine) blocks that live in the shared-VAE optimiser's
+    arena; the kernels address a block through per-condition element offsets (mmvae_cond_linear_*), so ONE table of all
+    banks of this species serves every layer: position j of the (per step shuffled) selection order simply reads the
+    GLOBAL block index of each cell from its own static array.  Per step the host derives from the metadata, for every
+    position: cond[R] (global block per cell), the cells grouped by block in batch order (rows / group_cond /
+    group_start, padded to R groups), and the optimiser's job table -- dense parameters + the blocks present, with each
+    tensor's own bias corrections (torch.optim.Adam semantics for parameters without a gradient: skipped, per-parameter
+    step counts) -- packs them into one page-locked array and uploads it with one copy before the replay."""
+
+    @staticmethod
+    def _resolve(cl, key, eid):
+        layer = cl.layers[key]
+        if isinstance(layer, nn.ModuleDict):
+            if eid not in layer:
+                raise RuntimeError(f"'species' must be set to access non-shared conditional layer for batch_key '{key}'")
+            layer = layer[eid]
+        return layer
+
+    @staticmethod
+    def _blocks(layer):
+        return list(layer.conditions.values()) if isinstance(layer, ConditionalLayer) else [layer]
+
+    @staticmethod
+    def _all_blocks(cl):
+        for layer in cl.layers.values():
+            for sub in (layer.values() if isinstance(layer, nn.ModuleDict) else [layer]):
+                yield from _CondProgram._blocks(sub)
+
+    @staticmethod
+    def supported(cl, opt_vae, Z: int) -> bool:
+        has_ln = None
+        for blk in _CondProgram._all_blocks(cl):
+            if not isinstance(blk, FCBlock) or len(blk.fc_layers) != 1:
+                return False
+            names = [n for n, _ in blk.fc_layers[0].named_children()]
+            if any(n not in ("lin", "ln") for n in names):
+                return False
+            lin = blk.fc_layers[0].lin
+            if lin.in_features != Z or lin.out_features != Z or lin.bias is None:
+                return False
+            ln = "ln" in names
+            if has_ln is None:
+                has_ln = ln
+            if ln != has_ln:
+                return False
+            for p in (lin.weight, lin.bias):
+                hit = arena_of(p)
+                if hit is None or hit[0] is not opt_vae:
+                    return False
+        return has_ln is not None
+
+    def __init__(self, plan: "_Plan", cl, eid: str, train: bool):
+        import numpy as np
+
+        self.np = np
+        self.plan, self.cl, self.eid, self.train = plan, cl, eid, train
+        eng = plan.eng
+        self.eng = eng
+        self.opt = eng.opts["vae"]
+        a = self.opt.arena
+        R = self.R = plan.R
+        Z = self.Z = plan.Z
+        self.parallel = bool(cl.is_parallel)
+        self.keys = list(cl.selection_order)
+        self.n_pos = len(self.keys)
+        # ---- one table of every block this species can meet
+        w_off, b_off = [], []
+        self.entries = {}
+        for key in self.keys:
+            layer = self._resolve(cl, key, eid)
+            blocks = self._blocks(layer)
+            lins = [b.fc_layers[0].lin for b in blocks]
+            w_idx = np.array([arena_of(l.weight)[1] for l in lins], dtype=np.int64)
+            b_idx = np.array([arena_of(l.bias)[1] for l in lins], dtype=np.int64)
+            ent = dict(base=len(w_off), w_idx=w_idx, b_idx=b_idx, layer=layer if isinstance(layer, ConditionalLayer) else None,
+                       raw_index={})
+            if ent["layer"] is not None:
+                ent["index"] = {k: i for i, k in enumerate(layer.conditions.keys())}
+            w_off += [a.offsets[i] for i in w_idx]
+            b_off += [a.offsets[i] for i in b_idx]
+            self.entries[key] = ent
+        first = next(self._all_blocks(cl)).fc_layers[0]
+        self.ln_eps = float(first.ln.eps) if hasattr(first, "ln") else None
+        dev = eng.device
+        self.w_off = torch.tensor(w_off, dtype=torch.int64, device=dev)
+        self.b_off = torch.tensor(b_off, dtype=torch.int64, device=dev)
+        # ---- optimiser bookkeeping: dense parameters (always stepped) vs condition blocks (any species)
+        managed = set()
+        for blk in self._all_blocks(cl):
+            lin = blk.fc_layers[0].lin
+            managed.update((arena_of(lin.weight)[1], arena_of(lin.bias)[1]))
+        self.dense = np.array([i for i in range(len(a.params)) if i not in managed], dtype=np.int64)
+        jpb = (Z * Z + 16383) // 16384 + 1  # jobs of one block: weight chunks + bias
+        b1, b2 = self.opt.param_groups[0]["betas"]
+        n_dense_jobs = len(self.opt.job_table(self.dense, b1, b2)) if train else 0
+        self.max_jobs = n_dense_jobs + sum(min(R, len(e["w_idx"])) for e in self.entries.values()) * jpb if train else 0
+        # ---- static device tables, filled by load(): per position cond[R] rows[R] group_cond[R] group_start[R+1]
+        self.P = 4 * R + 1
+        self.idx_words = (self.n_pos * self.P + 1) // 2 * 2
+        words = self.idx_words + 6 * self.max_jobs
+        self.pack_dev = eng.buf(f"cond.pack.{eid}.{int(train)}", (words,), torch.int32)
+        self.ring = _PinnedRing(words)
+        self._scratch = np.zeros(words, dtype=np.int32)
+        self.jobs_ptr = self.pack_dev.data_ptr() + 4 * self.idx_words
+        self.partials = eng.buf(f"cond.sqparts.{eid}", (max(self.max_jobs, 1),)) if train else None
+        self._active = None
+        # ---- activations
+        self.lin = eng.buf("cond.lin", (R, Z))  # pre-LayerNorm output of the position being computed
+        self.gl = eng.buf("cond.gl", (R, Z))    # gradient w.r.t. that pre-LayerNorm output
+        wide = self.n_pos * Z if self.parallel else Z
+        self.out = eng.buf("cond.out", (R, wide)) if self.parallel else None
+        self.d_out = eng.buf("cond.d_out", (R, wide)) if train else None
+        self.y = [None] * self.n_pos
+        self.invstd = [eng.buf(f"cond.invstd{j}", (R,)) for j in range(self.n_pos)] if self.ln_eps is not None else None
+        self.mean = eng.buf("cond.mean", (R,)) if self.ln_eps is not None else None
+        self.x_in = [None] * self.n_pos
+
+    def _ptr(self, j: int, part: int) -> int:
+        """Device address of part 0 cond / 1 rows / 2 group_cond / 3 group_start of position j."""
+        return self.pack_dev.data_ptr() + 4 * (j * self.P + part * self.R)
+
+    # ------------------------------------------------------------------------------------------ program emission
+    def emit_forward(self, z: torch.Tensor):
+        plan, lib, R, Z = self.plan, self.plan.lib, self.R, self.Z
+        params = self.opt.arena.data
+        cur = z
+        for j in range(self.n_pos):
+            x = z if self.parallel else cur
+            self.x_in[j] = x
+            if self.parallel:
+                y, ldy = self.out[:, j * Z:(j + 1) * Z], self.out.shape[1]
+            else:
+                y, ldy = self.eng.buf(f"cond.y{j}", (R, Z)), Z
+            self.y[j] = (y, ldy)
+            lin_out, ld_lin = (self.lin, Z) if self.ln_eps is not None else (y, ldy)
+            plan._emit(lib.mmvae_cond_linear_fwd, R, Z, Z, _p(x), Z, _p(params), _p(self.w_off), _p(self.b_off),
+                       self._ptr(j, 0), self._ptr(j, 1) if os.environ.get("MMVAE_COND_SORTED_FWD", "1") != "0" else None,
+                       _p(lin_out), ld_lin)
+            if self.ln_eps is not None:
+                plan._emit(lib.mmvae_layernorm_fwd, R, Z, _p(self.lin), Z, self.ln_eps, _p(y), ldy, _p(self.mean),
+                           _p(self.invstd[j]))
+            cur = y
+        return (self.out, self.out.shape[1]) if self.parallel else (cur, Z)
+
+    def emit_backward(self, dz: torch.Tensor):
+        """d_out (gradient w.r.t. what the decoder read) -> block gradients straight into the arena + dz."""
+        plan, lib, R, Z = self.plan, self.plan.lib, self.R, self.Z
+        a = self.opt.arena
+        g, ldg = self.d_out, self.d_out.shape[1]
+        for j in range(self.n_pos - 1, -1, -1):
+            y, ldy = self.y[j]
+            gj = g[:, j * Z:(j + 1) * Z] if self.parallel else g
+            if self.ln_eps is not None:
+                plan._emit(lib.mmvae_layernorm_bwd, R, Z, _p(gj), ldg, _p(y), ldy, _p(self.invstd[j]), _p(self.gl), Z)
+                gl, ldgl = self.gl, Z
+            else:
+                gl, ldgl = gj, ldg
+            plan._emit(lib.mmvae_cond_linear_bwd_dw, R, self._ptr(j, 2), self._ptr(j, 3), self._ptr(j, 1), Z, Z, _p(gl),
+                       ldgl, _p(self.x_in[j]), Z, _p(a.grad), _p(self.w_off), _p(self.b_off))
+            if self.parallel:
+                plan._emit(lib.mmvae_cond_linear_bwd_dx, R, Z, Z, _p(gl), ldgl, _p(a.data), _p(self.w_off),
+                           self._ptr(j, 0), _p(dz), Z, int(j != self.n_pos - 1))
+            else:
+                dx = dz if j == 0 else self.eng.buf(f"cond.dx{j % 2}", (R, Z))
+                plan._emit(lib.mmvae_cond_linear_bwd_dx, R, Z, Z, _p(gl), ldgl, _p(a.data), _p(self.w_off),
+                           self._ptr(j, 0), _p(dx), Z, 0)
+                g, ldg = dx, Z
+
+    # ------------------------------------------------------------------------------------------------ per step
+    def _local_indices(self, ent, key, metadata):
+        np = self.np
+        B = len(metadata)
+        if ent["layer"] is None:  # the species block: every cell goes through the one block of this expert
+            return np.zeros(B, dtype=np.int32)
+        raw_index, layer = ent["raw_index"], ent["layer"]
+        values = metadata[layer.batch_key].tolist()
+        try:
+            return np.fromiter((raw_index[v] for v in values), dtype=np.int32, count=B)
+        except KeyError:
+            for v in set(values) - raw_index.keys():
+                raw_index[v] = ent["index"][layer.format_condition_key(str(v))]  # KeyError: unknown condition
+            return np.fromiter((raw_index[v] for v in values), dtype=np.int32, count=B)
+
+    def load(self, metadata) -> None:
+        import random
+
+        np = self.np
+        R, P = self.R, self.P
+        order = self.keys
+        if self.cl.shuffle_selection_order:  # the same draw the module path makes (components.py:601-603)
+            order = random.sample(order, len(order))
+        # all host arithmetic first, into an ordinary array: the first runtime call after a graph launch waits until the
+        # launch has been handed to the device queue (~0.8 ms for this program), and that wait should overlap this work
+        pack = self._scratch
+        pack[self.idx_words:] = 0  # unused job slots: empty jobs
+        active = [self.dense]
+        for j, key in enumerate(order):
+            ent = self.entries[key]
+            local = self._local_indices(ent, key, metadata)
+            if len(local) != R:
+                raise _lib.HipLibraryError(f"engine: metadata has {len(local)} rows, the batch {R}")
+            seg = pack[j * P:(j + 1) * P]
+            seg[:R] = local + ent["base"]
+            rows = np.argsort(local, kind="stable").astype(np.int32)  # cells of a block stay in batch order
+            present, start = np.unique(local[rows], return_index=True)
+            n = len(present)
+            seg[R:2 * R] = rows
+            seg[2 * R:3 * R] = -1
+            seg[2 * R:2 * R + n] = present + ent["base"]
+            seg[3 * R:3 * R + n] = start
+            seg[3 * R + n:] = R
+            active.append(ent["w_idx"][present])
+            active.append(ent["b_idx"][present])
+        if self.train:
+            act = np.concatenate(active)
+            b1, b2 = self.opt.param_groups[0]["betas"]
+            jobs = self.opt.job_table(act, b1, b2)
+            if len(jobs) > self.max_jobs:
+                raise _lib.HipLibraryError("engine: conditional job table overflow")
+            pack[self.idx_words:self.idx_words + 6 * len(jobs)] = jobs.view(np.int32)
+            self._active = act
+        self.ring.take()[:] = pack
+        self.ring.upload(self.pack_dev)
+
+    def commit(self) -> None:
+        """The step ran: the tensors of its job table have taken one more step."""
+        steps = self.opt.host_steps()
+        steps[self._active] += 1

@@ -106,7 +106,7 @@ class CondLinearFn(torch.autograd.Function):
     def forward(ctx, x, bank, cond_dev, group_cond, group_start, rows, present_params):
         x2 = x if x.is_contiguous() else x.contiguous()
         a = bank["opt"].arena
-        y = ops.cond_linear_fwd(x2, a.data, bank["w_off"], bank["b_off"], cond_dev, bank["n_out"])
+        y = ops.cond_linear_fwd(x2, a.data, bank["w_off"], bank["b_off"], cond_dev, bank["n_out"], rows=rows)
         ctx.save_for_backward(x2, cond_dev, group_cond, group_start, rows)
         ctx.bank, ctx.present_params = bank, present_params
         return y

@@ -549,29 +549,32 @@ def csr_to_dense(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
 
 
 def cond_linear_fwd(x: torch.Tensor, params: torch.Tensor, w_off: torch.Tensor, b_off: torch.Tensor,
-                    cond: torch.Tensor, n_out: int) -> torch.Tensor:
-    """y[b] = W[cond[b]] x[b] + bias[cond[b]]; blocks addressed by element offsets into the flat `params` arena."""
+                    cond: torch.Tensor, n_out: int, rows: torch.Tensor = None) -> torch.Tensor:
+    """y[b] = W[cond[b]] x[b] + bias[cond[b]]; blocks addressed by element offsets into the flat `params` arena.
+    `rows` (int32 [B], the cells sorted by condition) selects the kernel that reads a shared block once per 8 cells."""
     lib = _lib.load()
     _chk(x, "x"), _chk(params, "params")
     B, n_in, ldx = _mat(x, "x")
     y = torch.empty((B, n_out), dtype=torch.float32, device=x.device)
     _lib.check(lib.mmvae_cond_linear_fwd(B, n_in, n_out, _ptr(x), ldx, _ptr(params), _ptr(w_off), _ptr(b_off),
-                                         _ptr(cond), _ptr(y), n_out, _stream()), "mmvae_cond_linear_fwd")
+                                         _ptr(cond), _ptr(rows), _ptr(y), n_out, _stream()), "mmvae_cond_linear_fwd")
     return y
 
 
 def cond_linear_bwd(dy: torch.Tensor, x: torch.Tensor, params: torch.Tensor, grads: torch.Tensor, w_off: torch.Tensor,
                     b_off: torch.Tensor, cond: torch.Tensor, group_cond: torch.Tensor, group_start: torch.Tensor,
-                    rows: torch.Tensor) -> torch.Tensor:
-    """dx, and dW / db of the PRESENT conditions written into `grads` (same layout as `params`)."""
+                    rows: torch.Tensor, dx: torch.Tensor = None, accumulate: bool = False) -> torch.Tensor:
+    """dx (into `dx`, added to it when `accumulate`), and dW / db of the PRESENT conditions written into `grads` (same
+    layout as `params`; groups with group_cond < 0 are padding)."""
     lib = _lib.load()
     _chk(dy, "dy"), _chk(x, "x")
     B, n_out, lddy = _mat(dy, "dy")
     _, n_in, ldx = _mat(x, "x")
-    dx = torch.empty((B, n_in), dtype=torch.float32, device=x.device)
+    if dx is None:
+        dx = torch.empty((B, n_in), dtype=torch.float32, device=x.device)
     s = _stream()
     _lib.check(lib.mmvae_cond_linear_bwd_dx(B, n_in, n_out, _ptr(dy), lddy, _ptr(params), _ptr(w_off), _ptr(cond),
-                                            _ptr(dx), n_in, s), "mmvae_cond_linear_bwd_dx")
+                                            _ptr(dx), _mat(dx, "dx")[2], int(accumulate), s), "mmvae_cond_linear_bwd_dx")
     _lib.check(lib.mmvae_cond_linear_bwd_dw(int(group_cond.numel()), _ptr(group_cond), _ptr(group_start), _ptr(rows), n_in,
                                             n_out, _ptr(dy), lddy, _ptr(x), ldx, _ptr(grads), _ptr(w_off), _ptr(b_off), s),
                "mmvae_cond_linear_bwd_dw")

@@ -119,6 +119,7 @@ class HipAdam(torch.optim.Optimizer):
         # the conditions absent from a batch).  While every parameter has taken part in every step the counts are all
         # equal to state_dev[0] and live on the device only; the first partial step materialises them here.
         self._steps: Optional[List[int]] = None
+        self._numel = None
         self._inactive: List[int] = []
         if self._hip:
             self.partials = torch.empty(max(ops.sqnorm_partials(self.arena.numel), 1), dtype=torch.float32, device=dev)
@@ -206,6 +207,40 @@ class HipAdam(torch.optim.Optimizer):
             self._step_cpu_plumbing(g, b1, b2)
         self._norm_valid = False
 
+    JOB_DTYPE = [("offset", "<i8"), ("len", "<i4"), ("bc1", "<f4"), ("bc2", "<f4"), ("reserved", "<i4")]
+
+    def host_steps(self):
+        """Per-parameter step counts kept on the host (created from the common device count on first use)."""
+        import numpy as np
+
+        if self._steps is None:
+            self._steps = np.full(len(self.arena.params), int(round(float(self.state_dev[0]))), dtype=np.int64)
+        return self._steps
+
+    def job_table(self, active, b1, b2):
+        """`mmvae_adam_job` records (numpy structured array) of the parameters `active` (indices into the arena) for
+        their NEXT step: a job per <= 16384-element chunk carrying the tensor's own bias corrections."""
+        import numpy as np
+
+        a = self.arena
+        if self._numel is None:
+            self._numel = np.fromiter((p.numel() for p in a.params), dtype=np.int64, count=len(a.params))
+            self._offsets = np.asarray(a.offsets, dtype=np.int64)
+        t_act = np.asarray(self.host_steps(), dtype=np.int64)[active] + 1
+        bc1 = (np.float32(1.0) - np.power(np.float32(b1), t_act.astype(np.float32))).astype(np.float32)
+        bc2 = (np.float32(1.0) - np.power(np.float32(b2), t_act.astype(np.float32))).astype(np.float32)
+        off, num = self._offsets[active], self._numel[active]
+        J = 16384
+        nchunk = (num + J - 1) // J
+        owner = np.repeat(np.arange(len(active)), nchunk)
+        first = np.cumsum(nchunk) - nchunk
+        k = np.arange(int(nchunk.sum())) - first[owner]
+        jobs = np.zeros(len(owner), dtype=np.dtype(self.JOB_DTYPE))
+        jobs["offset"] = off[owner] + k * J
+        jobs["len"] = np.minimum(num[owner] - k * J, J)
+        jobs["bc1"], jobs["bc2"] = bc1[owner], bc2[owner]
+        return jobs
+
     def _step_partial(self, g, b1, b2, norm_valid: bool):
         """A step in which some parameters have no gradient, or after such a step: torch.optim.Adam semantics --
         parameters without a gradient are left untouched (no moment decay, no weight decay) and every parameter uses
@@ -243,18 +278,7 @@ class HipAdam(torch.optim.Optimizer):
             # bias corrections (mmvae_adam_step_jobs)
             from . import _lib
 
-            off = np.asarray(a.offsets, dtype=np.int64)[active]
-            num = np.fromiter((a.params[i].numel() for i in active), dtype=np.int64, count=len(active))
-            J = 16384
-            nchunk = (num + J - 1) // J
-            owner = np.repeat(np.arange(len(active)), nchunk)
-            first = np.cumsum(nchunk) - nchunk
-            k = np.arange(int(nchunk.sum())) - first[owner]
-            jobs = np.zeros(len(owner), dtype=np.dtype([("offset", "<i8"), ("len", "<i4"), ("bc1", "<f4"), ("bc2", "<f4"),
-                                                        ("reserved", "<i4")]))
-            jobs["offset"] = off[owner] + k * J
-            jobs["len"] = np.minimum(num[owner] - k * J, J)
-            jobs["bc1"], jobs["bc2"] = bc1[owner], bc2[owner]
+            jobs = self.job_table(active, b1, b2)
             jobs_dev = torch.from_numpy(jobs.view(np.uint8)).to(a.device, non_blocking=False)
             lib = _lib.load()
             rc = lib.mmvae_adam_step_jobs(len(jobs), jobs_dev.data_ptr(), a.data.data_ptr(), a.grad.data_ptr(),

@@ -107,6 +107,7 @@ def replay_training(name, device, use_engine=False, check=True, prepare=None):
             logged = {k: (float(v.detach()) if torch.is_tensor(v) else v) for k, v in model.logged.items()}
             sd = {k: v.detach().cpu().clone() for k, v in model.module.state_dict().items()}
             results.append({"logged": logged, "sd": sd, "eid": eid})
+        replay_training.last_engine = model._engine
     return case, z, results
 
 

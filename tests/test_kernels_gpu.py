@@ -493,9 +493,20 @@ def test_cond_linear_fwd_bwd(ops, B, n_in, n_out, C):
     wo, bo, cd = dv(torch.tensor(w_off), torch.int64), dv(torch.tensor(b_off), torch.int64), dv(cond, torch.int32)
     y = ops.cond_linear_fwd(dev(x), P, wo, bo, cd, n_out)
     assert rel_l2(y, y_ref) < 1e-5
+    # the condition-sorted forward (a shared block read once per 8 cells) does the same arithmetic: same bits
+    y_sorted = ops.cond_linear_fwd(dev(x), P, wo, bo, cd, n_out, rows=dv(order, torch.int32))
+    assert torch.equal(y_sorted, y)
     dx = ops.cond_linear_bwd(dev(dy), dev(x), P, G, wo, bo, cd, dv(present, torch.int32), dv(start, torch.int32),
                              dv(order, torch.int32))
     assert rel_l2(dx, dx_ref) < 1e-5
+    # fixed-size launch of a captured program: one group slot per cell, unused slots marked -1; dx accumulated
+    pad = B - len(present)
+    gc_pad = torch.cat([present, torch.full((pad,), -1, dtype=present.dtype)])
+    gs_pad = torch.cat([start, torch.full((pad,), B, dtype=start.dtype)])
+    G2 = torch.full((pos,), 7.0, device="cuda")
+    dx2 = ops.cond_linear_bwd(dev(dy), dev(x), P, G2, wo, bo, cd, dv(gc_pad, torch.int32), dv(gs_pad, torch.int32),
+                              dv(order, torch.int32), dx=dx.clone(), accumulate=True)
+    assert torch.equal(G2, G) and torch.equal(dx2, dx + dx)
     Gc = G.cpu()
     touched = torch.zeros(pos, dtype=torch.bool)
     for c in present.tolist():

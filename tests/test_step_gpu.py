@@ -16,10 +16,14 @@ def test_module_path_matches_reference(name):
     MU.check_against_golden(case, z, results)
 
 
-@pytest.mark.parametrize("name", H.CASES)
+@pytest.mark.parametrize("name", H.CASES + H.COND_CASES)
 def test_engine_path_matches_reference(name):
     case, z, results = MU.replay_training(name, "cuda", use_engine=True)
     MU.check_against_golden(case, z, results)
+    engine = MU.replay_training.last_engine
+    assert engine, "the captured engine must have taken this configuration"
+    if name in H.COND_CASES:  # conditional layers ran inside the captured program, not on the module path
+        assert all(p.cond is not None for p in engine._plans.values())
 
 
 @pytest.mark.parametrize("name", H.CASES)

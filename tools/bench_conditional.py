@@ -18,7 +18,7 @@ import torch.nn as nn  # noqa: E402
 SIZES = {"assay": 8, "sex": 2, "dataset_id": 273, "donor_id": 4644}
 
 
-def build(root, G=20000, Z=128):
+def build(root, G=20000, Z=128, use_engine=False):
     from mmvae_amd.config import AutogradConfig, GradientClipConfig
     from mmvae_amd.models import CMMVAEModel
     from mmvae_amd.modules import CLVAE, CMMVAE, base
@@ -44,7 +44,7 @@ def build(root, G=20000, Z=128):
     clip = lambda: GradientClipConfig(val=10, algorithm="norm")
     torch.manual_seed(0)
     return CMMVAEModel(CMMVAE(vae, base.Experts(experts), None), autograd_config=AutogradConfig(clip(), clip(), clip()),
-                       use_engine=False).cuda()
+                       use_engine=use_engine).cuda()
 
 
 def metadata(B, eid, seed):
@@ -52,6 +52,33 @@ def metadata(B, eid, seed):
     md = {k: [f"{k}_{i}" for i in rng.integers(0, n, B)] for k, n in SIZES.items()}
     md["tissue"] = [f"t_{eid}_{i}" for i in rng.integers(0, 4, B)]
     return pd.DataFrame(md)
+
+
+def run_engine(steps=60, warm=12, B=512, G=20000):
+    """The same model through the captured engine (conditional layers inside the program); no host read-back inside the
+    timed region, metadata frames prepared beforehand (the feed's job)."""
+    from mmvae_amd import synthetic
+
+    with tempfile.TemporaryDirectory() as d:
+        model = build(d, G, use_engine=True)
+        model.train()
+        model.trainer.set_stage("training")
+        xs = {e: synthetic.synthetic_counts(B, G, seed=3 + i, device="cuda") for i, e in enumerate(("human", "mouse"))}
+        mds = [metadata(B, ("human", "mouse")[i % 2], i) for i in range(steps)]
+        first = []
+        for i in range(steps):
+            if i == warm:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            eid = ("human", "mouse")[i % 2]
+            model.training_step((xs[eid], mds[i], eid), i)
+            if i < 3:
+                first.append(float(model.logged[f"loss/training/{eid}"]))
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / (steps - warm) * 1e3
+        assert model._engine and all(p.cond is not None for p in model._engine._plans.values())
+        last = float(model.logged[f"loss/training/{eid}"])
+    return ms, first, last
 
 
 def run(grouped: bool, steps=12, B=512, G=20000):
@@ -79,6 +106,10 @@ def run(grouped: bool, steps=12, B=512, G=20000):
 
 
 if __name__ == "__main__":
+    ms_e, first_e, last_e = run_engine()
+    print(f"captured engine     : {ms_e:8.2f} ms / step   losses {first_e} ... {last_e:.1f} (device Philox noise)")
+    if "--engine-only" in sys.argv:
+        sys.exit(0)
     ms_g, loss_g, n = run(True)
     ms_l, loss_l, _ = run(False)
     print(f"conditional parameters: {n / 1e6:.1f} M in {sum(SIZES.values()) + 8 + 2} blocks")
