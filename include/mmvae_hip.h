@@ -360,21 +360,29 @@ int mmvae_csr_to_dense_f32(int B, int G, int64_t nnz, const int64_t* crow_indice
  *   _fwd      one workgroup per cell; with `rows` (DEVICE int32 [B]: the cells sorted by condition, NULL = none) and
  *             n_in <= 256, one workgroup per 8 sorted cells, which reads a block shared by them once.  Same results.
  *   _bwd_dx   dx[b] = W[c_b]^T dy[b].
- *   _bwd_dw   dW[c] = sum_{b in c} dy[b] (x) x[b], db[c] = sum dy[b] for the n_groups conditions PRESENT in the batch:
- *             group g covers cells rows[group_start[g] .. group_start[g+1]) (DEVICE int32 arrays; cells in batch order
- *             -> bitwise reproducible, no atomics) of condition group_cond[g] (< 0: padding, skipped); the block's gradient is
- *             overwritten; a block is sliced over several workgroups.  n_in + n_out <= 2048.
- *             Absent conditions are not touched (their parameters have no gradient this step).
+ *   _bwd_dw   dW[c] = sum_{b in c} dy[b] (x) x[b], db[c] = sum dy[b] for the conditions PRESENT in the batch.  `rows`
+ *             (DEVICE int32 [B]) lists the cells sorted by condition, cells of a condition in batch order; the host
+ *             cuts every present condition's range of `rows` into chunks of at most MMVAE_COND_DW_CHUNK cells:
+ *             chunk i covers rows[chunk_beg[i] .. chunk_end[i]) and has chunk_dst[i] >= 0: the only chunk of condition
+ *             chunk_dst[i], its gradient is written straight into `grads`; <= -2: one of several, its partial result
+ *             goes to scratch slot -2 - chunk_dst[i] of `partials` (slot = n_in*n_out + n_out floats); -1: padding.
+ *             Reduction r (n_red of them; red_cond[r] < 0: padding) sums slots red_slot[r] .. + red_n[r] - 1, in that
+ *             order, into condition red_cond[r].  Fixed summation tree, no atomics: bitwise reproducible.  Absent
+ *             conditions are not touched (their parameters have no gradient this step).  All index arrays are DEVICE
+ *             int32; a captured program launches the fixed maxima (mmvae_amd/cond_tables.py) padded with -1.
  * ------------------------------------------------------------------------------------------------------------ */
+#define MMVAE_COND_DW_CHUNK 32
 int mmvae_cond_linear_fwd(int B, int n_in, int n_out, const float* x, int64_t ldx, const float* params,
                           const int64_t* w_off, const int64_t* b_off, const int32_t* cond, const int32_t* rows, float* y,
                           int64_t ldy, mmvae_stream_t stream);
 int mmvae_cond_linear_bwd_dx(int B, int n_in, int n_out, const float* dy, int64_t lddy, const float* params,
                              const int64_t* w_off, const int32_t* cond, float* dx, int64_t lddx, int accumulate,
                              mmvae_stream_t stream);
-int mmvae_cond_linear_bwd_dw(int n_groups, const int32_t* group_cond, const int32_t* group_start, const int32_t* rows,
-                             int n_in, int n_out, const float* dy, int64_t lddy, const float* x, int64_t ldx,
-                             float* grads, const int64_t* w_off, const int64_t* b_off, mmvae_stream_t stream);
+int mmvae_cond_linear_bwd_dw(int n_chunks, const int32_t* chunk_dst, const int32_t* chunk_beg, const int32_t* chunk_end,
+                             const int32_t* rows, int n_in, int n_out, const float* dy, int64_t lddy, const float* x,
+                             int64_t ldx, float* grads, const int64_t* w_off, const int64_t* b_off, int n_red,
+                             const int32_t* red_cond, const int32_t* red_slot, const int32_t* red_n, float* partials,
+                             mmvae_stream_t stream);
 
 /* Small utilities used by the step engine: y = alpha*x (+ y), fill. */
 int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, float* y, mmvae_stream_t stream);

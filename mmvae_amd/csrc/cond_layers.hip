@@ -133,113 +133,121 @@ __global__ __launch_bounds__(256) void cond_linear_bwd_dx_kernel(int n_in, int n
     }
 }
 
-// Workgroup (g, slice): group g = one PRESENT condition, rows[start[g] .. start[g+1]) are its cells in batch order; the
-// slice is DW_U * 256 consecutive entries of the block's [n_out, n_in] gradient (slice 0 also owns the bias gradient).
-// A condition shared by many cells (the species block: all of them) is a real [n_out x cells] . [cells x n_in] product
-// walked by ONE workgroup per slice: the block is sliced finely, cells are staged in LDS DW_STAGE floats at a time and
-// the next stage is fetched into registers while the current one is consumed, so the walk is bound by its FMAs, not
-// by a global-load round trip per cell.  Every entry is accumulated over the group's cells in batch order by one
-// thread: bitwise reproducible, no atomics.
-constexpr int DW_U = 4;          // entries per thread
-constexpr int DW_STAGE = 4096;   // floats of (dy | x) rows staged per barrier pair
-constexpr int DW_NL = DW_STAGE / 256;
-constexpr int DW_ROWS = 1024;
-__global__ __launch_bounds__(256) void cond_linear_bwd_dw_kernel(int n_in, int n_out, const int32_t* __restrict__ group_cond,
-                                                                 const int32_t* __restrict__ group_start,
-                                                                 const int32_t* __restrict__ rows,
-                                                                 const float* __restrict__ dy, int64_t lddy,
-                                                                 const float* __restrict__ x, int64_t ldx,
-                                                                 float* __restrict__ grads,
-                                                                 const int64_t* __restrict__ w_off,
-                                                                 const int64_t* __restrict__ b_off) {
-    __shared__ __attribute__((aligned(16))) float sh[DW_STAGE];  // cb x (dy row [n_out] | x row [n_in])
-    __shared__ int cells[DW_ROWS];  // the group's first DW_ROWS cell indices (one round trip less per stage)
-    const int g = blockIdx.x, tid = threadIdx.x;
-    const int c = group_cond[g];
-    if (c < 0) return;  // padding of a fixed-size launch (captured programs launch one group per cell)
+// Weight / bias gradient of the blocks PRESENT in the batch.  The host cuts every block's cells (sorted order `rows`,
+// cells of a block in batch order) into chunks of at most DW_CHUNK cells; workgroup (chunk, tile) owns a 128 x 128 tile
+// of dW = sum_cells dy (x) x over its chunk: the chunk's dy / x rows are staged in LDS by one branch-free pass (one
+// float per thread and cell), every thread accumulates an 8 x 8 register tile (16 LDS floats per 64 FMAs).  A block with
+// one chunk (dst >= 0) is written straight into the gradient arena; the chunks of a larger block (the species block:
+// every cell) leave partials in scratch slots (dst = -2 - slot) that cond_dw_reduce_kernel sums in chunk order.  Fixed
+// summation tree, no atomics: bitwise reproducible; a block shared by many cells is spread over workgroups.
+constexpr int DW_CHUNK = MMVAE_COND_DW_CHUNK;
+constexpr int DW_T = 128;  // tile edge
+__global__ __launch_bounds__(256) void cond_dw_chunk_kernel(int n_in, int n_out, const int32_t* __restrict__ chunk_dst,
+                                                            const int32_t* __restrict__ chunk_beg,
+                                                            const int32_t* __restrict__ chunk_end,
+                                                            const int32_t* __restrict__ rows,
+                                                            const float* __restrict__ dy, int64_t lddy,
+                                                            const float* __restrict__ x, int64_t ldx,
+                                                            float* __restrict__ grads, const int64_t* __restrict__ w_off,
+                                                            const int64_t* __restrict__ b_off, float* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) float sh[DW_CHUNK * 2 * DW_T];  // per cell: dy tile rows | x tile columns
+    __shared__ int cells[DW_CHUNK];
+    const int dst = chunk_dst[blockIdx.x];
+    if (dst == -1) return;  // padding of a fixed-size launch
+    const int tid = threadIdx.x;
+    const int beg = chunk_beg[blockIdx.x], nb = chunk_end[blockIdx.x] - beg;
+    const int tiles_k = (n_in + DW_T - 1) / DW_T;
+    const int o_base = (blockIdx.y / tiles_k) * DW_T, k_base = (blockIdx.y % tiles_k) * DW_T;
+    if (tid < DW_CHUNK) cells[tid] = rows[beg + min(tid, nb - 1)];
+    __syncthreads();
+    {
+        // thread t < 128 stages dy[cell][o_base + t], thread t >= 128 stages x[cell][k_base + t - 128]: unconditional
+        // loads from clamped addresses + a select (a conditional load per cell would serialise the round trips)
+        const bool is_dy = tid < DW_T;
+        const int j = is_dy ? o_base + tid : k_base + tid - DW_T;
+        const bool inside = is_dy ? j < n_out : j < n_in;
+        const int jc = inside ? j : 0;
+        const float* src = is_dy ? dy + jc : x + jc;
+        const int64_t ld = is_dy ? lddy : ldx;
+        float v[DW_CHUNK];
+#pragma unroll
+        for (int q = 0; q < DW_CHUNK; ++q) v[q] = src[(int64_t)cells[q] * ld];
+#pragma unroll
+        for (int q = 0; q < DW_CHUNK; ++q) sh[q * 2 * DW_T + tid] = (inside && q < nb) ? v[q] : 0.f;
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;  // rows o_base + 8 ty .. + 7, columns k_base + 8 tx .. + 7
+    float acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    float accb = 0.f;
+    const bool bias_here = (blockIdx.y % tiles_k) == 0 && tid < DW_T;
+    for (int q = 0; q < nb; ++q) {
+        const float* cell = sh + q * 2 * DW_T;
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(cell + 8 * ty);
+        const f32x4 d1 = *reinterpret_cast<const f32x4*>(cell + 8 * ty + 4);
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(cell + DW_T + 8 * tx);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(cell + DW_T + 8 * tx + 4);
+        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] += dv[i] * xv[j];
+        if (bias_here) accb += cell[tid];
+    }
+    float* dW;
+    float* db;
+    if (dst >= 0) {
+        dW = grads + w_off[dst];
+        db = grads + b_off[dst];
+    } else {
+        dW = partials + (int64_t)(-2 - dst) * ((int64_t)n_in * n_out + n_out);
+        db = dW + (int64_t)n_in * n_out;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int o = o_base + 8 * ty + i;
+        if (o >= n_out) break;
+        float* out = dW + (int64_t)o * n_in + k_base + 8 * tx;
+        if (k_base + 8 * tx + 8 <= n_in && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {
+            *reinterpret_cast<f32x4*>(out) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+            *reinterpret_cast<f32x4*>(out + 4) = f32x4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k_base + 8 * tx + j < n_in) out[j] = acc[i][j];
+        }
+    }
+    if (bias_here && o_base + tid < n_out) db[o_base + tid] = accb;
+}
+
+// Blocks cut into several chunks: grads[block] = sum of their partial slots, in chunk order.
+__global__ __launch_bounds__(256) void cond_dw_reduce_kernel(int n_in, int n_out, const int32_t* __restrict__ red_cond,
+                                                             const int32_t* __restrict__ red_slot,
+                                                             const int32_t* __restrict__ red_n,
+                                                             const float* __restrict__ partials, float* __restrict__ grads,
+                                                             const int64_t* __restrict__ w_off,
+                                                             const int64_t* __restrict__ b_off) {
+    const int c = red_cond[blockIdx.x];
+    if (c < 0) return;
+    const int64_t n = (int64_t)n_in * n_out, tot = n + n_out;
+    const float* src = partials + (int64_t)red_slot[blockIdx.x] * tot;
+    const int pieces = red_n[blockIdx.x];
     float* dW = grads + w_off[c];
     float* db = grads + b_off[c];
-    const int n = n_in * n_out;
-    const int beg = group_start[g], end = group_start[g + 1];
-    const int e_base = blockIdx.y * (256 * DW_U);
-    const int stride = n_in + n_out;
-    const int CB = DW_STAGE / stride;  // cells per stage (>= 2: n_in + n_out <= 2048)
-    int ro[DW_U], co[DW_U];
-    float acc[DW_U];
 #pragma unroll
-    for (int u = 0; u < DW_U; ++u) {
-        int e = e_base + tid + 256 * u;
-        if (e >= n) e = n - 1;  // clamped: computed, never stored
-        ro[u] = e / n_in;
-        co[u] = n_out + e % n_in;
-        acc[u] = 0.f;
-    }
-    // element q of this thread's share of a stage: cell qc[q] of the stage, column qj[q] of its (dy | x) row
-    int qc[DW_NL], qj[DW_NL];
-#pragma unroll
-    for (int q = 0; q < DW_NL; ++q) {
-        const int i = tid + 256 * q;
-        qc[q] = i / stride;
-        qj[q] = i - qc[q] * stride;
-    }
-    // cells[] is a window of the group's cell indices starting at row `win`; loads below are branch-free (clamped
-    // addresses + selects): a conditional load per element would serialise DW_NL round trips per stage
-    int win = beg;
-    auto window = [&](int r0) {
-        __syncthreads();
-        for (int i = tid; i < min(end - r0, DW_ROWS); i += 256) cells[i] = rows[r0 + i];
-        win = r0;
-        __syncthreads();
-    };
-    float pre[DW_NL];
-    auto fetch = [&](int r0) {
-        if (r0 + CB > win + DW_ROWS) window(r0);  // uniform over the workgroup
-        const int nb = min(CB, end - r0);
-#pragma unroll
-        for (int q = 0; q < DW_NL; ++q) {
-            const bool valid = qc[q] < nb;
-            const int b = cells[r0 - win + (valid ? qc[q] : 0)];
-            const bool from_dy = qj[q] < n_out;
-            const float* src = from_dy ? dy + ((int64_t)b * lddy + qj[q]) : x + ((int64_t)b * ldx + (qj[q] - n_out));
-            const float v = *src;
-            pre[q] = valid ? v : 0.f;
-        }
-    };
-    const bool bias_here = blockIdx.y == 0;
-    float accb = 0.f;
-    if (beg >= end) return;  // (never: a listed group has cells)
-    window(beg);
-    fetch(beg);
-    for (int r0 = beg; r0 < end; r0 += CB) {
-        const int nb = min(CB, end - r0);
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < DW_NL; ++q) sh[tid + 256 * q] = pre[q];
-        __syncthreads();
-        if (r0 + CB < end) fetch(r0 + CB);
-#pragma unroll 4
-        for (int cb = 0; cb < nb; ++cb) {
-            const float* row = sh + cb * stride;
-#pragma unroll
-            for (int u = 0; u < DW_U; ++u) acc[u] += row[ro[u]] * row[co[u]];
-            if (bias_here && tid < n_out) accb += row[tid];
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < DW_U; ++u) {
-        const int e = e_base + tid + 256 * u;
-        if (e < n) dW[e] = acc[u];
-    }
-    if (bias_here) {
-        for (int o = tid; o < n_out; o += 256) {  // n_out > 256: the rest of the bias gradient, row by row
-            if (o < 256) {
-                db[o] = accb;
-            } else {
-                float s = 0.f;
-                for (int r = beg; r < end; ++r) s += dy[(int64_t)rows[r] * lddy + o];
-                db[o] = s;
-            }
-        }
+    for (int u = 0; u < 4; ++u) {
+        const int64_t e = (int64_t)blockIdx.y * 1024 + threadIdx.x + 256 * u;
+        if (e >= tot) break;
+        float s = src[e];
+        for (int p = 1; p < pieces; ++p) s += src[p * tot + e];
+        if (e < n)
+            dW[e] = s;
+        else
+            db[e - n] = s;
     }
 }
 
@@ -285,18 +293,26 @@ extern "C" int mmvae_cond_linear_bwd_dx(int B, int n_in, int n_out, const float*
     return MMVAE_OK;
 }
 
-extern "C" int mmvae_cond_linear_bwd_dw(int n_groups, const int32_t* group_cond, const int32_t* group_start,
-                                        const int32_t* rows, int n_in, int n_out, const float* dy, int64_t lddy,
-                                        const float* x, int64_t ldx, float* grads, const int64_t* w_off,
-                                        const int64_t* b_off, mmvae_stream_t stream) {
-    if (n_groups <= 0 || n_in <= 0 || n_out <= 0 || n_in + n_out > 2048 || !group_cond || !group_start || !rows || !dy ||
-        !x || !grads || !w_off || !b_off || lddy < n_out || ldx < n_in)
+extern "C" int mmvae_cond_linear_bwd_dw(int n_chunks, const int32_t* chunk_dst, const int32_t* chunk_beg,
+                                        const int32_t* chunk_end, const int32_t* rows, int n_in, int n_out,
+                                        const float* dy, int64_t lddy, const float* x, int64_t ldx, float* grads,
+                                        const int64_t* w_off, const int64_t* b_off, int n_red, const int32_t* red_cond,
+                                        const int32_t* red_slot, const int32_t* red_n, float* partials,
+                                        mmvae_stream_t stream) {
+    if (n_chunks <= 0 || n_in <= 0 || n_out <= 0 || !chunk_dst || !chunk_beg || !chunk_end || !rows || !dy || !x ||
+        !grads || !w_off || !b_off || lddy < n_out || ldx < n_in || n_red < 0)
         return MMVAE_ERR_ARG;
-    const int64_t n = (int64_t)n_in * n_out;
-    const int64_t slices = (n + 256 * DW_U - 1) / (256 * DW_U);
-    if (slices > 65535) return MMVAE_ERR_ARG;
-    MMVAE_LAUNCH(cond_linear_bwd_dw_kernel, dim3(n_groups, (unsigned)slices), dim3(256), 0, (hipStream_t)stream, n_in,
-                 n_out, group_cond, group_start, rows, dy, lddy, x, ldx, grads, w_off, b_off);
+    if (n_red > 0 && (!red_cond || !red_slot || !red_n || !partials)) return MMVAE_ERR_ARG;
+    const int64_t tiles = (int64_t)((n_out + DW_T - 1) / DW_T) * ((n_in + DW_T - 1) / DW_T);
+    const int64_t red_y = ((int64_t)n_in * n_out + n_out + 1023) / 1024;
+    if (tiles > 65535 || red_y > 65535) return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(cond_dw_chunk_kernel, dim3(n_chunks, (unsigned)tiles), dim3(256), 0, (hipStream_t)stream, n_in, n_out,
+                 chunk_dst, chunk_beg, chunk_end, rows, dy, lddy, x, ldx, grads, w_off, b_off, partials);
     MMVAE_LAUNCH_CHECK();
+    if (n_red > 0) {
+        MMVAE_LAUNCH(cond_dw_reduce_kernel, dim3(n_red, (unsigned)red_y), dim3(256), 0, (hipStream_t)stream, n_in, n_out,
+                     red_cond, red_slot, red_n, partials, grads, w_off, b_off);
+        MMVAE_LAUNCH_CHECK();
+    }
     return MMVAE_OK;
 }

@@ -29,7 +29,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from . import _lib, dist as mdist, rng
+from . import _lib, cond_tables, dist as mdist, rng
 from .constants import REGISTRY_KEYS as RK
 from .modules.base.components import Adversarial, ConditionalLayer, FCBlock, _identity
 from .optim import HipAdam, arena_of
@@ -1090,8 +1090,8 @@ class _CondProgram:
     arena; the kernels address a block through per-condition element offsets (mmvae_cond_linear_*), so ONE table of all
     banks of this species serves every layer: position j of the (per step shuffled) selection order simply reads the
     GLOBAL block index of each cell from its own static array.  Per step the host derives from the metadata, for every
-    position: cond[R] (global block per cell), the cells grouped by block in batch order (rows / group_cond /
-    group_start, padded to R groups), and the optimiser's job table -- dense parameters + the blocks present, with each
+    position: cond[R] (global block per cell), the cells sorted by block and cut into chunks, the reduction list of
+    the blocks with several chunks (mmvae_amd.cond_tables, padded to fixed sizes), and the optimiser's job table -- dense parameters + the blocks present, with each
     tensor's own bias corrections (torch.optim.Adam semantics for parameters without a gradient: skipped, per-parameter
     step counts) -- packs them into one page-locked array and uploads it with one copy before the replay."""
 
@@ -1182,8 +1182,11 @@ class _CondProgram:
         b1, b2 = self.opt.param_groups[0]["betas"]
         n_dense_jobs = len(self.opt.job_table(self.dense, b1, b2)) if train else 0
         self.max_jobs = n_dense_jobs + sum(min(R, len(e["w_idx"])) for e in self.entries.values()) * jpb if train else 0
-        # ---- static device tables, filled by load(): per position cond[R] rows[R] group_cond[R] group_start[R+1]
-        self.P = 4 * R + 1
+        # ---- static device tables, filled by load(): one padded cond_tables set per position
+        self.P = cond_tables.words(R)
+        self.lay = cond_tables.layout(R)
+        self.n_chunks, self.n_red = cond_tables.max_chunks(R), cond_tables.max_reductions(R)
+        self.dw_partials = eng.buf("cond.dw_partials", (cond_tables.partial_slots(R) * (Z * Z + Z),)) if train else None
         self.idx_words = (self.n_pos * self.P + 1) // 2 * 2
         words = self.idx_words + 6 * self.max_jobs
         self.pack_dev = eng.buf(f"cond.pack.{eid}.{int(train)}", (words,), torch.int32)
@@ -1203,9 +1206,9 @@ class _CondProgram:
         self.mean = eng.buf("cond.mean", (R,)) if self.ln_eps is not None else None
         self.x_in = [None] * self.n_pos
 
-    def _ptr(self, j: int, part: int) -> int:
-        """Device address of part 0 cond / 1 rows / 2 group_cond / 3 group_start of position j."""
-        return self.pack_dev.data_ptr() + 4 * (j * self.P + part * self.R)
+    def _ptr(self, j: int, name: str) -> int:
+        """Device address of array `name` (cond_tables.layout) of position j."""
+        return self.pack_dev.data_ptr() + 4 * (j * self.P + self.lay[name])
 
     # ------------------------------------------------------------------------------------------ program emission
     def emit_forward(self, z: torch.Tensor):
@@ -1222,8 +1225,7 @@ class _CondProgram:
             self.y[j] = (y, ldy)
             lin_out, ld_lin = (self.lin, Z) if self.ln_eps is not None else (y, ldy)
             plan._emit(lib.mmvae_cond_linear_fwd, R, Z, Z, _p(x), Z, _p(params), _p(self.w_off), _p(self.b_off),
-                       self._ptr(j, 0), self._ptr(j, 1) if os.environ.get("MMVAE_COND_SORTED_FWD", "1") != "0" else None,
-                       _p(lin_out), ld_lin)
+                       self._ptr(j, "cond"), self._ptr(j, "rows"), _p(lin_out), ld_lin)
             if self.ln_eps is not None:
                 plan._emit(lib.mmvae_layernorm_fwd, R, Z, _p(self.lin), Z, self.ln_eps, _p(y), ldy, _p(self.mean),
                            _p(self.invstd[j]))
@@ -1243,15 +1245,17 @@ class _CondProgram:
                 gl, ldgl = self.gl, Z
             else:
                 gl, ldgl = gj, ldg
-            plan._emit(lib.mmvae_cond_linear_bwd_dw, R, self._ptr(j, 2), self._ptr(j, 3), self._ptr(j, 1), Z, Z, _p(gl),
-                       ldgl, _p(self.x_in[j]), Z, _p(a.grad), _p(self.w_off), _p(self.b_off))
+            plan._emit(lib.mmvae_cond_linear_bwd_dw, self.n_chunks, self._ptr(j, "chunk_dst"), self._ptr(j, "chunk_beg"),
+                       self._ptr(j, "chunk_end"), self._ptr(j, "rows"), Z, Z, _p(gl), ldgl, _p(self.x_in[j]), Z, _p(a.grad),
+                       _p(self.w_off), _p(self.b_off), self.n_red, self._ptr(j, "red_cond"), self._ptr(j, "red_slot"),
+                       self._ptr(j, "red_n"), _p(self.dw_partials))
             if self.parallel:
                 plan._emit(lib.mmvae_cond_linear_bwd_dx, R, Z, Z, _p(gl), ldgl, _p(a.data), _p(self.w_off),
-                           self._ptr(j, 0), _p(dz), Z, int(j != self.n_pos - 1))
+                           self._ptr(j, "cond"), _p(dz), Z, int(j != self.n_pos - 1))
             else:
                 dx = dz if j == 0 else self.eng.buf(f"cond.dx{j % 2}", (R, Z))
                 plan._emit(lib.mmvae_cond_linear_bwd_dx, R, Z, Z, _p(gl), ldgl, _p(a.data), _p(self.w_off),
-                           self._ptr(j, 0), _p(dx), Z, 0)
+                           self._ptr(j, "cond"), _p(dx), Z, 0)
                 g, ldg = dx, Z
 
     # ------------------------------------------------------------------------------------------------ per step
@@ -1287,18 +1291,10 @@ class _CondProgram:
             local = self._local_indices(ent, key, metadata)
             if len(local) != R:
                 raise _lib.HipLibraryError(f"engine: metadata has {len(local)} rows, the batch {R}")
-            seg = pack[j * P:(j + 1) * P]
-            seg[:R] = local + ent["base"]
-            rows = np.argsort(local, kind="stable").astype(np.int32)  # cells of a block stay in batch order
-            present, start = np.unique(local[rows], return_index=True)
-            n = len(present)
-            seg[R:2 * R] = rows
-            seg[2 * R:3 * R] = -1
-            seg[2 * R:2 * R + n] = present + ent["base"]
-            seg[3 * R:3 * R + n] = start
-            seg[3 * R + n:] = R
-            active.append(ent["w_idx"][present])
-            active.append(ent["b_idx"][present])
+            t = cond_tables.group_tables(local, ent["base"])
+            cond_tables.fill_padded(pack[j * P:(j + 1) * P], t, R)
+            active.append(ent["w_idx"][t["present"]])
+            active.append(ent["b_idx"][t["present"]])
         if self.train:
             act = np.concatenate(active)
             b1, b2 = self.opt.param_groups[0]["betas"]

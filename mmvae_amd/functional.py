@@ -103,25 +103,24 @@ class CondLinearFn(torch.autograd.Function):
     parameters took part (the others keep "no gradient", like under torch autograd)."""
 
     @staticmethod
-    def forward(ctx, x, bank, cond_dev, group_cond, group_start, rows, present_params):
+    def forward(ctx, x, bank, tables, present_params):
         x2 = x if x.is_contiguous() else x.contiguous()
         a = bank["opt"].arena
-        y = ops.cond_linear_fwd(x2, a.data, bank["w_off"], bank["b_off"], cond_dev, bank["n_out"], rows=rows)
-        ctx.save_for_backward(x2, cond_dev, group_cond, group_start, rows)
-        ctx.bank, ctx.present_params = bank, present_params
+        y = ops.cond_linear_fwd(x2, a.data, bank["w_off"], bank["b_off"], tables["cond"], bank["n_out"], rows=tables["rows"])
+        ctx.save_for_backward(x2)
+        ctx.bank, ctx.tables, ctx.present_params = bank, tables, present_params
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, cond_dev, group_cond, group_start, rows = ctx.saved_tensors
+        (x,) = ctx.saved_tensors
         bank = ctx.bank
         opt = bank["opt"]
         a = opt.arena
         gy = gy if gy.is_contiguous() else gy.contiguous()
-        dx = ops.cond_linear_bwd(gy, x, a.data, a.grad, bank["w_off"], bank["b_off"], cond_dev, group_cond, group_start,
-                                 rows)
+        dx = ops.cond_linear_bwd(gy, x, a.data, a.grad, bank["w_off"], bank["b_off"], ctx.tables)
         opt.note_direct_grads(ctx.present_params)
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None
 
 
 class ReparamKLFn(torch.autograd.Function):

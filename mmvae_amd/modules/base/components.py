@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 from torch.distributions import Normal
 
-from ... import backend
+from ... import backend, cond_tables, ops
 from ... import functional as HF
 from ... import optim
 
@@ -318,16 +318,10 @@ class ConditionalLayer(nn.Module):
             for v in set(values) - raw_index.keys():
                 raw_index[v] = bank["index"][self.format_condition_key(str(v))]  # KeyError: unknown condition, as before
             cond = np.fromiter((raw_index[v] for v in values), dtype=np.int32, count=len(values))
-        keys = values
-        order = np.argsort(cond, kind="stable").astype(np.int32)  # cells of a condition stay in batch order
-        present, start = np.unique(cond[order], return_index=True)
-        start = np.append(start, len(keys)).astype(np.int32)
-        dev = x.device
-        packed = torch.from_numpy(np.concatenate([cond, order, present.astype(np.int32), start])).to(dev, non_blocking=True)
-        B, P = len(keys), len(present)
-        cond_dev, rows, group_cond, group_start = packed[:B], packed[B:2 * B], packed[2 * B:2 * B + P], packed[2 * B + P:]
+        t = cond_tables.group_tables(cond)
+        present = t["present"]
         present_params = np.concatenate([bank["w_idx"][present], bank["b_idx"][present]])
-        y = HF.CondLinearFn.apply(x, bank, cond_dev, group_cond, group_start, rows, present_params)
+        y = HF.CondLinearFn.apply(x, bank, ops.cond_tables_to_device(t, x.device), present_params)
         if bank["ln_eps"] is not None:
             y = HF.LayerNormFn.apply(y, bank["ln_eps"])
         return y

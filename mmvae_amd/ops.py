@@ -561,11 +561,28 @@ def cond_linear_fwd(x: torch.Tensor, params: torch.Tensor, w_off: torch.Tensor, 
     return y
 
 
+_COND_PARTIALS: dict = {}
+
+
+def cond_tables_to_device(t: dict, device) -> dict:
+    """The index tables of `cond_tables.group_tables` as ONE device upload; returns int32 device views by name."""
+    import numpy as np
+
+    names = ("cond", "rows", "chunk_dst", "chunk_beg", "chunk_end", "red_cond", "red_slot", "red_n")
+    packed = torch.from_numpy(np.concatenate([t[n] for n in names])).to(device, non_blocking=True)
+    out, off = {}, 0
+    for n in names:
+        out[n] = packed[off:off + len(t[n])]
+        off += len(t[n])
+    return out
+
+
 def cond_linear_bwd(dy: torch.Tensor, x: torch.Tensor, params: torch.Tensor, grads: torch.Tensor, w_off: torch.Tensor,
-                    b_off: torch.Tensor, cond: torch.Tensor, group_cond: torch.Tensor, group_start: torch.Tensor,
-                    rows: torch.Tensor, dx: torch.Tensor = None, accumulate: bool = False) -> torch.Tensor:
+                    b_off: torch.Tensor, tables: dict, dx: torch.Tensor = None, accumulate: bool = False) -> torch.Tensor:
     """dx (into `dx`, added to it when `accumulate`), and dW / db of the PRESENT conditions written into `grads` (same
-    layout as `params`; groups with group_cond < 0 are padding)."""
+    layout as `params`).  `tables`: device int32 arrays cond, rows, chunk_*, red_* (cond_tables.group_tables)."""
+    from . import cond_tables
+
     lib = _lib.load()
     _chk(dy, "dy"), _chk(x, "x")
     B, n_out, lddy = _mat(dy, "dy")
@@ -573,10 +590,22 @@ def cond_linear_bwd(dy: torch.Tensor, x: torch.Tensor, params: torch.Tensor, gra
     if dx is None:
         dx = torch.empty((B, n_in), dtype=torch.float32, device=x.device)
     s = _stream()
-    _lib.check(lib.mmvae_cond_linear_bwd_dx(B, n_in, n_out, _ptr(dy), lddy, _ptr(params), _ptr(w_off), _ptr(cond),
+    _lib.check(lib.mmvae_cond_linear_bwd_dx(B, n_in, n_out, _ptr(dy), lddy, _ptr(params), _ptr(w_off), _ptr(tables["cond"]),
                                             _ptr(dx), _mat(dx, "dx")[2], int(accumulate), s), "mmvae_cond_linear_bwd_dx")
-    _lib.check(lib.mmvae_cond_linear_bwd_dw(int(group_cond.numel()), _ptr(group_cond), _ptr(group_start), _ptr(rows), n_in,
-                                            n_out, _ptr(dy), lddy, _ptr(x), ldx, _ptr(grads), _ptr(w_off), _ptr(b_off), s),
+    n_red = int(tables["red_cond"].numel())
+    partials = None
+    if n_red:
+        need = cond_tables.partial_slots(B) * (n_in * n_out + n_out)
+        key = (x.device, torch.cuda.current_stream().cuda_stream)
+        partials = _COND_PARTIALS.get(key)
+        if partials is None or partials.numel() < need:
+            partials = _COND_PARTIALS[key] = torch.empty(need, dtype=torch.float32, device=x.device)
+    _lib.check(lib.mmvae_cond_linear_bwd_dw(int(tables["chunk_dst"].numel()), _ptr(tables["chunk_dst"]),
+                                            _ptr(tables["chunk_beg"]), _ptr(tables["chunk_end"]), _ptr(tables["rows"]),
+                                            n_in, n_out, _ptr(dy), lddy, _ptr(x), ldx, _ptr(grads), _ptr(w_off), _ptr(b_off),
+                                            n_red, _ptr(tables["red_cond"]) if n_red else None,
+                                            _ptr(tables["red_slot"]) if n_red else None,
+                                            _ptr(tables["red_n"]) if n_red else None, _ptr(partials), s),
                "mmvae_cond_linear_bwd_dw")
     return dx
 

@@ -192,3 +192,47 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+
+
+# ---------------------------------------------------------------------------- conditional-layer index tables (8 f2)
+@pytest.mark.parametrize("B,C", [(512, 1), (512, 2), (512, 8), (512, 273), (512, 4644), (33, 5), (1, 1), (65, 2)])
+def test_cond_tables_cover_every_cell_once_in_batch_order(B, C):
+    """mmvae_amd.cond_tables: chunks partition the cells, stay inside one block, keep batch order, never exceed the
+    chunk size or the padded maxima; multi-chunk blocks get consecutive scratch slots and one reduction entry."""
+    import numpy as np
+
+    from mmvae_amd import cond_tables as CT
+
+    rng = np.random.default_rng(B * 7 + C)
+    local = rng.integers(0, C, B).astype(np.int32)
+    t = CT.group_tables(local, base=11)
+    assert np.array_equal(t["cond"], local + 11)
+    assert np.array_equal(np.sort(t["rows"]), np.arange(B))
+    seen, slots = np.zeros(B, dtype=int), {}
+    for d, b, e in zip(t["chunk_dst"], t["chunk_beg"], t["chunk_end"]):
+        assert 0 < e - b <= CT.CHUNK
+        cells = t["rows"][b:e]
+        assert np.all(np.diff(cells) > 0), "cells of a block stay in batch order"
+        blocks = set(local[cells].tolist())
+        assert len(blocks) == 1
+        seen[cells] += 1
+        if d >= 0:
+            assert d - 11 in blocks
+        else:
+            assert d <= -2
+            slots[-2 - d] = blocks.pop()
+    assert (seen == 1).all()
+    assert sorted(slots) == list(range(len(slots))) and len(slots) <= CT.partial_slots(B)
+    for c, s0, n in zip(t["red_cond"], t["red_slot"], t["red_n"]):
+        assert n > 1 and all(slots[s] == c - 11 for s in range(s0, s0 + n))
+    assert sum(t["red_n"]) == len(slots)
+    assert len(t["chunk_dst"]) <= CT.max_chunks(B) and len(t["red_cond"]) <= CT.max_reductions(B)
+    assert np.array_equal(t["present"], np.unique(local))
+    seg = np.full(CT.words(B), 12345, dtype=np.int32)
+    CT.fill_padded(seg, t, B)
+    lay = CT.layout(B)
+    n = len(t["chunk_dst"])
+    assert np.array_equal(seg[lay["chunk_dst"]:lay["chunk_dst"] + n], t["chunk_dst"])
+    assert (seg[lay["chunk_dst"] + n:lay["chunk_dst"] + CT.max_chunks(B)] == -1).all()
+    assert (seg[lay["red_cond"] + len(t["red_cond"]):lay["red_cond"] + CT.max_reductions(B)] == -1).all()
+    assert not (seg == 12345).any(), "every word of the padded set is written"

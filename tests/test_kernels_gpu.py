@@ -462,7 +462,8 @@ def test_gemm_with_fused_sum_of_squares(ops, layout, M, N, K):
 
 
 # ------------------------------------------------------------------------------------------ conditional layers (f2)
-@pytest.mark.parametrize("B,n_in,n_out,C", [(512, 128, 128, 37), (33, 8, 8, 5), (64, 24, 40, 200), (16, 300, 260, 3)])
+@pytest.mark.parametrize("B,n_in,n_out,C", [(512, 128, 128, 37), (512, 128, 128, 1), (300, 128, 128, 3), (33, 8, 8, 5),
+                                            (64, 24, 40, 200), (16, 300, 260, 3), (100, 130, 70, 2)])
 def test_cond_linear_fwd_bwd(ops, B, n_in, n_out, C):
     """Per-cell conditional Linear against a per-condition torch loop (the reference's ConditionalLayer.forward):
     forward / dx to 1e-5, dW / db of the present conditions to 1e-5, absent conditions untouched."""
@@ -485,27 +486,30 @@ def test_cond_linear_fwd_bwd(ops, B, n_in, n_out, C):
     bias = torch.stack([params[b_off[c]:b_off[c] + n_out] for c in range(C)])
     y_ref = torch.einsum("boi,bi->bo", W[cond], x) + bias[cond]
     dx_ref = torch.einsum("boi,bo->bi", W[cond], dy)
-    order = torch.argsort(cond, stable=True)
-    present, counts = torch.unique_consecutive(cond[order], return_counts=True)
-    start = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)])
-    dv = lambda t, dt: t.to(dt).cuda()
+    from mmvae_amd import cond_tables as CT
+
+    t = CT.group_tables(cond.numpy().astype("int32"))
+    present = torch.from_numpy(t["present"])
+    tables = ops.cond_tables_to_device(t, "cuda")
+    dv = lambda t_, dt: t_.to(dt).cuda()
     P, G = params.cuda(), torch.full((pos,), 7.0, device="cuda")
-    wo, bo, cd = dv(torch.tensor(w_off), torch.int64), dv(torch.tensor(b_off), torch.int64), dv(cond, torch.int32)
+    wo, bo, cd = dv(torch.tensor(w_off), torch.int64), dv(torch.tensor(b_off), torch.int64), tables["cond"]
     y = ops.cond_linear_fwd(dev(x), P, wo, bo, cd, n_out)
     assert rel_l2(y, y_ref) < 1e-5
     # the condition-sorted forward (a shared block read once per 8 cells) does the same arithmetic: same bits
-    y_sorted = ops.cond_linear_fwd(dev(x), P, wo, bo, cd, n_out, rows=dv(order, torch.int32))
+    y_sorted = ops.cond_linear_fwd(dev(x), P, wo, bo, cd, n_out, rows=tables["rows"])
     assert torch.equal(y_sorted, y)
-    dx = ops.cond_linear_bwd(dev(dy), dev(x), P, G, wo, bo, cd, dv(present, torch.int32), dv(start, torch.int32),
-                             dv(order, torch.int32))
+    dx = ops.cond_linear_bwd(dev(dy), dev(x), P, G, wo, bo, tables)
     assert rel_l2(dx, dx_ref) < 1e-5
-    # fixed-size launch of a captured program: one group slot per cell, unused slots marked -1; dx accumulated
-    pad = B - len(present)
-    gc_pad = torch.cat([present, torch.full((pad,), -1, dtype=present.dtype)])
-    gs_pad = torch.cat([start, torch.full((pad,), B, dtype=start.dtype)])
+    # fixed-size launch of a captured program: chunk / reduction lists padded to their maxima with -1; dx accumulated
+    seg = np.zeros(CT.words(B), dtype=np.int32)
+    CT.fill_padded(seg, t, B)
+    seg_dev, lay = torch.from_numpy(seg).cuda(), CT.layout(B)
+    sizes_of = dict(cond=B, rows=B, chunk_dst=CT.max_chunks(B), chunk_beg=CT.max_chunks(B), chunk_end=CT.max_chunks(B),
+                    red_cond=CT.max_reductions(B), red_slot=CT.max_reductions(B), red_n=CT.max_reductions(B))
+    padded = {k: seg_dev[lay[k]:lay[k] + n] for k, n in sizes_of.items()}
     G2 = torch.full((pos,), 7.0, device="cuda")
-    dx2 = ops.cond_linear_bwd(dev(dy), dev(x), P, G2, wo, bo, cd, dv(gc_pad, torch.int32), dv(gs_pad, torch.int32),
-                              dv(order, torch.int32), dx=dx.clone(), accumulate=True)
+    dx2 = ops.cond_linear_bwd(dev(dy), dev(x), P, G2, wo, bo, padded, dx=dx.clone(), accumulate=True)
     assert torch.equal(G2, G) and torch.equal(dx2, dx + dx)
     Gc = G.cpu()
     touched = torch.zeros(pos, dtype=torch.bool)

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Conditional-layer model at the reference's scale: Z = 128, one Linear(128, 128) + LayerNorm per
 condition, conditionals assay (8), sex (2), dataset_id (273), donor_id (4644) + the per-species block, B = 512, two
-20 000-gene modalities.  Times CMMVAEModel.training_step on the module path with the grouped HIP kernels and with the
-per-condition loop (MMVAE_COND_GROUPED=0), and checks that both give the same losses."""
+20 000-gene modalities.  Times CMMVAEModel.training_step through the captured engine (conditional layers inside the
+program), on the module path with the grouped HIP kernels, and on the module path with the per-condition loop of the
+reference (MMVAE_COND_GROUPED=0).  --engine-only: the first of the three."""
 import os
 import sys
 import tempfile

@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Host-side cost of one conditional-layer step through the captured engine (tools/bench_conditional.py's model):
+wall time per step with and without the final synchronisation, and the time inside _CondProgram.load split into
+metadata -> block indices ("li"), the optimiser job table ("jt"), waiting for a staging slot ("take") and the upload
+call ("up": includes waiting for the previous graph launch to be handed to the device queue)."""
 import sys, os, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
