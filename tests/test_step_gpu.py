@@ -74,13 +74,15 @@ def _trained_mirror(name, tmpdir, use_engine):
     meta = {cond: [f"{cond}_{int(i)}" for i in idx] for cond, idx in labels.items()}
     import pandas as pd
 
+    if case.get("cond"):
+        meta.update(H.cond_inputs(case, z, T, str(z["eval/expert_id"]))[0])
     metadata = pd.DataFrame(meta if meta else {"dummy": [0] * x.shape[0]})
     model.module.vae.encoder.explicit_eps = eps.cuda()
     return case, z, model, x.cuda(), metadata, str(z["eval/expert_id"])
 
 
 @pytest.mark.parametrize("use_engine", [False, True])
-@pytest.mark.parametrize("name", H.CASES)
+@pytest.mark.parametrize("name", H.CASES + H.COND_CASES)
 def test_eval_and_predict_paths_match_reference(name, use_engine, tmp_path):
     """validation_step (eval-mode forward + ELBO, cmmvae_model.py:219-248), predict_step /
     get_latent_embeddings (cmmvae.py:115-142) and cross-generation (cmmvae.py:95-107) on the HIP path against the
@@ -88,8 +90,12 @@ def test_eval_and_predict_paths_match_reference(name, use_engine, tmp_path):
     running statistics: activations are huge), tensors rel-L2 <= 2e-5."""
     import numpy as np
 
+    import random
+
     case, z, model, x, metadata, eid = _trained_mirror(name, str(tmp_path), use_engine)
+    reseed = (lambda: random.seed(case["seed"] * 100 + 99)) if case.get("cond") else (lambda: None)
     with torch.no_grad():
+        reseed()  # the shuffled order of the conditional layers (components.py:601-603), as the generator drew it
         ld = model.validation_step((x, metadata, eid))
         torch.cuda.synchronize()
         for k in ("loss", "recon_loss", "kl_loss"):
@@ -99,6 +105,9 @@ def test_eval_and_predict_paths_match_reference(name, use_engine, tmp_path):
         emb = model.predict_step((x, metadata, eid))
         assert H.rel_l2(emb["z"][0], z["eval/out/embedding_z"]) < 2e-5
         assert (emb["z"][1]["species"] == eid).all()
+        if use_engine and case.get("cond"):  # the validation program ran the conditional layers inside the engine
+            assert all(p.cond is not None for k, p in model._engine._plans.items() if k[0] == "validate")
+        reseed()
         qz, pz, zz, xhats, hidden = model.module(x, metadata, eid, cross_generate=True)
         assert set(xhats) == set(case["experts"])
         for other, xh in xhats.items():
