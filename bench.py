@@ -34,6 +34,8 @@ def parse():
                     help="csr: batches arrive as torch.sparse_csr (resident in HBM) and are densified per step (8 f1); "
                          "npz: batches stream from npz-CSR / pkl chunk files on disk through mmvae_amd.data (8 f4: host "
                          "feed and PCIe transfer inside the timed region)")
+    ap.add_argument("--genes", default="", help="diagnostics: comma-separated gene counts replacing the config's (one per "
+                                                "modality), e.g. 60530,52437 = the reference's human / mouse widths")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample")
     return ap.parse_args()
@@ -135,7 +137,10 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    cfg = synthetic.CONFIGS[a.config]
+    cfg = dict(synthetic.CONFIGS[a.config])
+    if a.genes:
+        widths = [int(v) for v in a.genes.split(",")]
+        cfg["experts"] = {eid: widths[i % len(widths)] for i, eid in enumerate(cfg["experts"])}
     B, K = cfg["batch"], cfg["K"]
 
     model = synthetic.build_model(cfg["experts"], adversarial=cfg["adversarial"], n_samples=K,

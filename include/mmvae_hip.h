@@ -63,6 +63,9 @@ const char* mmvae_build_arch(void);
 #define MMVAE_GEMM_RELU 1u        /* C = max(C, 0) after bias */
 #define MMVAE_GEMM_ACCUMULATE 2u  /* C += result (beta = 1) */
 #define MMVAE_GEMM_RAW_SLABS 4u   /* write exactly [splitk, M, ldc] partial slabs, no epilogue (bias must be NULL) */
+#define MMVAE_GEMM_OPERAND_SLACK 8u /* the caller guarantees 16 readable bytes past the last element of A and of B: lets a
+                                      rows-contiguous operand whose extent is not a multiple of 4 (60 530 / 52 437-gene
+                                      matrices) use the pipelined 16-byte loader (its edge group reads past a row end) */
 
 /* How the chip-filling GEMMs multiply (process-wide switch, host side; default BF16X3):
  *   MMVAE_GEMM_PRECISION_F32     v_mfma_f32_32x32x2_f32: exact f32 products (bitwise an fmaf chain), 157 TFLOP/s peak.

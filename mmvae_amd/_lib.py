@@ -18,7 +18,7 @@ OK, ERR_ARG, ERR_LAUNCH, ERR_WORKSPACE = 0, 1, 2, 3
 _ERR_NAMES = {1: "MMVAE_ERR_ARG", 2: "MMVAE_ERR_LAUNCH", 3: "MMVAE_ERR_WORKSPACE"}
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-GEMM_RELU, GEMM_ACCUMULATE, GEMM_RAW_SLABS = 1, 2, 4
+GEMM_RELU, GEMM_ACCUMULATE, GEMM_RAW_SLABS, GEMM_OPERAND_SLACK = 1, 2, 4, 8
 GEMM_PRECISION_F32, GEMM_PRECISION_BF16X3 = 0, 1
 ADAM_STATE_FLOATS = 8
 PREPARE_NORM, PREPARE_ADVANCE = 1, 2

@@ -71,6 +71,7 @@ struct GemmArgs {
     float alpha;
     unsigned flags;
     int aligned;           // 1: A, B 16-byte aligned with leading dimensions % 4 == 0; 2: and M, N, K % 4 == 0
+    int x3_vec;            // bf16x3 kernel: operands may be read in 16-byte groups (x3_vec_ok)
     // recon epilogue
     const float* x;
     float* xhat;
@@ -79,7 +80,7 @@ struct GemmArgs {
     int64_t ldx, ldxhat, lddp;
     int x_rows;    // x row = output row % x_rows (K-sample decode stacks K copies of the batch)
     int se_tiles;  // rows of se_part the caller reads (>= nt); the last column tile zeroes rows nt .. se_tiles-1
-    int c_vec;     // C (or the slabs) 16-byte regular: aligned base, ldc % 4 == 0, N % 4 == 0 -> 16-byte epilogue stores
+    int c_vec;     // 16-byte epilogue accesses (a group straddling the N edge falls back to elements); 0: element path
     int nwork;     // bf16x3 kernel: work items (output tiles x split-K slices), looped over by <= 512 workgroups
     float* sq_part;  // optional [mt * nt]: sum of squares of the C values this tile stores (unsplit launches only)
 };
@@ -213,7 +214,14 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
                 for (int n = 0; n < TN; ++n) {
                     const int col = bn * BN + wn * WTN + n * 32 + (l31 & ~3);
                     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                    if (!raw && g.bias && col < g.N) bv = *reinterpret_cast<const f32x4*>(g.bias + col);
+                    const bool whole = col + 3 < g.N;  // N % 4 != 0: the group straddling the edge goes element-wise
+                    if (!raw && g.bias && col < g.N) {
+                        if (whole) {
+                            bv = *reinterpret_cast<const f32x4*>(g.bias + col);
+                        } else {
+                            for (int j = 0; j < g.N - col; ++j) bv[j] = g.bias[col + j];
+                        }
+                    }
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         float a0 = acc[i][n][4 * gq], a1 = acc[i][n][4 * gq + 1], a2 = acc[i][n][4 * gq + 2],
@@ -232,13 +240,23 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
                         if (row < g.M && col < g.N) {
                             float* cp = C + (int64_t)row * g.ldc + col;
                             v = v * alpha + bv;
-                            if (accum) v += *reinterpret_cast<const f32x4*>(cp);
-                            if (relu) {
+                            if (whole) {
+                                if (accum) v += *reinterpret_cast<const f32x4*>(cp);
+                                if (relu) {
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                                }
+                                *reinterpret_cast<f32x4*>(cp) = v;
+                                sq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                            } else {
+                                for (int j = 0; j < g.N - col; ++j) {
+                                    float e = v[j];
+                                    if (accum) e += cp[j];
+                                    if (relu) e = fmaxf(e, 0.f);
+                                    cp[j] = e;
+                                    sq += e * e;
+                                }
                             }
-                            *reinterpret_cast<f32x4*>(cp) = v;
-                            sq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                         }
                     }
                 }
@@ -279,7 +297,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
             for (int n = 0; n < TN; ++n) {
                 const int col = bn * BN + wn * WTN + n * 32 + (l31 & ~3);
                 bv[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (g.bias && col < g.N) bv[n] = *reinterpret_cast<const f32x4*>(g.bias + col);
+                if (g.bias && col < g.N) {
+                    if (col + 3 < g.N) {
+                        bv[n] = *reinterpret_cast<const f32x4*>(g.bias + col);
+                    } else {
+                        for (int j = 0; j < g.N - col; ++j) bv[n][j] = g.bias[col + j];
+                    }
+                }
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -302,7 +326,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
                         p[2] = hi ? c2 : t0;
                         p[3] = hi ? c3 : t1;
                         const int col = bn * BN + wn * WTN + n * 32 + (l31 & ~3);
-                        if (row < g.M && col < g.N) {
+                        if (row < g.M && col + 3 < g.N) {
                             p += bv[n];
                             const f32x4 xv = *reinterpret_cast<const f32x4*>(g.x + (int64_t)xr * g.ldx + col);
                             f32x4 xh, dp;
@@ -315,6 +339,15 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
                             }
                             if (g.xhat) *reinterpret_cast<f32x4*>(g.xhat + (int64_t)row * g.ldxhat + col) = xh;
                             if (g.dP) *reinterpret_cast<f32x4*>(g.dP + (int64_t)row * g.lddp + col) = dp;
+                        } else if (row < g.M && col < g.N) {  // G % 4 != 0: the group straddling the edge, element-wise
+                            p += bv[n];
+                            for (int j = 0; j < g.N - col; ++j) {
+                                const float xhj = fmaxf(p[j], 0.f);
+                                const float d = xhj - g.x[(int64_t)xr * g.ldx + col + j];
+                                sr += d * d;
+                                if (g.xhat) g.xhat[(int64_t)row * g.ldxhat + col + j] = xhj;
+                                if (g.dP) g.dP[(int64_t)row * g.lddp + col + j] = (p[j] > 0.f) ? 2.f * d : 0.f;
+                            }
                         }
                     }
                     sr += __shfl_xor(sr, 4, 64);
@@ -749,12 +782,15 @@ __device__ __forceinline__ void x3p_offsets(unsigned (&off)[R / 32], int64_t ld,
         }
     } else {
         const int c4 = tid >> 3, kq = tid & 7;
-        const int xo = (r0 + 4 * c4 + 3 < Rtot) ? 4 * c4 : 0;
+        // a group that straddles the edge (extent % 4 != 0, operands with tail slack) is read whole: its rows beyond
+        // the matrix only reach accumulators that are never stored
+        const int Rpad = (Rtot + 3) & ~3;
+        const int xo = (r0 + 4 * c4 + 3 < Rpad) ? 4 * c4 : 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) off[j] = (unsigned)(((int64_t)(4 * kq + j) * ld + xo) * 4);
         if (NU == 5) {
             const int xt = 128 + 4 * ((tid >> 2) & 7);
-            off[NU - 1] = (unsigned)(((int64_t)(4 * (tid >> 5) + (tid & 3)) * ld + ((r0 + xt + 3 < Rtot) ? xt : 0)) * 4);
+            off[NU - 1] = (unsigned)(((int64_t)(4 * (tid >> 5) + (tid & 3)) * ld + ((r0 + xt + 3 < Rpad) ? xt : 0)) * 4);
         }
     }
 }
@@ -1384,10 +1420,21 @@ int launch_gemm_x3(int tile_id, const GemmArgs& g0, int nwork, hipStream_t s) {
 template <int AFORM, int BFORM, int EPI>
 int launch_gemm_forms(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) {
     if (tile_id >= 3)  // the pipelined bf16x3 loop needs 16-byte-regular operands and whole k-tiles
-        return (g.aligned == 2 && g.K % X3_BK == 0) ? launch_gemm_x3<AFORM, BFORM, true, EPI>(tile_id, g, nblocks, s)
+        return (g.x3_vec && g.K % X3_BK == 0) ? launch_gemm_x3<AFORM, BFORM, true, EPI>(tile_id, g, nblocks, s)
                                                     : launch_gemm_x3<AFORM, BFORM, false, EPI>(tile_id, g, nblocks, s);
     return g.aligned == 2 ? launch_gemm_vec<AFORM, BFORM, true, EPI>(tile_id, g, nblocks, s)
                           : launch_gemm_vec<AFORM, BFORM, false, EPI>(tile_id, g, nblocks, s);
+}
+
+// The pipelined bf16x3 loader reads operands in 16-byte groups.  gfx950 serves 16-byte global accesses at any 4-byte
+// aligned address at full rate (tools/ubench/unaligned.hip), so neither the base pointers nor the leading dimensions
+// need 16-byte alignment.  What is needed: groups along K must not cross the K edge (whole k-tiles: K % 32 == 0, or
+// the tail slab), and a rows-contiguous operand (A of TN along M, B of NN / TN along N) whose extent is not a multiple
+// of 4 has an edge group that reads up to 12 bytes past the end of a row -- past the matrix for its last row: legal
+// only when the caller vouches for the slack (MMVAE_GEMM_OPERAND_SLACK).
+bool x3_vec_ok(int layout, int M, int N, bool slack) {
+    const bool a_rc = layout == MMVAE_GEMM_TN, b_rc = layout != MMVAE_GEMM_NT;
+    return (!a_rc || M % 4 == 0 || slack) && (!b_rc || N % 4 == 0 || slack);
 }
 
 int bk_of(int layout, int tile_id) {
@@ -1434,6 +1481,9 @@ void plan(int layout, int M, int N, int K, int* tile_id, int* splitk) {
     if (t128 * sA >= 256 || t128 * sA >= t64 * sB) {
         *tile_id = 0;
         *splitk = sA;
+        // K not a multiple of the 32-wide k-tile (30 000 genes): one more slab for the K tail, so that the slabs over
+        // the whole k-tiles can run on the pipelined bf16x3 kernel (gemm_f32_impl, "tail slab")
+        if (sA > 1 && K % X3_BK != 0 && sA < 64) *splitk = sA + 1;
     } else {
         *tile_id = 2;
         *splitk = sB;
@@ -1507,7 +1557,8 @@ extern "C" int mmvae_gemm_sq_partials(int layout, int M, int N, int K, int opera
     // (aligned bases, leading dimensions and M, N, K multiples of 4), otherwise the larger of the two counts (the
     // launch zero-fills the slots it does not use)
     const int a = sq_tiles(layout, M, N, K, true), b = sq_tiles(layout, M, N, K, false);
-    if (operands_regular && (M | N | K) % 4 == 0) return a;
+    (void)operands_regular;  // (alignment no longer decides the tile shape; kept for ABI stability)
+    if (x3_vec_ok(layout, M, N, false)) return a;
     return a > b ? a : b;
 }
 
@@ -1537,8 +1588,10 @@ static int gemm_f32_impl(int layout, int M, int N, int K, float alpha, const flo
     if (splitk > 1 && tile_id == 1) tile_id = 0;  // split-K slices use the square tiles
     int aligned = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     if (aligned && M % 4 == 0 && N % 4 == 0 && K % 4 == 0) aligned = 2;
+    const bool x3v = x3_vec_ok(layout, M, N, (flags & MMVAE_GEMM_OPERAND_SLACK) != 0);
+    flags &= ~MMVAE_GEMM_OPERAND_SLACK;
     if (g_precision == MMVAE_GEMM_PRECISION_BF16X3 && tile_id != 2)  // chip-filling GEMMs: bf16x3 cores
-        tile_id = (aligned == 2 && K % X3_BK == 0 && splitk == 1) ? x3_tile_for(M, N, true) : 3;
+        tile_id = (x3v && K % X3_BK == 0 && splitk == 1) ? x3_tile_for(M, N, true) : 3;
     const TileShape ts = tile_shape(layout, tile_id);
     const int ktiles = ceil_div_i(K, bk_of(layout, tile_id));
     const bool raw = (flags & MMVAE_GEMM_RAW_SLABS) != 0;
@@ -1564,6 +1617,7 @@ static int gemm_f32_impl(int layout, int M, int N, int K, float alpha, const flo
     g.flags = flags;
     g.x_rows = 1;
     g.aligned = aligned;
+    g.x3_vec = x3v;
     if (raw) {
         g.C = C;
         g.ldc = ldc;
@@ -1578,8 +1632,7 @@ static int gemm_f32_impl(int layout, int M, int N, int K, float alpha, const flo
         g.ldc = ldc;
         g.slab_stride = 0;
     }
-    g.c_vec = aligned16(g.C) && g.ldc % 4 == 0 && N % 4 == 0 && (g.slab_stride % 4 == 0) &&
-              (!bias || aligned16(bias)) ? 1 : 0;
+    g.c_vec = 1;  // 16-byte epilogue accesses need no alignment on gfx950; the N-edge group goes element-wise
     if (sq_partials) {  // fused sum of squares: one partial per output tile, the rest of the caller's slots zeroed
         if (splitk != 1 || (int64_t)g.mt * g.nt > sq_capacity) return MMVAE_ERR_ARG;
         g.sq_part = sq_partials;
@@ -1588,15 +1641,44 @@ static int gemm_f32_impl(int layout, int M, int N, int K, float alpha, const flo
                            s) != hipSuccess)
             return MMVAE_ERR_LAUNCH;
     }
-    const int nblocks = g.mt * g.nt * splitk;
+    auto launch = [&](const GemmArgs& ga, int slabs) {
+        const int nblocks = ga.mt * ga.nt * slabs;
+        if (layout == MMVAE_GEMM_NT) return launch_gemm_forms<FORM_KC, FORM_KC, EPI_STD>(tile_id, ga, nblocks, s);
+        if (layout == MMVAE_GEMM_NN) return launch_gemm_forms<FORM_KC, FORM_RC, EPI_STD>(tile_id, ga, nblocks, s);
+        return launch_gemm_forms<FORM_RC, FORM_RC, EPI_STD>(tile_id, ga, nblocks, s);
+    };
     int rc;
-    if (layout == MMVAE_GEMM_NT)
-        rc = launch_gemm_forms<FORM_KC, FORM_KC, EPI_STD>(tile_id, g, nblocks, s);
-    else if (layout == MMVAE_GEMM_NN)
-        rc = launch_gemm_forms<FORM_KC, FORM_RC, EPI_STD>(tile_id, g, nblocks, s);
-    else
-        rc = launch_gemm_forms<FORM_RC, FORM_RC, EPI_STD>(tile_id, g, nblocks, s);
-    if (rc != MMVAE_OK) return rc;
+    // Tail slab: slab outputs of a bf16x3 split over 16-byte-regular operands whose K is not a multiple of the k-tile.
+    // The pipelined kernel needs whole k-tiles, so slabs 0 .. splitk-2 cover the whole k-tiles [0, K_main) and run on
+    // it; the last slab is the K tail (< 32 columns) on the element-guarded variant.  The slab count is unchanged.
+    const int K_main = K / X3_BK * X3_BK;
+    if (tile_id == 3 && splitk > 1 && x3v && K % X3_BK != 0 && K_main / X3_BK >= splitk - 1 && g.slab_stride > 0) {
+        GemmArgs gm = g;
+        gm.K = K_main;
+        gm.ktiles = K_main / X3_BK;
+        gm.ktiles_per_split = ceil_div_i(gm.ktiles, splitk - 1);
+        int sk_main = splitk - 1;
+        if (!raw) sk_main = ceil_div_i(gm.ktiles, gm.ktiles_per_split);
+        rc = launch(gm, sk_main);
+        if (rc != MMVAE_OK) return rc;
+        GemmArgs gt = g;
+        const bool a_kc = layout != MMVAE_GEMM_TN, b_kc = layout == MMVAE_GEMM_NT;
+        gt.A = A + (a_kc ? (int64_t)K_main : (int64_t)K_main * lda);
+        gt.B = B + (b_kc ? (int64_t)K_main : (int64_t)K_main * ldb);
+        gt.K = K - K_main;
+        gt.ktiles = 1;
+        gt.ktiles_per_split = 1;
+        gt.C = g.C + (int64_t)sk_main * g.slab_stride;
+        rc = launch(gt, 1);
+        if (rc != MMVAE_OK) return rc;
+        if (raw && sk_main + 1 < splitk) {  // (cannot happen: K_main / 32 >= splitk - 1 slabs of >= 1 k-tile)
+            return MMVAE_ERR_ARG;
+        }
+        if (!raw) splitk = sk_main + 1;
+    } else {
+        rc = launch(g, splitk);
+        if (rc != MMVAE_OK) return rc;
+    }
     if (!raw && splitk > 1) {
         const int64_t total = (int64_t)M * N;
         int blocks = (int)((total + 255) / 256);
@@ -1690,7 +1772,8 @@ extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, 
     const bool x3 = g_precision == MMVAE_GEMM_PRECISION_BF16X3;
     g.aligned = aligned16(h) && aligned16(W) && (ldh % 4 == 0) && (ldw % 4 == 0);
     if (g.aligned && rows % 4 == 0 && G % 4 == 0 && H % 4 == 0) g.aligned = 2;
-    const int tile_id = !x3 ? 1 : ((g.aligned == 2 && H % X3_BK == 0) ? x3_tile_for(rows, G, false) : 3);
+    g.x3_vec = 1;  // both operands K-contiguous: rows are clamped one by one, no edge groups
+    const int tile_id = !x3 ? 1 : ((H % X3_BK == 0) ? x3_tile_for(rows, G, false) : 3);
     g.mt = ceil_div_i(rows, 128);
     g.nt = ceil_div_i(G, tile_shape(0, tile_id).bn);
     g.se_tiles = mmvae_recon_tiles(G);  // rows nt .. se_tiles-1 of se_part are zeroed by the last column tile
@@ -1705,8 +1788,7 @@ extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, 
     g.ldxhat = ldxhat;
     g.lddp = lddp;
     g.x_rows = x_rows;
-    g.c_vec = G % 4 == 0 && aligned16(x) && ldx % 4 == 0 && (!xhat || (aligned16(xhat) && ldxhat % 4 == 0)) &&
-              (!dP || (aligned16(dP) && lddp % 4 == 0)) && (!bias || aligned16(bias));
+    g.c_vec = 1;
     return launch_gemm_forms<FORM_KC, FORM_KC, EPI_RECON>(tile_id, g, g.mt * g.nt, (hipStream_t)stream);
 }
 

@@ -38,6 +38,7 @@ NT, NN, TN = _lib.GEMM_NT, _lib.GEMM_NN, _lib.GEMM_TN
 RAW = _lib.GEMM_RAW_SLABS
 ACC = _lib.GEMM_ACCUMULATE
 RELU = _lib.GEMM_RELU
+SLACK = _lib.GEMM_OPERAND_SLACK  # every operand the engine hands to a GEMM has 16 readable bytes behind it
 MAX_POINTER_PLANS = 8
 
 
@@ -180,7 +181,12 @@ class StepEngine:
         key = (name, tuple(int(s) for s in shape), dtype)
         t = self._pool.get(key)
         if t is None:
-            t = torch.zeros(key[1], dtype=dtype, device=self.device)
+            # 16 spare elements behind every buffer: a rows-contiguous GEMM operand whose extent is not a multiple of 4
+            # (60 530 genes) is read in 16-byte groups up to its last row's end + 12 bytes (MMVAE_GEMM_OPERAND_SLACK)
+            n = 1
+            for d in key[1]:
+                n *= d
+            t = torch.zeros(n + 16, dtype=dtype, device=self.device)[:n].view(key[1])
             self._pool[key] = t
         return t
 
@@ -224,7 +230,8 @@ class StepEngine:
         seen = self._ptr_seen.get(pkey, 0)
         self._ptr_seen[pkey] = seen + 1
         n_ptr_plans = sum(1 for k in self._plans if k[-2] != 0)
-        if pkey in self._plans or (seen >= 1 and n_ptr_plans < MAX_POINTER_PLANS):
+        # a caller's tensor has no slack behind it: with a gene count that is not a multiple of 4 it is always staged
+        if x.shape[1] % 4 == 0 and (pkey in self._plans or (seen >= 1 and n_ptr_plans < MAX_POINTER_PLANS)):
             return pkey, x
         x_in = self.buf(f"x_static.{base_key[1]}", (B, x.shape[1]))
         if x.is_contiguous():  # own 16-byte copy kernel: the runtime's blit kernel reaches < 1 TB/s here
@@ -438,7 +445,7 @@ class _Plan:
         plan = self
 
         def call():
-            rc = plan.lib.mmvae_gemm_f32_sq(layout, M, N, K, alpha, _p(A), lda, _p(Bm), ldb, _p(Cm), ldc, _p(bias), flags,
+            rc = plan.lib.mmvae_gemm_f32_sq(layout, M, N, K, alpha, _p(A), lda, _p(Bm), ldb, _p(Cm), ldc, _p(bias), flags | SLACK,
                                             buf.data_ptr() + 4 * base, n_part, _s())
             if rc != 0:
                 raise _lib.HipLibraryError(f"mmvae_gemm_f32_sq failed with code {rc} (layout {layout}, {M}x{N}x{K})")
@@ -554,7 +561,7 @@ class _Plan:
         def launch():
             ws = plan.ws_side if use_ws == "side" else plan.ws
             c_ptr = _p(Cm) if Cm is not None else plan.slab.data_ptr()
-            rc = plan.lib.mmvae_gemm_f32(layout, M, N, K, alpha, _p(A), lda, _p(Bm), ldb, c_ptr, ldc, _p(bias), flags, sk,
+            rc = plan.lib.mmvae_gemm_f32(layout, M, N, K, alpha, _p(A), lda, _p(Bm), ldb, c_ptr, ldc, _p(bias), flags | SLACK, sk,
                                          ws.data_ptr() if use_ws else None, ws.numel() * 4 if use_ws else 0, _s())
             if rc != 0:
                 raise _lib.HipLibraryError(f"mmvae_gemm_f32 failed with code {rc} (layout {layout}, {M}x{N}x{K})")

@@ -42,8 +42,10 @@ class ParamArena:
             self.offsets.append(n)
             n += _pad4(p.numel())
         self.numel = n
-        self.data = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        # 16 spare elements behind each arena: its tensors may be read as rows-contiguous GEMM operands in 16-byte groups
+        # up to 12 bytes past their end (MMVAE_GEMM_OPERAND_SLACK)
+        self.data = torch.zeros(n + 16, dtype=torch.float32, device=dev)[:n]
+        self.grad = torch.zeros(n + 16, dtype=torch.float32, device=dev)[:n]
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         for p, off in zip(self.params, self.offsets):

@@ -53,7 +53,9 @@ def test_gemm_exact_integers(ops, layout, M, N, K):
 @pytest.mark.parametrize(
     "M,N,K,splitk",
     [(512, 1024, 2000, 0), (512, 512, 1024, 0), (96, 257, 300, 1), (130, 70, 1000, 5), (512, 2000, 512, 0),
-     (1024, 1200, 512, 1), (64, 48, 33, 0), (8, 24, 64, 0)],
+     (1024, 1200, 512, 1), (64, 48, 33, 0), (8, 24, 64, 0),
+     # K tail slab (K % 32 != 0 over 16-byte-regular operands: whole k-tiles on the pipelined kernel + one tail slab)
+     (512, 1024, 3000, 0), (512, 1024, 30000, 0), (256, 512, 2012, 4), (128, 128, 100, 3), (128, 128, 68, 2)],
 )
 def test_gemm_random(ops, layout, M, N, K, splitk):
     a, b = rnd(M, K, seed=1), rnd(K, N, seed=2)
@@ -120,6 +122,21 @@ def test_gemm_raw_slabs(ops, layout):
     slabs = ops.gemm_slabs(layout, dev(A), dev(Bm), splitk=6)
     assert slabs.shape == (6, M, N)
     assert rel_l2(slabs.sum(0), a.double() @ b.double()) < 2e-6
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(512, 1024, 30000), (512, 1024, 20016), (512, 1024, 60532)])
+def test_gemm_raw_slabs_with_k_tail(ops, layout, M, N, K):
+    """The engine's K = G reductions (encoder forward, decoder dX) at gene counts that are not a multiple of the k-tile:
+    the planner's slab count includes the tail slab; slabs sum to the product; the tail slab holds only the last
+    K % 32 columns' contribution."""
+    a, b = rnd(M, K, seed=7, scale=0.1), rnd(K, N, seed=8, scale=0.1)
+    A = a if layout != 2 else a.t().contiguous()
+    Bm = b.t().contiguous() if layout == 0 else b
+    slabs = ops.gemm_slabs(layout, dev(A), dev(Bm), splitk=0)
+    assert rel_l2(slabs.sum(0), a.double() @ b.double()) < 2e-6
+    km = K // 32 * 32
+    assert rel_l2(slabs[-1], a[:, km:].double() @ b[km:].double()) < 2e-6
 
 
 @pytest.mark.parametrize("R,B,G,H", [(8, 8, 64, 48), (33, 33, 257, 72), (128, 128, 2000, 256), (66, 33, 131, 40),
