@@ -78,6 +78,8 @@ def conditional_kwargs(base, case, tmpdir):
         conditional_config=base.FCBlockConfig(layers=[Z], dropout_rate=0.0, use_batch_norm=False,
                                               use_layer_norm=cond["layer_norm"], activation_fn=None),
         conditionals_directory=root, conditionals=list(cond["keys"]),
+        # (selection_order: null, as configs/model/compare/adversarial-conditional.yaml writes it, does not instantiate at
+        # the reference's HEAD: components.py:519 indexes it -- so the shuffled order is only reachable as "parallel")
         selection_order=["parallel"] if cond["parallel"] else list(cond["keys"]),
     )
     if cond["parallel"]:
@@ -342,6 +344,14 @@ CASES = {
                      cond=dict(keys=["assay", "donor_id", "species", "sex"], shared={"assay": 4, "sex": 2},
                                species_specific={"donor_id": {"human": 5, "mouse": 3}}, layer_norm=True,
                                parallel=True)),
+    # the reference's adversarial-conditional configuration in small: conditional layers AND two adversaries (on h1
+    # and on z, which is taken BEFORE the conditional layers)
+    "cond_adv": dict(seed=47, experts={"human": 48, "mouse": 40}, expert_hidden=[32, 16], vae_hidden=[12], Z=8, B=12,
+                     dropout=0.1, hidden_z=True, schedule=["human", "mouse", "human"], kl_weights=[1.0, 1.0, 0.5],
+                     adversarials=[[12, 8, 6], [8, 6]], conditions={"tissue": 4, "dev_stage": 3}, adv_weight=25,
+                     cond=dict(keys=["assay", "donor_id", "species", "sex"], shared={"assay": 4, "sex": 2},
+                               species_specific={"donor_id": {"human": 5, "mouse": 3}}, layer_norm=True,
+                               parallel=False)),
 }
 
 

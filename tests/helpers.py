@@ -9,7 +9,8 @@ from oracle import mmvae_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["c1_small", "two_mod_odd", "adversarial"]
-COND_CASES = ["cond_seq", "cond_par"]  # conditional layers after the reparameterisation
+# conditional layers after the reparameterisation; cond_adv: + two adversaries
+COND_CASES = ["cond_seq", "cond_par", "cond_adv"]
 
 
 def load_case(name):
