@@ -185,7 +185,8 @@ def main():
             while True:
                 yield from MultiModalBatches(feeds, seed=0, round_robin=True)
 
-        feed = endless()
+        # the whole feed (gather, metadata slices, H2D copies on a stream of its own) runs ahead of the step loop
+        feed = iter(mdata.Prefetcher(endless(), depth=3, device=device))
     if a.mode != "train":
         model.eval()
         model.trainer.set_stage("validation" if a.mode == "validate" else "predict")

@@ -303,6 +303,73 @@ class SpeciesChunks:
         raise TypeError("SpeciesChunks streams chunk files: its length is not known without reading them")
 
 
+class Prefetcher:
+    """Runs a batch iterable -- `SpeciesChunks`, `trainer.MultiModalBatches` over several of them -- in a background
+    thread, `depth` batches ahead of the training loop, so that the consumer thread only launches steps: waiting for a
+    gather, slicing the metadata and enqueueing the host-to-device copies no longer sit between two step launches.
+    On a GPU the producer issues its copies on a stream of its own; the consumer's stream waits for the event recorded
+    behind each batch, and the batch's device arrays are marked as used by the consumer's stream (allocator safety).
+    Order and content of the batches are unchanged; an exception in the producer is re-raised in the consumer."""
+
+    def __init__(self, batches, depth: int = 3, device: Optional[Union[str, torch.device]] = None):
+        self.batches = batches
+        self.depth = max(1, int(depth))
+        self.device = torch.device(device) if device is not None else None
+
+    def __iter__(self):
+        from contextlib import nullcontext
+
+        q: "queue.Queue" = queue.Queue(maxsize=self.depth)
+        done, stop = object(), threading.Event()
+        on_gpu = self.device is not None and self.device.type == "cuda"
+        stream = torch.cuda.Stream(device=self.device) if on_gpu else None
+
+        def put(item) -> bool:
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def work():
+            try:
+                with (torch.cuda.stream(stream) if on_gpu else nullcontext()):
+                    for item in self.batches:
+                        ev = None
+                        if on_gpu:
+                            ev = torch.cuda.Event()
+                            ev.record(stream)
+                        if not put((item, ev)):
+                            return
+                put(done)
+            except BaseException as e:  # noqa: BLE001 -- re-raised in the consumer
+                put(e)
+
+        thread = threading.Thread(target=work, daemon=True)
+        thread.start()
+        try:
+            while True:
+                got = q.get()
+                if got is done:
+                    return
+                if isinstance(got, BaseException):
+                    raise got
+                item, ev = got
+                if ev is not None:
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ev)
+                    x = item[0] if isinstance(item, tuple) else item
+                    if torch.is_tensor(x) and x.is_cuda:
+                        parts = ((x.crow_indices(), x.col_indices(), x.values()) if x.layout == torch.sparse_csr else (x,))
+                        for part in parts:
+                            part.record_stream(cur)
+                yield item
+        finally:
+            stop.set()
+
+
 def write_chunks(directory: str, name: str, matrix, metadata: pd.DataFrame, chunk_rows: int, split: str = "train",
                  compressed: bool = True) -> List[str]:
     """Write `{name}_{split}_counts_{i}.npz` / `{name}_{split}_metadata_{i}.pkl` chunk pairs (the layout the

@@ -124,3 +124,43 @@ def test_native_row_gather_matches_scipy_and_validates():
     assert lib.mmvae_feed_gather_rows(m.indptr.ctypes.data, m.indices.ctypes.data, 4, m.data.ctypes.data, 300,
                                       rows.ctypes.data, len(rows), np.empty(98, np.int64).ctypes.data, col.ctypes.data,
                                       val.ctypes.data, 3, 1, None) == 2
+
+
+def test_prefetcher_keeps_order_and_reraises(tmp_path):
+    """mmvae_amd.data.Prefetcher: same batches in the same order as the wrapped iterable; producer errors surface in
+    the consumer; an abandoned consumer stops the producer."""
+    import threading
+    import time
+
+    from mmvae_amd.data import Prefetcher
+
+    items = [(torch.full((2, 3), float(i)), {"i": i}, "human") for i in range(17)]
+    got = list(Prefetcher(iter(items), depth=2))
+    assert [int(g[0][0, 0]) for g in got] == list(range(17)) and all(a is b for a, b in zip(got, items))
+
+    def failing():
+        yield items[0]
+        raise KeyError("chunk 3 is missing")
+
+    it = iter(Prefetcher(failing(), depth=2))
+    assert next(it) is items[0]
+    with pytest.raises(KeyError, match="chunk 3"):
+        next(it)
+
+    produced = []
+
+    def endless():
+        i = 0
+        while True:
+            produced.append(i)
+            yield (torch.zeros(1), None, "human")
+            i += 1
+
+    before = threading.active_count()
+    it = iter(Prefetcher(endless(), depth=2))
+    next(it)
+    it.close()  # consumer walks away: the producer must not spin or block forever
+    time.sleep(0.5)
+    n = len(produced)
+    time.sleep(0.3)
+    assert len(produced) == n and threading.active_count() <= before + 1
