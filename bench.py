@@ -50,7 +50,7 @@ F32_MFMA_TFLOPS = 157.3
 HBM_TRAFFIC_PMC_BYTES = (2 * 48174 + 80000) * 1024
 
 
-def time_dominant_kernel(cfg, device, iters=20):
+def time_dominant_kernel(cfg, device, iters=10):
     """Roofline leg: the dominant kernel of the step (2 launches per step -- enc-L1 dW and, with the tile transposed,
     dec-L2 dW -- ~23 % of the GPU time in profiles/r1_bench_kernel_stats.csv) -- the weight-gradient GEMM of a G-wide layer, dW[1024, G] = dY^T[1024, B] .
     X[B, G] (TN layout, fp32 in / fp32 out, computed as 6 bf16 MFMAs per product = gemm_x3_kernel<TN>) -- launched on
@@ -67,7 +67,9 @@ def time_dominant_kernel(cfg, device, iters=20):
         ops.gemm(ops.GEMM_TN, dY, X, out=dW, splitk=1)
     torch.cuda.synchronize()
     # one event pair around `iters` back-to-back launches on the launch stream: the average is the kernel's duration
-    # (an event pair per launch would add the ~10 us host launch latency to every sample)
+    # (an event pair per launch would add the ~10 us host launch latency to every sample).  Kept short: after ~1.7 ms
+    # of nothing but this GEMM the chip lowers its clock and the same launch goes from 132 to 170 us
+    # (profiles/r1d: kernel trace of the leg) -- a state the training step, which interleaves lighter kernels, is never in
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):

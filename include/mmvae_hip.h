@@ -228,6 +228,11 @@ int mmvae_cross_entropy_sum(int B, int C, const float* logits, int64_t ld, const
                             mmvae_stream_t stream);
 /* sums n floats in fixed order (fp64 accumulate) into out[0] (+= if accumulate). Used for loss_rows, se_row. */
 int mmvae_sum_f32(int64_t n, const float* v, float* out, int accumulate, mmvae_stream_t stream);
+/* H such sums in one launch: out_each[h] = sum of the n floats at v + h*ld (each reduced as mmvae_sum_f32 does),
+ * out_total[0] = their float sum in row order (either output may be NULL).  The per-head losses of one adversarial
+ * phase and their total (cmmvae_model.py:118-136: sum over heads of CrossEntropyLoss(sum)). */
+int mmvae_sum_rows_f32(int H, int64_t n, const float* v, int64_t ld, float* out_each, float* out_total,
+                       mmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Optimiser: global-norm clip + Adam over a flat parameter arena (k12, k13)

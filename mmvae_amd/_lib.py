@@ -76,6 +76,7 @@ PROTOTYPES = {
     "mmvae_elbo_finalize": (_i, [_i, _i, _i, _p, _p, _p, _i, _p, _f, _p, _p, _p, _p]),
     "mmvae_cross_entropy_sum": (_i, [_i, _i, _p, _l, _p, _p, _p, _l, _p, _f, _p]),
     "mmvae_sum_f32": (_i, [_l, _p, _p, _i, _p]),
+    "mmvae_sum_rows_f32": (_i, [_i, _l, _p, _l, _p, _p, _p]),
     "mmvae_sqnorm_partials": (_l, [_l]),
     "mmvae_grad_sqnorm": (_i, [_l, _p, _p, _p]),
     "mmvae_adam_prepare": (_i, [_l, _p, _f, _f, _f, _f, _p, _u, _p]),

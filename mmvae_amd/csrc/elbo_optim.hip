@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(int B, int C, const float*
 // Wide heads (e.g. donor_id: 4644 classes): one WORKGROUP per row, the row held in registers (16-byte loads, all in
 // flight at once), block-wide max and sum of exponentials, gradient written from the registers: one pass over the
 // logits instead of three latency-bound strided sweeps by a single wavefront (37 us -> a few us at 512 x 4644).
-// Requires 16-byte-regular rows and C <= 256 * 4 * VPT.
+// Requires C <= 256 * 4 * VPT.
 template <int VPT>
 __global__ __launch_bounds__(256) void ce_rows_block_kernel(int B, int C, const float* __restrict__ logits, int64_t ld,
                                                             const int64_t* __restrict__ labels,
@@ -286,6 +286,31 @@ __global__ __launch_bounds__(1024) void sum_kernel(int64_t n, const float* __res
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + (float)red[0];
+}
+
+// H sums of n floats each (rows of v, stride ld) by one workgroup, each reduced exactly like sum_kernel, plus their
+// float total in row order: the per-head losses of one adversarial phase and their sum in one launch instead of a
+// sum + an accumulate per head.
+__global__ __launch_bounds__(1024) void sum_rows_kernel(int H, int64_t n, const float* __restrict__ v, int64_t ld,
+                                                        float* __restrict__ out_each, float* __restrict__ out_total) {
+    __shared__ double red[1024];
+    float total = 0.f;
+    for (int h = 0; h < H; ++h) {
+        const float* row = v + (int64_t)h * ld;
+        double s = 0.0;
+        for (int64_t i = threadIdx.x; i < n; i += 1024) s += (double)row[i];
+        __syncthreads();
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int st = 512; st >= 1; st >>= 1) {
+            if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        const float r = (float)red[0];
+        if (threadIdx.x == 0 && out_each) out_each[h] = r;
+        total = h == 0 ? r : total + r;
+    }
+    if (threadIdx.x == 0 && out_total) out_total[0] = total;
 }
 
 // ---------------------------------------------------------------- clip + Adam over a flat arena
@@ -682,8 +707,9 @@ extern "C" int mmvae_cross_entropy_sum(int B, int C, const float* logits, int64_
     if (B <= 0 || C <= 0 || !logits || !labels || ld < C) return MMVAE_ERR_ARG;
     if (!loss_rows && !dlogits) return MMVAE_ERR_ARG;
     if (dlogits && ldd < C) return MMVAE_ERR_ARG;
-    const bool regular = aligned16(logits) && ld % 4 == 0 && (!dlogits || (aligned16(dlogits) && ldd % 4 == 0));
-    if (regular && C >= 1024 && C <= 256 * 4 * 8)  // wide heads: one workgroup per row, the row in registers
+    // (16-byte row accesses need no alignment on gfx950: heads packed side by side in one logits matrix -- column
+    // offsets and a leading dimension that are not multiples of 4 -- take the same kernel)
+    if (C >= 1024 && C <= 256 * 4 * 8)  // wide heads: one workgroup per row, the row in registers
         MMVAE_LAUNCH(ce_rows_block_kernel<8>, dim3(B), dim3(256), 0, (hipStream_t)stream, B, C, logits, ld, labels,
                      loss_rows, dlogits, ldd, gscale_dev, gscale_host);
     else
@@ -696,6 +722,14 @@ extern "C" int mmvae_cross_entropy_sum(int B, int C, const float* logits, int64_
 extern "C" int mmvae_sum_f32(int64_t n, const float* v, float* out, int accumulate, mmvae_stream_t stream) {
     if (n < 0 || (n > 0 && !v) || !out) return MMVAE_ERR_ARG;
     MMVAE_LAUNCH(sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, v, out, accumulate);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_sum_rows_f32(int H, int64_t n, const float* v, int64_t ld, float* out_each, float* out_total,
+                                  mmvae_stream_t stream) {
+    if (H <= 0 || n < 0 || (n > 0 && !v) || ld < n || (!out_each && !out_total)) return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(sum_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, H, n, v, ld, out_each, out_total);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }

@@ -921,10 +921,26 @@ class _Plan:
             heads = {c: adv.heads[c].fc_layers[0].lin for c in self.conditions}
             logits = {c: eng.buf(f"adv{i}.logits.{c}", (B, heads[c].out_features)) for c in self.conditions}
             dlogits = {c: eng.buf(f"adv{i}.dlogits.{c}", (B, heads[c].out_features)) for c in self.conditions}
-            rows = eng.buf(f"adv{i}.ce_rows", (B,))
+            H = len(self.conditions)
+            rows = eng.buf(f"adv{i}.ce_rows", (max(H, 1), B))
             de = eng.buf(f"adv{i}.de", (B, n_e))
             gh = eng.buf(f"adv{i}.gh", (B, layers[0].n_in))
             opt = self.opt_adv[i - 1]
+            # heads laid out back to back in the optimiser arena (HipAdam pack=): ONE matrix [sum of classes, n_e] and
+            # one bias vector -> forward, bias gradient, weight gradient and input gradient of all heads are one launch
+            # each instead of one per head (and the input gradient loses its accumulate chain)
+            fused = None
+            lins = [heads[c] for c in self.conditions]
+            if H > 1 and os.environ.get("MMVAE_FUSE_HEADS", "1") != "0":
+                ws, bs = [l.weight for l in lins], [l.bias for l in lins]
+                chain = lambda ts: all(ts[k + 1].data_ptr() == ts[k].data_ptr() + 4 * ts[k].numel() for k in range(H - 1))
+                if chain(ws) and chain(bs) and chain([g(w) for w in ws]) and chain([g(b) for b in bs]):
+                    Ct = sum(l.out_features for l in lins)
+                    a, iw, ib = opt.arena, arena_of(ws[0])[1], arena_of(bs[0])[1]
+                    ow, ob = a.offsets[iw], a.offsets[ib]
+                    fused = dict(Ct=Ct, W=a.data[ow:ow + Ct * n_e].view(Ct, n_e), b=a.data[ob:ob + Ct],
+                                 gW=a.grad[ow:ow + Ct * n_e].view(Ct, n_e), gb=a.grad[ob:ob + Ct],
+                                 logits=eng.buf(f"adv{i}.logits_all", (B, Ct)), dlogits=eng.buf(f"adv{i}.dlogits_all", (B, Ct)))
             for phase in ("discriminator", "generator"):
                 gen = phase == "generator"
                 cur, ld = h, layers[0].n_in
@@ -933,19 +949,36 @@ class _Plan:
                     ld = l.n_out
                 e = cur
                 gscale = self.adv_weight if gen else 1.0
-                for ci, c in enumerate(self.conditions):
+                if fused is not None:
+                    Ct, col = fused["Ct"], 0
+                    self.gemm(NT, B, Ct, n_e, e, n_e, fused["W"], n_e, fused["logits"], Ct, bias=fused["b"])
+                    for ci, c in enumerate(self.conditions):
+                        Cn = heads[c].out_features
+                        self._emit(lib.mmvae_cross_entropy_sum, B, Cn, fused["logits"].data_ptr() + 4 * col, Ct,
+                                   _p(self.labels_dev[c]), _p(rows[ci]), fused["dlogits"].data_ptr() + 4 * col, Ct, None,
+                                   gscale)
+                        col += Cn
+                    self._emit_fc_bwd(B, Ct, fused["dlogits"], None, None, None, fused["gb"])
+                    self.gemm(TN, Ct, n_e, B, fused["dlogits"], Ct, e, n_e, fused["gW"], n_e, side=True)
+                    self.gemm(NN, B, n_e, Ct, fused["dlogits"], Ct, fused["W"], n_e, de, n_e)
+                for ci, c in enumerate(self.conditions if fused is None else []):
                     lin = heads[c]
                     Cn = lin.out_features
                     self.gemm(NT, B, Cn, n_e, e, n_e, lin.weight, n_e, logits[c], Cn, bias=lin.bias)
-                    self._emit(lib.mmvae_cross_entropy_sum, B, Cn, _p(logits[c]), Cn, _p(self.labels_dev[c]), _p(rows),
+                    self._emit(lib.mmvae_cross_entropy_sum, B, Cn, _p(logits[c]), Cn, _p(self.labels_dev[c]), _p(rows[ci]),
                                _p(dlogits[c]), Cn, None, gscale)
-                    self._emit(lib.mmvae_sum_f32, B, _p(rows), self.mptr(f"{phase}_{i}/{c}"), 0)
-                    self._emit(lib.mmvae_axpby, 1, 1.0, self.mptr(f"{phase}_{i}/{c}"), 1.0 if ci > 0 else 0.0,
-                               self.mptr(f"{phase}_{i}/summed"))
                     # head backward
                     self._emit_fc_bwd(B, Cn, dlogits[c], None, None, None, g(lin.bias))
                     self.gemm(TN, Cn, n_e, B, dlogits[c], Cn, e, n_e, g(lin.weight), n_e, side=True)
                     self.gemm(NN, B, n_e, Cn, dlogits[c], Cn, lin.weight, n_e, de, n_e, flags=ACC if ci > 0 else 0)
+                # the heads' losses and their sum: consecutive metrics words, one launch
+                first = self.slot(f"{phase}_{i}/{self.conditions[0]}") if H else None
+                for k, c in enumerate(self.conditions):
+                    assert self.slot(f"{phase}_{i}/{c}") == first + k
+                total_slot = self.slot(f"{phase}_{i}/summed")
+                if H:
+                    self._emit(lib.mmvae_sum_rows_f32, H, B, _p(rows), B, self.metrics.data_ptr() + 4 * first,
+                               self.metrics.data_ptr() + 4 * total_slot)
                 din, S = de, 1
                 for j in range(len(layers) - 1, -1, -1):
                     l = layers[j]

@@ -209,15 +209,26 @@ class CMMVAEModel(BaseModel):
     def configure_optimizers(self, optim_cls="Adam"):
         """One Adam(lr=5e-3, weight_decay=1e-6) per expert, one for the VAE, one per adversary, as a flat list plus
         `optimizer_map` (:299-351).  "Adam" builds the fused flat-arena HipAdam; torch.optim.AdamW for "AdamW"."""
-        def make(params):
+        def make(params, pack=None):
             if optim_cls == "Adam":
-                return HipAdam(params, lr=5e-3, weight_decay=1e-6)
+                return HipAdam(params, lr=5e-3, weight_decay=1e-6, pack=pack)
             return torch.optim.AdamW(params, lr=5e-3, weight_decay=1e-6)
+
+        def head_packs(adv):
+            """Single-Linear heads: their weights back to back, then their biases (one GEMM over all heads)."""
+            lins = []
+            for head in adv.heads.values():
+                if len(head.fc_layers) != 1 or [n for n, _ in head.fc_layers[0].named_children()] != ["lin"]:
+                    return None
+                lins.append(head.fc_layers[0].lin)
+            if len(lins) < 2 or any(l.bias is None for l in lins):
+                return None
+            return [[l.weight for l in lins], [l.bias for l in lins]]
 
         optim_dict = {"experts": {eid: make(m.parameters()) for eid, m in self.module.experts.items()},
                       "vae": make(self.module.vae.parameters())}
         if len(self.module.adversarials) > 0:
-            optim_dict["adversarials"] = {i: make(m.parameters())
+            optim_dict["adversarials"] = {i: make(m.parameters(), head_packs(m) if optim_cls == "Adam" else None)
                                           for i, m in enumerate(self.module.adversarials, start=1)}
         optimizers: list = []
         self.optimizer_map = convert_to_flat_list_and_map(optim_dict, optimizers)

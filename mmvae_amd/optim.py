@@ -28,7 +28,11 @@ def _pad4(n: int) -> int:
 class ParamArena:
     """Contiguous storage for a list of parameters (+ grads and Adam moments).  Device (HIP) or CPU plumbing."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    def __init__(self, params: Iterable[torch.nn.Parameter], pack: Optional[list] = None):
+        """`pack`: groups of parameters to be laid out back to back WITHOUT padding, in the order given (the heads of an
+        adversary: their weights form one [sum of classes, width] matrix and their biases one vector, so that all heads
+        run as one GEMM).  Placement only: the parameter order -- and with it the optimiser's state_dict -- is that of
+        `params`."""
         self.params: List[torch.nn.Parameter] = [p for p in params]
         if not self.params:
             raise ValueError("empty parameter list")
@@ -36,11 +40,22 @@ class ParamArena:
         if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
             raise ValueError("all parameters of an arena must be fp32 on one device")
         self.device = dev
-        self.offsets: List[int] = []
+        group_of = {id(q): gi for gi, grp in enumerate(pack or []) for q in grp}
+        placed: Dict[int, int] = {}
         n = 0
         for p in self.params:
-            self.offsets.append(n)
-            n += _pad4(p.numel())
+            if id(p) in placed:
+                continue
+            gi = group_of.get(id(p))
+            if gi is None:
+                placed[id(p)] = n
+                n += _pad4(p.numel())
+            else:  # the whole group here, unpadded between members
+                for q in pack[gi]:
+                    placed[id(q)] = n
+                    n += q.numel()
+                n = _pad4(n)
+        self.offsets: List[int] = [placed[id(p)] for p in self.params]
         self.numel = n
         # 16 spare elements behind each arena: its tensors may be read as rows-contiguous GEMM operands in 16-byte groups
         # up to 12 bytes past their end (MMVAE_GEMM_OPERAND_SLACK)
@@ -99,11 +114,11 @@ class HipAdam(torch.optim.Optimizer):
     with the gradient-norm clip fused in.  State (`step`, last pre-clip grad norm, clip coefficient) stays on device."""
 
     def __init__(self, params, lr: float = 5e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-6,
-                 max_grad_norm: Optional[float] = None):
+                 max_grad_norm: Optional[float] = None, pack: Optional[list] = None):
         params = list(params)
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
-        self.arena = ParamArena(params)
+        self.arena = ParamArena(params, pack=pack)
         for i, p in enumerate(self.arena.params):
             _ARENA_OF[id(p)] = (self, i)
         self._direct: set = set()  # parameters whose gradient a kernel wrote straight into the arena this step
