@@ -35,6 +35,27 @@ def test_engine_overlapped_exchange_program_matches_reference(name, monkeypatch)
     MU.check_against_golden(case, z, results)
 
 
+def test_engine_lazy_expert_update_matches_reference(monkeypatch):
+    """MMVAE_DP_LAZY_ADAM=1: the expert's clip + Adam is stashed and run at the start of that expert's next step (or at
+    engine.flush()); parameters and logged norms are the reference's once flushed."""
+    monkeypatch.setenv("MMVAE_DP_OVERLAP", "1")
+    monkeypatch.setenv("MMVAE_DP_LAZY_ADAM", "1")
+    from mmvae_amd.models import CMMVAEModel
+
+    orig = CMMVAEModel.training_step
+
+    def step_and_flush(self, batch, batch_idx):
+        out = orig(self, batch, batch_idx)
+        assert self._engine and self._engine._lazy, "the expert update must have been stashed"
+        self._engine.flush()
+        return out
+
+    monkeypatch.setattr(CMMVAEModel, "training_step", step_and_flush)
+    for name in ("two_mod_odd", "adversarial"):
+        case, z, results = MU.replay_training(name, "cuda", use_engine=True)
+        MU.check_against_golden(case, z, results)
+
+
 def test_engine_overlapped_exchange_with_single_rank_rccl(monkeypatch):
     """Same program with a real process group (RCCL, one rank): every collective is issued, on both communicators,
     beside the graph replays."""
