@@ -293,6 +293,19 @@ int mmvae_philox_keep_mask(int64_t n, float p_drop, uint8_t* mask, uint64_t* rng
                            int advance, mmvae_stream_t stream);
 int mmvae_philox_normal(int64_t n, float* out, uint64_t* rng_state, uint64_t stream_id, int advance,
                         mmvae_stream_t stream);
+/* Several fills in one launch (the keep-masks and the noise of one step): job = {out, n, stream_id, p_drop, kind}, kind 0
+ * = keep mask (uint8, as mmvae_philox_keep_mask), 1 = standard normal (float, as mmvae_philox_normal); no advance.  The
+ * numbers are those of the single-fill entry points for the same (rng_state, stream_id).  `jobs_dev` is a DEVICE array;
+ * max_n = the largest n among the jobs. */
+typedef struct {
+    void* out;
+    int64_t n;
+    uint64_t stream_id;
+    float p_drop;
+    int32_t kind;
+} mmvae_philox_job;
+int mmvae_philox_fill_jobs(int n_jobs, const mmvae_philox_job* jobs_dev, int64_t max_n, uint64_t* rng_state,
+                           mmvae_stream_t stream);
 /* rng_state[1] += by  (one call at the end of a step whose fills used distinct stream_ids with advance = 0). */
 int mmvae_philox_advance(uint64_t* rng_state, uint64_t by, mmvae_stream_t stream);
 

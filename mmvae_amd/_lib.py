@@ -86,6 +86,7 @@ PROTOTYPES = {
     "mmvae_philox_keep_mask": (_i, [_l, _f, _p, _p, _u64, _i, _p]),
     "mmvae_philox_normal": (_i, [_l, _p, _p, _u64, _i, _p]),
     "mmvae_philox_advance": (_i, [_p, _u64, _p]),
+    "mmvae_philox_fill_jobs": (_i, [_i, _p, _l, _p, _p]),
     "mmvae_axpby": (_i, [_l, _f, _p, _f, _p, _p]),
     "mmvae_scale_rows": (_i, [_i, _i, _p, _l, _p, _p, _l, _p]),
     "mmvae_sum_parts_batch": (_i, [_i, _p, _p]),
@@ -106,6 +107,12 @@ class SumJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("part_stride", C.c_int64), ("ld_src", C.c_int64),
                 ("ld_dst", C.c_int64), ("n_parts", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("alpha", C.c_float), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class PhiloxJob(C.Structure):
+    """mmvae_philox_job of include/mmvae_hip.h."""
+    _fields_ = [("out", C.c_void_p), ("n", C.c_int64), ("stream_id", C.c_uint64), ("p_drop", C.c_float),
+                ("kind", C.c_int32)]
 
 
 class GemmJob(C.Structure):

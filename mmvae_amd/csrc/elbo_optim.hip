@@ -575,6 +575,41 @@ __global__ __launch_bounds__(256) void philox_normal_kernel(int64_t n, float* __
 
 __global__ void philox_advance_kernel(uint64_t* rng, uint64_t by) { rng[1] += by; }
 
+// Several fills of one step (the dropout keep-masks and the rsample noise) in one launch: workgroup column blockIdx.y
+// serves job y with the arithmetic of philox_mask_kernel / philox_normal_kernel (counter-based: the numbers depend on
+// (offset, stream id, element) only, not on the launch shape).
+__global__ __launch_bounds__(256) void philox_fill_jobs_kernel(const mmvae_philox_job* __restrict__ jobs,
+                                                               const uint64_t* __restrict__ rng) {
+    const mmvae_philox_job job = jobs[blockIdx.y];
+    const uint64_t seed = rng[0], off = rng[1];
+    const int64_t n = job.n, nq = (n + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+        const u32x4 r = philox4x32_10(off + (uint64_t)q, job.stream_id, seed);
+        if (job.kind == 0) {
+            uint8_t* mask = static_cast<uint8_t*>(job.out);
+            const uint32_t rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t i = q * 4 + j;
+                if (i < n) mask[i] = (u01(rv[j]) >= job.p_drop) ? 1 : 0;
+            }
+        } else {
+            float* out = static_cast<float*>(job.out);
+            const float u0 = u01(r.x), u1 = u01(r.y), u2 = u01(r.z), u3 = u01(r.w);
+            const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+            float s0, c0, s1, c1;
+            sincosf(6.283185307179586f * u1, &s0, &c0);
+            sincosf(6.283185307179586f * u3, &s1, &c1);
+            const float nv[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t i = q * 4 + j;
+                if (i < n) out[i] = nv[j];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void axpby_kernel(int64_t n, float alpha, const float* __restrict__ x, float beta,
                                                     float* __restrict__ y) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -808,6 +843,15 @@ extern "C" int mmvae_philox_normal(int64_t n, float* out, uint64_t* rng_state, u
                            (uint64_t)((n + 3) / 4));
         MMVAE_LAUNCH_CHECK();
     }
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_philox_fill_jobs(int n_jobs, const mmvae_philox_job* jobs_dev, int64_t max_n, uint64_t* rng_state,
+                                      mmvae_stream_t stream) {
+    if (n_jobs <= 0 || n_jobs > 65535 || !jobs_dev || max_n <= 0 || !rng_state) return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(philox_fill_jobs_kernel, dim3(grid_for((max_n + 3) / 4, 256, 2048), n_jobs), dim3(256), 0,
+                 (hipStream_t)stream, jobs_dev, rng_state);
+    MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }
 

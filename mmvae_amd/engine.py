@@ -145,6 +145,20 @@ class StepEngine:
                 self._grad_of[id(p)] = opt.arena.grad_view(i)
         self._pool: Dict[tuple, torch.Tensor] = {}
         self._plans: Dict[tuple, "_Plan"] = {}
+        # The optimisers' device state words (step, pre-clip norm, clip coefficient, bias corrections) are moved into the
+        # top of the engine's metrics buffer: the logged gradient norms are then part of the one 256-word copy that ends
+        # the captured program, instead of a single-word copy launch per optimiser.
+        self._state_slot: Dict[int, int] = {}
+        opts_list = list(model.optimizers())
+        self.merge_launches = os.environ.get("MMVAE_MERGE_LAUNCHES", "1") != "0"  # diagnostics: =0 one launch per item
+        if len(opts_list) <= 8 and self.merge_launches:
+            metrics = self.buf("metrics", (256,))
+            for i, opt in enumerate(opts_list):
+                view = metrics[192 + 8 * i:200 + 8 * i]
+                if opt.state_dev.data_ptr() != view.data_ptr():
+                    view.copy_(opt.state_dev)
+                    opt.state_dev = view
+                self._state_slot[id(opt)] = 192 + 8 * i
         self._ptr_seen: Dict[tuple, int] = {}
         self.klw_dev = torch.ones(1, dtype=torch.float32, device=self.device)
         self._klw_host = None
@@ -432,8 +446,8 @@ class _Plan:
 
     def slot(self, name: str) -> int:
         if name not in self.metric_slots:
-            self.metric_slots[name] = 8 + len(self.metric_slots)
-            assert self.metric_slots[name] < 256
+            self.metric_slots[name] = 8 + sum(1 for v in self.metric_slots.values() if 8 <= v < 192)
+            assert self.metric_slots[name] < 192
         return self.metric_slots[name]
 
     def mptr(self, name: str) -> int:
@@ -752,6 +766,16 @@ class _Plan:
     def copy_scalar(self, src_ptr: int, dst_name: str):
         self._emit(self.lib.mmvae_axpby, 1, 1.0, src_ptr, 0.0, self.mptr(dst_name))
 
+    def log_norm(self, opt: HipAdam, name: str, final: bool = True):
+        """The pre-clip gradient norm `opt` has just computed, under metric `name`.  Its state word lives in the metrics
+        buffer (StepEngine.__init__): when it is not overwritten again within the step (`final`), the metric is that
+        word itself -- no launch; otherwise (discriminator phase: the generator phase reuses the optimiser) it is copied."""
+        base = self.eng._state_slot.get(id(opt))
+        if base is not None and final:
+            self.metric_slots[name] = base + 1
+        else:
+            self.copy_scalar(opt.state_dev.data_ptr() + 4, name)
+
     # ---------------------------------------------------------------------------------------------------- build
     def _build(self):
         eng, lib = self.eng, self.lib
@@ -803,8 +827,11 @@ class _Plan:
                    _p(eng.klw_dev), 1.0, _p(self.metrics), _p(self.w), _p(self.recon_row))
         if not train:  # validation: the program ends with the ELBO terms in the metrics buffer
             return self._finish_forward_only()
-        # total loss slot starts as the ELBO loss
-        self._emit(lib.mmvae_axpby, 1, 1.0, _p(self.metrics), 0.0, self.mptr("total_loss"))
+        # total loss slot starts as the ELBO loss (without adversaries it IS the ELBO loss word: no launch)
+        if self.has_adv or not eng.merge_launches:
+            self._emit(lib.mmvae_axpby, 1, 1.0, _p(self.metrics), 0.0, self.mptr("total_loss"))
+        else:
+            self.metric_slots["total_loss"] = 0
         for _ in range(int(os.environ.get("MMVAE_EXTRA_LAUNCHES", "0"))):  # diagnostics: price of one trivial launch
             self._emit(lib.mmvae_axpby, 1, 1.0, _p(self.metrics), 0.0, self.mptr("total_loss"))
 
@@ -875,26 +902,37 @@ class _Plan:
             self._emit(lib.mmvae_axpby, 256, 1.0, _p(self.metrics), 0.0, _p(self.log_buf))
 
         self.optimizer(self.opt_vae, self.clip_vae, exchange="wait" if early else "inline")
-        self.copy_scalar(self.opt_vae.state_dev.data_ptr() + 4, "grad_norms/vae")
+        self.log_norm(self.opt_vae, "grad_norms/vae")
         if early:  # the expert's exchange + update leave the main stream: its norm is logged from the comm stream
             emit_log_copy()
         self.optimizer(self.opt_exp, self.clip_exp, exchange="deferred" if early else "inline")
         if early:
             self.exp_norm_log = torch.zeros(1, dtype=torch.float32, device=eng.device)
         else:
-            self.copy_scalar(self.opt_exp.state_dev.data_ptr() + 4, "grad_norms/expert")
+            self.log_norm(self.opt_exp, "grad_norms/expert")
             emit_log_copy()
         self.segments.append(self._cur)
         self._cur = []
         # noise: Philox fills (production) or explicit buffers (parity mode), at the head of the program
         if not self.explicit:
             n_max = K * B * Z
+            fills = []  # every keep-mask and the rsample noise of the step: one launch (same numbers as one fill each)
             for i, l in enumerate(self.enc_layers + self.dec_layers[:-1]):
                 if l.mask is not None:
                     n_max = max(n_max, l.mask.numel())
-                    self._emit(lib.mmvae_philox_keep_mask, l.mask.numel(), l.p, _p(l.mask), _p(self.rng_state),
-                               rng.STREAM_DROPOUT + i, 0)
-            self._emit(lib.mmvae_philox_normal, K * B * Z, _p(self.eps), _p(self.rng_state), rng.STREAM_NORMAL, 0)
+                    fills.append(_lib.PhiloxJob(_p(l.mask), l.mask.numel(), rng.STREAM_DROPOUT + i, l.p, 0))
+            fills.append(_lib.PhiloxJob(_p(self.eps), K * B * Z, rng.STREAM_NORMAL, 0.0, 1))
+            if eng.merge_launches:
+                arr = (_lib.PhiloxJob * len(fills))(*fills)
+                jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(eng.device)
+                self._job_tables.append(jobs_dev)
+                self._emit(lib.mmvae_philox_fill_jobs, len(fills), jobs_dev.data_ptr(), n_max, _p(self.rng_state))
+            else:
+                for f in fills:
+                    if f.kind == 0:
+                        self._emit(lib.mmvae_philox_keep_mask, f.n, f.p_drop, f.out, _p(self.rng_state), f.stream_id, 0)
+                    else:
+                        self._emit(lib.mmvae_philox_normal, f.n, f.out, _p(self.rng_state), f.stream_id, 0)
             self._emit(lib.mmvae_philox_advance, _p(self.rng_state), (n_max + 3) // 4)
             self.segments[0] = self._cur + self.segments[0]
             self._cur = []
@@ -1019,11 +1057,11 @@ class _Plan:
                     self._emit(lib.mmvae_axpby, 1, self.adv_weight, self.mptr(f"generator_{i}/summed"), 1.0,
                                self.mptr("total_loss"))
                     self.optimizer(opt, 0.0, step=False)  # norm of the (never applied) generator-phase gradients
-                    self.copy_scalar(opt.state_dev.data_ptr() + 4, f"grad_norms/generator_{i}")
+                    self.log_norm(opt, f"grad_norms/generator_{i}")
                     self.adv_grad_into[id(h)] = gh
                 else:
                     self.optimizer(opt, self.clip_adv)
-                    self.copy_scalar(opt.state_dev.data_ptr() + 4, f"grad_norms/discriminator_{i}")
+                    self.log_norm(opt, f"grad_norms/discriminator_{i}", final=False)
 
     # ------------------------------------------------------------------------------------------------ execution
     def load_explicit_noise(self, enc_mod, expert):

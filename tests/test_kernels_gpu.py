@@ -355,6 +355,30 @@ def test_philox_streams(ops):
     assert torch.equal(ops.philox_keep_mask((512, 1024), 0.1, rng2), m1)  # reproducible from (seed, offset)
 
 
+def test_philox_fill_jobs_gives_the_numbers_of_single_fills(ops):
+    """mmvae_philox_fill_jobs (the keep-masks and the noise of one step in one launch) == one fill per launch."""
+    from mmvae_amd import _lib
+
+    rng = torch.tensor([1234, 77], dtype=torch.int64, device="cuda")
+    shapes = [((512, 1024), 0.1, 5), ((512, 512), 0.25, 6), ((33, 7), 0.5, 9)]
+    want = [ops.philox_keep_mask(sh, p, rng, stream_id=sid, advance=False) for sh, p, sid in shapes]
+    want_n = ops.philox_normal((3, 512, 128), rng, stream_id=2, advance=False)
+    got = [torch.zeros(sh, dtype=torch.uint8, device="cuda") for sh, _, _ in shapes]
+    got_n = torch.zeros((3, 512, 128), device="cuda")
+    jobs = [_lib.PhiloxJob(g.data_ptr(), g.numel(), sid, p, 0) for g, (_, p, sid) in zip(got, shapes)]
+    jobs.append(_lib.PhiloxJob(got_n.data_ptr(), got_n.numel(), 2, 0.0, 1))
+    arr = (_lib.PhiloxJob * len(jobs))(*jobs)
+    jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    lib = _lib.load()
+    _lib.check(lib.mmvae_philox_fill_jobs(len(jobs), jobs_dev.data_ptr(), max(j.n for j in jobs), rng.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream), "mmvae_philox_fill_jobs")
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+    assert torch.equal(got_n, want_n)
+    assert rng.tolist() == [1234, 77]  # no advance
+
+
 def test_small_utils(ops):
     x, y = rnd(1000, seed=1), rnd(1000, seed=2)
     out = ops.axpby(2.0, dev(x), -0.5, dev(y.clone()))
