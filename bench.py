@@ -45,9 +45,9 @@ def parse():
 BF16_DENSE_TFLOPS = 2500.0
 F32_MFMA_TFLOPS = 157.3
 # HBM bytes per launch of the roofline kernel, from the separate rocprofv3 --pmc passes summarised in
-# profiles/r1b_pmc_roofline_kernel.csv: 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, in KiB.
+# profiles/r1d_pmc_roofline_kernel.csv (r1b: 48174): 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, in KiB.
 # Algorithmic bytes of the launch: 4 (B*1024 + B*G + 1024*G) = 125.0 MB (X is re-read by the 8 row tiles: 2x fetch).
-HBM_TRAFFIC_PMC_BYTES = (2 * 48174 + 80000) * 1024
+HBM_TRAFFIC_PMC_BYTES = (2 * 47450 + 80000) * 1024
 
 
 def time_dominant_kernel(cfg, device, iters=10):

@@ -4,7 +4,9 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mmvae_amd import ops, synthetic  # noqa: E402
 
 cfg = synthetic.CONFIGS["c2"]
