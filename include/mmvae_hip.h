@@ -380,7 +380,8 @@ int mmvae_csr_to_dense_f32(int B, int G, int64_t nnz, const int64_t* crow_indice
  * condition index of every cell.
  *   _fwd      one workgroup per cell; with `rows` (DEVICE int32 [B]: the cells sorted by condition, NULL = none) and
  *             n_in <= 256, one workgroup per 8 sorted cells, which reads a block shared by them once.  Same results.
- *   _bwd_dx   dx[b] = W[c_b]^T dy[b].
+ *   _bwd_dx   dx[b] = W[c_b]^T dy[b] (+= when `accumulate`); with `rows` (as for _fwd) 8 sorted cells that share their
+ *             block are computed by one workgroup that reads the block once.
  *   _bwd_dw   dW[c] = sum_{b in c} dy[b] (x) x[b], db[c] = sum dy[b] for the conditions PRESENT in the batch.  `rows`
  *             (DEVICE int32 [B]) lists the cells sorted by condition, cells of a condition in batch order; the host
  *             cuts every present condition's range of `rows` into chunks of at most MMVAE_COND_DW_CHUNK cells:
@@ -397,8 +398,8 @@ int mmvae_cond_linear_fwd(int B, int n_in, int n_out, const float* x, int64_t ld
                           const int64_t* w_off, const int64_t* b_off, const int32_t* cond, const int32_t* rows, float* y,
                           int64_t ldy, mmvae_stream_t stream);
 int mmvae_cond_linear_bwd_dx(int B, int n_in, int n_out, const float* dy, int64_t lddy, const float* params,
-                             const int64_t* w_off, const int32_t* cond, float* dx, int64_t lddx, int accumulate,
-                             mmvae_stream_t stream);
+                             const int64_t* w_off, const int32_t* cond, const int32_t* rows, float* dx, int64_t lddx,
+                             int accumulate, mmvae_stream_t stream);
 int mmvae_cond_linear_bwd_dw(int n_chunks, const int32_t* chunk_dst, const int32_t* chunk_beg, const int32_t* chunk_end,
                              const int32_t* rows, int n_in, int n_out, const float* dy, int64_t lddy, const float* x,
                              int64_t ldx, float* grads, const int64_t* w_off, const int64_t* b_off, int n_red,

@@ -17,6 +17,7 @@
 //             the block's gradient once.  Absent conditions are not touched: their parameters keep "no gradient",
 //             which the optimiser honours (torch.optim.Adam skips them).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -75,25 +76,27 @@ __global__ __launch_bounds__(256) void cond_linear_fwd_sorted_kernel(int B, int 
     }
     __syncthreads();
     const int o0 = blockIdx.y * FW_RO + w * FW_RW;
-    float wv[FW_RW][T], bias[FW_RW];
-    int prev = -1;
-    for (int j = 0; j < nb; ++j) {
-        const int c = cnd[j];
-        if (c != prev) {  // wave-uniform
-            const float* W = params + w_off[c];
-            const float* bs = params + b_off[c];
+    float wv[FW_RW][T], bias[FW_RW], wn[FW_RW][T], bn[FW_RW];
+    auto fetch = [&](int c, float (&wd)[FW_RW][T], float (&bd)[FW_RW]) {
+        const float* W = params + w_off[c];
+        const float* bs = params + b_off[c];
 #pragma unroll
-            for (int r = 0; r < FW_RW; ++r) {
-                const int o = o0 + r;
+        for (int r = 0; r < FW_RW; ++r) {
+            const int o = o0 + r;
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const int k = lane + 64 * t;
-                    wv[r][t] = (o < n_out && k < n_in) ? W[(int64_t)o * n_in + k] : 0.f;
-                }
-                bias[r] = o < n_out ? bs[o] : 0.f;
+            for (int t = 0; t < T; ++t) {
+                const int k = lane + 64 * t;
+                wd[r][t] = (o < n_out && k < n_in) ? W[(int64_t)o * n_in + k] : 0.f;
             }
-            prev = c;
+            bd[r] = o < n_out ? bs[o] : 0.f;
         }
+    };
+    fetch(cnd[0], wv, bias);
+    for (int j = 0; j < nb; ++j) {
+        // the next cell's block rows (when it has another block) are requested before this cell's reduction: one HBM
+        // round trip per cell is hidden behind the previous cell's arithmetic (donor_id: every cell has its own block)
+        const bool change = j + 1 < nb && cnd[j + 1] != cnd[j];  // wave-uniform
+        if (change) fetch(cnd[j + 1], wn, bn);
         const float* xr = xs + j * n_in;
         float s[FW_RW];
 #pragma unroll
@@ -111,6 +114,14 @@ __global__ __launch_bounds__(256) void cond_linear_fwd_sorted_kernel(int B, int 
 #pragma unroll
             for (int r = 0; r < FW_RW; ++r)
                 if (o0 + r < n_out) y[(int64_t)cell[j] * ldy + o0 + r] = s[r] + bias[r];
+        }
+        if (change) {
+#pragma unroll
+            for (int r = 0; r < FW_RW; ++r) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) wv[r][t] = wn[r][t];
+                bias[r] = bn[r];
+            }
         }
     }
 }
@@ -130,6 +141,99 @@ __global__ __launch_bounds__(256) void cond_linear_bwd_dx_kernel(int n_in, int n
         for (int o = 0; o < n_out; ++o) s += W[(int64_t)o * n_in + k] * dys[o];
         float* out = dx + (int64_t)b * lddx + k;
         *out = accumulate ? *out + s : s;
+    }
+}
+
+// dx over cells taken in condition-sorted order.  Workgroups come in sets of DX_CB: set g owns the DX_CB consecutive
+// sorted cells rows[DX_CB g ..].  When they all share their block (the layers with few conditions), workgroup 0 of the set
+// computes all of them -- every element of W is loaded once and used DX_CB times -- and the others return at once;
+// otherwise workgroup s computes cell s alone (one block per cell: nothing to share).  Per cell the arithmetic is the
+// same on both paths: thread (h, k) sums W[o][k] dy[o] over its half h of the output rows in ascending order, the two
+// halves are added through LDS -- the result does not depend on how the cells happen to be grouped.
+constexpr int DX_CB = 8;
+constexpr int DX_K = 128;  // input columns per pass
+constexpr int DX_U = 8;    // output rows whose W elements are in flight together
+__global__ __launch_bounds__(256) void cond_linear_bwd_dx_sorted_kernel(int B, int n_in, int n_out,
+                                                                        const float* __restrict__ dy, int64_t lddy,
+                                                                        const float* __restrict__ params,
+                                                                        const int64_t* __restrict__ w_off,
+                                                                        const int32_t* __restrict__ cond,
+                                                                        const int32_t* __restrict__ rows,
+                                                                        float* __restrict__ dx, int64_t lddx,
+                                                                        int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];  // dy rows [DX_CB][n_out] | half-sums [DX_CB][DX_K]
+    __shared__ int cell[DX_CB], cnd[DX_CB];
+    const int tid = threadIdx.x, set = blockIdx.x / DX_CB, s = blockIdx.x % DX_CB;
+    const int r0 = set * DX_CB, nb = min(DX_CB, B - r0);
+    if (tid < nb) {
+        const int b = rows[r0 + tid];
+        cell[tid] = b;
+        cnd[tid] = cond[b];
+    }
+    __syncthreads();
+    bool uniform = true;
+    for (int j = 1; j < nb; ++j) uniform = uniform && (cnd[j] == cnd[0]);
+    if (uniform ? (s != 0) : (s >= nb)) return;
+    const int j0 = uniform ? 0 : s, nc = uniform ? nb : 1;  // this workgroup's cells: j0 .. j0 + nc - 1
+    float* dys = sh;
+    float* part = sh + DX_CB * n_out;
+    for (int i = tid; i < nc * n_out; i += 256) {
+        const int j = i / n_out, o = i - j * n_out;
+        dys[j * n_out + o] = dy[(int64_t)cell[j0 + j] * lddy + o];
+    }
+    __syncthreads();
+    const float* W = params + w_off[cnd[j0]];
+    const int h = tid >> 7, kk = tid & (DX_K - 1);
+    const int o_mid = (n_out + 1) / 2, o_beg = h ? o_mid : 0, o_end = h ? n_out : o_mid;
+    for (int k0 = 0; k0 < n_in; k0 += DX_K) {
+        const int k = k0 + kk;
+        float acc[DX_CB];
+#pragma unroll
+        for (int j = 0; j < DX_CB; ++j) acc[j] = 0.f;
+        if (k < n_in) {
+            // batches of DX_U output rows: the loads of a batch are issued together, then consumed in ascending order
+            const float* wp = W + k;
+            auto run = [&](auto full) {  // full: all DX_CB cells (no per-cell predicate in the inner loop)
+                int o = o_beg;
+                for (; o + DX_U <= o_end; o += DX_U) {
+                    float w[DX_U];
+#pragma unroll
+                    for (int u = 0; u < DX_U; ++u) w[u] = wp[(int64_t)(o + u) * n_in];
+#pragma unroll
+                    for (int u = 0; u < DX_U; ++u) {
+#pragma unroll
+                        for (int j = 0; j < DX_CB; ++j)
+                            if (decltype(full)::value || j < nc) acc[j] += w[u] * dys[j * n_out + o + u];
+                    }
+                }
+                for (; o < o_end; ++o) {
+                    const float w1 = wp[(int64_t)o * n_in];
+#pragma unroll
+                    for (int j = 0; j < DX_CB; ++j)
+                        if (decltype(full)::value || j < nc) acc[j] += w1 * dys[j * n_out + o];
+                }
+            };
+            if (nc == DX_CB)
+                run(std::true_type{});
+            else
+                run(std::false_type{});
+        }
+        __syncthreads();  // (the previous pass has finished reading `part`)
+        if (h == 1) {
+#pragma unroll
+            for (int j = 0; j < DX_CB; ++j)
+                if (j < nc) part[j * DX_K + kk] = acc[j];
+        }
+        __syncthreads();
+        if (h == 0 && k < n_in) {
+#pragma unroll
+            for (int j = 0; j < DX_CB; ++j)
+                if (j < nc) {
+                    float* out = dx + (int64_t)cell[j0 + j] * lddx + k;
+                    const float v = acc[j] + part[j * DX_K + kk];
+                    *out = accumulate ? *out + v : v;
+                }
+        }
     }
 }
 
@@ -282,11 +386,19 @@ extern "C" int mmvae_cond_linear_fwd(int B, int n_in, int n_out, const float* x,
 }
 
 extern "C" int mmvae_cond_linear_bwd_dx(int B, int n_in, int n_out, const float* dy, int64_t lddy, const float* params,
-                                        const int64_t* w_off, const int32_t* cond, float* dx, int64_t lddx,
-                                        int accumulate, mmvae_stream_t stream) {
+                                        const int64_t* w_off, const int32_t* cond, const int32_t* rows, float* dx,
+                                        int64_t lddx, int accumulate, mmvae_stream_t stream) {
     if (B <= 0 || n_in <= 0 || n_out <= 0 || n_out > 8192 || !dy || !params || !w_off || !cond || !dx ||
         lddy < n_out || lddx < n_in)
         return MMVAE_ERR_ARG;
+    if (rows && n_out <= 1024) {
+        const int sets = (B + DX_CB - 1) / DX_CB;
+        MMVAE_LAUNCH(cond_linear_bwd_dx_sorted_kernel, dim3(sets * DX_CB), dim3(256),
+                     (size_t)DX_CB * (n_out + DX_K) * sizeof(float), (hipStream_t)stream, B, n_in, n_out, dy, lddy, params,
+                     w_off, cond, rows, dx, lddx, accumulate);
+        MMVAE_LAUNCH_CHECK();
+        return MMVAE_OK;
+    }
     MMVAE_LAUNCH(cond_linear_bwd_dx_kernel, dim3(B), dim3(256), n_out * sizeof(float), (hipStream_t)stream, n_in, n_out,
                  dy, lddy, params, w_off, cond, dx, lddx, accumulate);
     MMVAE_LAUNCH_CHECK();

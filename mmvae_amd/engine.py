@@ -1365,11 +1365,11 @@ class _CondProgram:
                        self._ptr(j, "red_n"), _p(self.dw_partials))
             if self.parallel:
                 plan._emit(lib.mmvae_cond_linear_bwd_dx, R, Z, Z, _p(gl), ldgl, _p(a.data), _p(self.w_off),
-                           self._ptr(j, "cond"), _p(dz), Z, int(j != self.n_pos - 1))
+                           self._ptr(j, "cond"), self._ptr(j, "rows"), _p(dz), Z, int(j != self.n_pos - 1))
             else:
                 dx = dz if j == 0 else self.eng.buf(f"cond.dx{j % 2}", (R, Z))
                 plan._emit(lib.mmvae_cond_linear_bwd_dx, R, Z, Z, _p(gl), ldgl, _p(a.data), _p(self.w_off),
-                           self._ptr(j, "cond"), _p(dx), Z, 0)
+                           self._ptr(j, "cond"), self._ptr(j, "rows"), _p(dx), Z, 0)
                 g, ldg = dx, Z
 
     # ------------------------------------------------------------------------------------------------ per step

@@ -578,7 +578,8 @@ def cond_tables_to_device(t: dict, device) -> dict:
 
 
 def cond_linear_bwd(dy: torch.Tensor, x: torch.Tensor, params: torch.Tensor, grads: torch.Tensor, w_off: torch.Tensor,
-                    b_off: torch.Tensor, tables: dict, dx: torch.Tensor = None, accumulate: bool = False) -> torch.Tensor:
+                    b_off: torch.Tensor, tables: dict, dx: torch.Tensor = None, accumulate: bool = False,
+                    sorted_dx: bool = True) -> torch.Tensor:
     """dx (into `dx`, added to it when `accumulate`), and dW / db of the PRESENT conditions written into `grads` (same
     layout as `params`).  `tables`: device int32 arrays cond, rows, chunk_*, red_* (cond_tables.group_tables)."""
     from . import cond_tables
@@ -591,7 +592,8 @@ def cond_linear_bwd(dy: torch.Tensor, x: torch.Tensor, params: torch.Tensor, gra
         dx = torch.empty((B, n_in), dtype=torch.float32, device=x.device)
     s = _stream()
     _lib.check(lib.mmvae_cond_linear_bwd_dx(B, n_in, n_out, _ptr(dy), lddy, _ptr(params), _ptr(w_off), _ptr(tables["cond"]),
-                                            _ptr(dx), _mat(dx, "dx")[2], int(accumulate), s), "mmvae_cond_linear_bwd_dx")
+                                            _ptr(tables["rows"]) if sorted_dx else None, _ptr(dx), _mat(dx, "dx")[2],
+                                            int(accumulate), s), "mmvae_cond_linear_bwd_dx")
     n_red = int(tables["red_cond"].numel())
     partials = None
     if n_red:
