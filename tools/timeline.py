@@ -4,7 +4,7 @@ import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
-anchor = sys.argv[2] if len(sys.argv) > 2 else "philox_mask"
+anchor = sys.argv[2] if len(sys.argv) > 2 else "philox_fill_jobs"
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
 # steps start at the first anchor kernel after a non-anchor kernel
 starts = [i for i, r in enumerate(rows) if anchor in r[0] and (i == 0 or anchor not in rows[i - 1][0])]
