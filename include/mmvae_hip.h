@@ -226,6 +226,14 @@ int mmvae_elbo_finalize(int B, int K, int T, const float* se_part, const float* 
 int mmvae_cross_entropy_sum(int B, int C, const float* logits, int64_t ld, const int64_t* labels, float* loss_rows,
                             float* dlogits, int64_t ldd, const float* gscale_dev, float gscale_host,
                             mmvae_stream_t stream);
+/* The heads of one adversary in ONE launch: head h reads columns [col[h], col[h] + classes[h]) of `logits` [B, ld]
+ * (the heads' Linears packed into one matrix), its labels at labels + h*B, and writes its per-row losses to
+ * loss_rows + h*B and its gradient into the same columns of `dlogits`.  col / classes: DEVICE int32 [H];
+ * max_classes = the widest head (<= 8192).  Per head the arithmetic is that of the wide-head kernel of
+ * mmvae_cross_entropy_sum. */
+int mmvae_cross_entropy_heads(int B, int H, int max_classes, const int32_t* col_dev, const int32_t* classes_dev,
+                              const float* logits, int64_t ld, const int64_t* labels, float* loss_rows, float* dlogits,
+                              int64_t ldd, float gscale, mmvae_stream_t stream);
 /* sums n floats in fixed order (fp64 accumulate) into out[0] (+= if accumulate). Used for loss_rows, se_row. */
 int mmvae_sum_f32(int64_t n, const float* v, float* out, int accumulate, mmvae_stream_t stream);
 /* H such sums in one launch: out_each[h] = sum of the n floats at v + h*ld (each reduced as mmvae_sum_f32 does),

@@ -215,14 +215,11 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(int B, int C, const float*
 // logits instead of three latency-bound strided sweeps by a single wavefront (37 us -> a few us at 512 x 4644).
 // Requires C <= 256 * 4 * VPT.
 template <int VPT>
-__global__ __launch_bounds__(256) void ce_rows_block_kernel(int B, int C, const float* __restrict__ logits, int64_t ld,
-                                                            const int64_t* __restrict__ labels,
-                                                            float* __restrict__ loss_rows, float* __restrict__ dlogits,
-                                                            int64_t ldd, const float* __restrict__ gscale_dev,
-                                                            float gscale_host) {
+__device__ __forceinline__ void ce_row_block(int b, int C, const float* __restrict__ logits, int64_t ld,
+                                             const int64_t* __restrict__ labels, float* __restrict__ loss_rows,
+                                             float* __restrict__ dlogits, int64_t ldd, float gscale) {
     __shared__ float red[4];
-    const float gscale = gscale_host * (gscale_dev ? *gscale_dev : 1.f);
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float* lr = logits + (int64_t)b * ld;
     const int nv = C >> 2;  // whole float4 groups; the (C & 3) tail elements are handled by the first threads
     f32x4 v[VPT];
@@ -271,6 +268,29 @@ __global__ __launch_bounds__(256) void ce_rows_block_kernel(int B, int C, const 
         }
         if (ti < C) dr[ti] = gscale * (expf(tail - lse) - ((int64_t)ti == y ? 1.f : 0.f));
     }
+}
+
+template <int VPT>
+__global__ __launch_bounds__(256) void ce_rows_block_kernel(int B, int C, const float* __restrict__ logits, int64_t ld,
+                                                            const int64_t* __restrict__ labels,
+                                                            float* __restrict__ loss_rows, float* __restrict__ dlogits,
+                                                            int64_t ldd, const float* __restrict__ gscale_dev,
+                                                            float gscale_host) {
+    ce_row_block<VPT>(blockIdx.x, C, logits, ld, labels, loss_rows, dlogits, ldd,
+                      gscale_host * (gscale_dev ? *gscale_dev : 1.f));
+}
+
+// All heads of an adversary in one launch: head h = columns [col[h], col[h] + classes[h]) of one logits matrix, labels
+// and per-row losses in rows h of [H, B] arrays.  Workgroup (b, h) is ce_rows_block_kernel's workgroup b of head h.
+template <int VPT>
+__global__ __launch_bounds__(256) void ce_heads_kernel(int B, const int32_t* __restrict__ col,
+                                                       const int32_t* __restrict__ classes,
+                                                       const float* __restrict__ logits, int64_t ld,
+                                                       const int64_t* __restrict__ labels, float* __restrict__ loss_rows,
+                                                       float* __restrict__ dlogits, int64_t ldd, float gscale) {
+    const int h = blockIdx.y, c0 = col[h];
+    ce_row_block<VPT>(blockIdx.x, classes[h], logits + c0, ld, labels + (int64_t)h * B,
+                      loss_rows ? loss_rows + (int64_t)h * B : nullptr, dlogits ? dlogits + c0 : nullptr, ldd, gscale);
 }
 
 // fixed-order fp64 sum of n floats by one workgroup
@@ -750,6 +770,18 @@ extern "C" int mmvae_cross_entropy_sum(int B, int C, const float* logits, int64_
     else
         MMVAE_LAUNCH(ce_rows_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, C, logits, ld,
                      labels, loss_rows, dlogits, ldd, gscale_dev, gscale_host);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_cross_entropy_heads(int B, int H, int max_classes, const int32_t* col_dev, const int32_t* classes_dev,
+                                         const float* logits, int64_t ld, const int64_t* labels, float* loss_rows,
+                                         float* dlogits, int64_t ldd, float gscale, mmvae_stream_t stream) {
+    if (B <= 0 || H <= 0 || H > 65535 || max_classes <= 0 || max_classes > 256 * 4 * 8 || !col_dev || !classes_dev ||
+        !logits || !labels || (!loss_rows && !dlogits))
+        return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(ce_heads_kernel<8>, dim3(B, H), dim3(256), 0, (hipStream_t)stream, B, col_dev, classes_dev, logits, ld,
+                 labels, loss_rows, dlogits, ldd, gscale);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }

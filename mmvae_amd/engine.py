@@ -1015,12 +1015,23 @@ class _Plan:
                 if fused is not None:
                     Ct, col = fused["Ct"], 0
                     self.gemm(NT, B, Ct, n_e, e, n_e, fused["W"], n_e, fused["logits"], Ct, bias=fused["b"])
-                    for ci, c in enumerate(self.conditions):
-                        Cn = heads[c].out_features
-                        self._emit(lib.mmvae_cross_entropy_sum, B, Cn, fused["logits"].data_ptr() + 4 * col, Ct,
-                                   _p(self.labels_dev[c]), _p(rows[ci]), fused["dlogits"].data_ptr() + 4 * col, Ct, None,
+                    widths = [heads[c].out_features for c in self.conditions]
+                    if max(widths) <= 8192 and eng.merge_launches:  # every head's cross-entropy in one launch
+                        if "cols" not in fused:
+                            starts = [sum(widths[:k]) for k in range(H)]
+                            fused["cols"] = torch.tensor(starts + widths, dtype=torch.int32, device=eng.device)
+                            self._job_tables.append(fused["cols"])  # the captured program reads it on every replay
+                        cw = fused["cols"]
+                        self._emit(lib.mmvae_cross_entropy_heads, B, H, max(widths), _p(cw), cw.data_ptr() + 4 * H,
+                                   _p(fused["logits"]), Ct, _p(self._labels_all), _p(rows), _p(fused["dlogits"]), Ct,
                                    gscale)
-                        col += Cn
+                    else:
+                        for ci, c in enumerate(self.conditions):
+                            Cn = heads[c].out_features
+                            self._emit(lib.mmvae_cross_entropy_sum, B, Cn, fused["logits"].data_ptr() + 4 * col, Ct,
+                                       _p(self.labels_dev[c]), _p(rows[ci]), fused["dlogits"].data_ptr() + 4 * col, Ct,
+                                       None, gscale)
+                            col += Cn
                     self._emit_fc_bwd(B, Ct, fused["dlogits"], None, None, None, fused["gb"])
                     self.gemm(TN, Ct, n_e, B, fused["dlogits"], Ct, e, n_e, fused["gW"], n_e, side=True)
                     self.gemm(NN, B, n_e, Ct, fused["dlogits"], Ct, fused["W"], n_e, de, n_e)

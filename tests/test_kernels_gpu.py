@@ -566,3 +566,29 @@ def test_cond_linear_fwd_bwd(ops, B, n_in, n_out, C):
         touched[w_off[c]:w_off[c] + n_out * n_in] = True
         touched[b_off[c]:b_off[c] + n_out] = True
     assert bool((Gc[~touched] == 7.0).all()), "gradients of absent conditions (and the gaps) must not be written"
+
+
+def test_cross_entropy_heads_one_launch(ops):
+    """mmvae_cross_entropy_heads: all heads of an adversary on one packed logits matrix == one launch per head."""
+    from mmvae_amd import _lib
+
+    B, widths = 512, [8, 2, 273, 4644]
+    Ct, H = sum(widths), len(widths)
+    g = torch.Generator().manual_seed(5)
+    logits = (torch.randn(B, Ct, generator=g) * 2).cuda()
+    labels = torch.stack([torch.randint(0, w, (B,), generator=g) for w in widths]).cuda()
+    cols = [sum(widths[:k]) for k in range(H)]
+    lib, s = _lib.load(), torch.cuda.current_stream().cuda_stream
+    rows_ref, d_ref = torch.zeros(H, B, device="cuda"), torch.zeros(B, Ct, device="cuda")
+    for h, (c0, w) in enumerate(zip(cols, widths)):
+        _lib.check(lib.mmvae_cross_entropy_sum(B, w, logits.data_ptr() + 4 * c0, Ct, labels[h].data_ptr(),
+                                               rows_ref[h].data_ptr(), d_ref.data_ptr() + 4 * c0, Ct, None, 25.0, s), "ce")
+    rows, d = torch.zeros(H, B, device="cuda"), torch.zeros(B, Ct, device="cuda")
+    cw = torch.tensor(cols + widths, dtype=torch.int32, device="cuda")
+    _lib.check(lib.mmvae_cross_entropy_heads(B, H, max(widths), cw.data_ptr(), cw.data_ptr() + 4 * H, logits.data_ptr(), Ct,
+                                             labels.data_ptr(), rows.data_ptr(), d.data_ptr(), Ct, 25.0, s), "ce heads")
+    torch.cuda.synchronize()
+    want = torch.stack([torch.nn.functional.cross_entropy(logits[:, c0:c0 + w].double().cpu(), labels[h].cpu(),
+                                                          reduction="none") for h, (c0, w) in enumerate(zip(cols, widths))])
+    assert rel_l2(rows, want) < 1e-6 and rel_l2(rows, rows_ref) < 1e-6 and rel_l2(d, d_ref) < 1e-6
+    assert torch.equal(rows[3], rows_ref[3]) and torch.equal(d[:, cols[3]:], d_ref[:, cols[3]:])  # wide head: same kernel body
