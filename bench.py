@@ -36,6 +36,9 @@ def parse():
                          "feed and PCIe transfer inside the timed region)")
     ap.add_argument("--genes", default="", help="diagnostics: comma-separated gene counts replacing the config's (one per "
                                                 "modality), e.g. 60530,52437 = the reference's human / mouse widths")
+    ap.add_argument("--sim-comm", default="", help="diagnostics: CUS,LDS_KB,MICROS -- a stand-in for a collective beside the "
+                                                   "step: that many workgroups holding that much LDS each spin on a side "
+                                                   "stream for that long, started with every step (DESIGN.md section 7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample")
     return ap.parse_args()
@@ -193,7 +196,18 @@ def main():
         model.eval()
         model.trainer.set_stage("validation" if a.mode == "validate" else "predict")
 
+    sim = None
+    if a.sim_comm:
+        from mmvae_amd import _lib as _l
+
+        cus, lds_kb, micros = (int(v) for v in a.sim_comm.split(","))
+        sim = (_l.load(), torch.cuda.Stream(device=device), cus, lds_kb * 1024, micros)
+
     def step(i):
+        if sim is not None:
+            lib_, side_, cus_, lds_, us_ = sim
+            side_.wait_stream(torch.cuda.current_stream())
+            _l.check(lib_.mmvae_debug_occupy(cus_, lds_, us_, None, side_.cuda_stream), "mmvae_debug_occupy")
         if feed is not None:
             x, meta, eid = next(feed)
         else:

@@ -414,6 +414,10 @@ int mmvae_cond_linear_bwd_dw(int n_chunks, const int32_t* chunk_dst, const int32
                              const int32_t* red_cond, const int32_t* red_slot, const int32_t* red_n, float* partials,
                              mmvae_stream_t stream);
 
+/* Diagnostics: `workgroups` workgroups that each hold `lds_bytes` of LDS and spin for `micros` microseconds -- a stand-in
+ * for a collective occupying workgroup slots beside the step (bench.py --sim-comm). */
+int mmvae_debug_occupy(int workgroups, int lds_bytes, int micros, float* sink, mmvae_stream_t stream);
+
 /* Small utilities used by the step engine: y = alpha*x (+ y), fill. */
 int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, float* y, mmvae_stream_t stream);
 int mmvae_scale_rows(int B, int N, const float* x, int64_t ldx, const float* row_scale, float* y, int64_t ldy,

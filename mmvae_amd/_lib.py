@@ -77,6 +77,7 @@ PROTOTYPES = {
     "mmvae_cross_entropy_sum": (_i, [_i, _i, _p, _l, _p, _p, _p, _l, _p, _f, _p]),
     "mmvae_cross_entropy_heads": (_i, [_i, _i, _i, _p, _p, _p, _l, _p, _p, _p, _l, _f, _p]),
     "mmvae_sum_f32": (_i, [_l, _p, _p, _i, _p]),
+    "mmvae_debug_occupy": (_i, [_i, _i, _i, _p, _p]),
     "mmvae_sum_rows_f32": (_i, [_i, _l, _p, _l, _p, _p, _p]),
     "mmvae_sqnorm_partials": (_l, [_l]),
     "mmvae_grad_sqnorm": (_i, [_l, _p, _p, _p]),

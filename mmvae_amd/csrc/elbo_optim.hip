@@ -531,6 +531,19 @@ __global__ __launch_bounds__(256) void sqnorm_jobs_kernel(const mmvae_adam_job* 
     if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Diagnostics: stand-in for a collective that runs beside the step.  Each workgroup holds `lds`
+// bytes of LDS (so that a CU cannot host its usual two GEMM workgroups beside it) and spins for `micros` microseconds of
+// the constant 100 MHz wall clock; every wave reaches the exit condition, the grid always drains.
+__global__ __launch_bounds__(256) void occupy_kernel(long long ticks, float* __restrict__ sink) {
+    extern __shared__ float hold[];
+    hold[threadIdx.x] = (float)threadIdx.x;
+    __syncthreads();
+    const long long t0 = wall_clock64();
+    float acc = hold[(threadIdx.x + 1) & 255];
+    while (wall_clock64() - t0 < ticks) acc = acc * 1.0000001f + 1e-7f;
+    if (acc == -1.f && sink) sink[0] = acc;  // keeps the loop alive; never true
+}
+
 // ---------------------------------------------------------------- Philox4x32-10
 struct u32x4 {
     uint32_t x, y, z, w;
@@ -782,6 +795,20 @@ extern "C" int mmvae_cross_entropy_heads(int B, int H, int max_classes, const in
         return MMVAE_ERR_ARG;
     MMVAE_LAUNCH(ce_heads_kernel<8>, dim3(B, H), dim3(256), 0, (hipStream_t)stream, B, col_dev, classes_dev, logits, ld,
                  labels, loss_rows, dlogits, ldd, gscale);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_debug_occupy(int workgroups, int lds_bytes, int micros, float* sink, mmvae_stream_t stream) {
+    if (workgroups <= 0 || workgroups > 256 || lds_bytes < 1024 || lds_bytes > 160 * 1024 || micros <= 0 ||
+        micros > 20000)
+        return MMVAE_ERR_ARG;
+    if (lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            lds_bytes) != hipSuccess)
+        return MMVAE_ERR_LAUNCH;
+    MMVAE_LAUNCH(occupy_kernel, dim3(workgroups), dim3(256), (size_t)lds_bytes, (hipStream_t)stream,
+                 (long long)micros * 100, sink);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }
