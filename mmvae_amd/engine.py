@@ -996,9 +996,12 @@ class _Plan:
             lins = [heads[c] for c in self.conditions]
             if H > 1 and os.environ.get("MMVAE_FUSE_HEADS", "1") != "0":
                 ws, bs = [l.weight for l in lins], [l.bias for l in lins]
-                chain = lambda ts: all(ts[k + 1].data_ptr() == ts[k].data_ptr() + 4 * ts[k].numel() for k in range(H - 1))
-                if chain(ws) and chain(bs) and chain([g(w) for w in ws]) and chain([g(b) for b in bs]):
-                    Ct = sum(l.out_features for l in lins)
+                pad4 = lambda c: (c + 3) // 4 * 4
+                rows_of = [pad4(l.out_features) for l in lins]  # class counts padded to 4 (HipAdam pack alignment)
+                chain = lambda ts, per_row: all(ts[k + 1].data_ptr() == ts[k].data_ptr() + 4 * rows_of[k] * per_row
+                                                for k in range(H - 1))
+                if (chain(ws, n_e) and chain(bs, 1) and chain([g(w) for w in ws], n_e) and chain([g(b) for b in bs], 1)):
+                    Ct = sum(rows_of)
                     a, iw, ib = opt.arena, arena_of(ws[0])[1], arena_of(bs[0])[1]
                     ow, ob = a.offsets[iw], a.offsets[ib]
                     fused = dict(Ct=Ct, W=a.data[ow:ow + Ct * n_e].view(Ct, n_e), b=a.data[ob:ob + Ct],
@@ -1016,9 +1019,10 @@ class _Plan:
                     Ct, col = fused["Ct"], 0
                     self.gemm(NT, B, Ct, n_e, e, n_e, fused["W"], n_e, fused["logits"], Ct, bias=fused["b"])
                     widths = [heads[c].out_features for c in self.conditions]
+                    padded = [(w + 3) // 4 * 4 for w in widths]  # a head's columns start on a multiple of 4
                     if max(widths) <= 8192 and eng.merge_launches:  # every head's cross-entropy in one launch
                         if "cols" not in fused:
-                            starts = [sum(widths[:k]) for k in range(H)]
+                            starts = [sum(padded[:k]) for k in range(H)]
                             fused["cols"] = torch.tensor(starts + widths, dtype=torch.int32, device=eng.device)
                             self._job_tables.append(fused["cols"])  # the captured program reads it on every replay
                         cw = fused["cols"]
@@ -1031,7 +1035,7 @@ class _Plan:
                             self._emit(lib.mmvae_cross_entropy_sum, B, Cn, fused["logits"].data_ptr() + 4 * col, Ct,
                                        _p(self.labels_dev[c]), _p(rows[ci]), fused["dlogits"].data_ptr() + 4 * col, Ct,
                                        None, gscale)
-                            col += Cn
+                            col += (Cn + 3) // 4 * 4
                     self._emit_fc_bwd(B, Ct, fused["dlogits"], None, None, None, fused["gb"])
                     self.gemm(TN, Ct, n_e, B, fused["dlogits"], Ct, e, n_e, fused["gW"], n_e, side=True)
                     self.gemm(NN, B, n_e, Ct, fused["dlogits"], Ct, fused["W"], n_e, de, n_e)

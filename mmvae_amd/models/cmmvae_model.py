@@ -223,7 +223,11 @@ class CMMVAEModel(BaseModel):
                 lins.append(head.fc_layers[0].lin)
             if len(lins) < 2 or any(l.bias is None for l in lins):
                 return None
-            return [[l.weight for l in lins], [l.bias for l in lins]]
+            n_e = lins[0].in_features
+            if any(l.in_features != n_e for l in lins):
+                return None
+            # class counts padded to multiples of 4 rows: the packed matrix keeps 16-byte-regular shapes (2, 273 classes)
+            return [([l.weight for l in lins], 4 * n_e), ([l.bias for l in lins], 4)]
 
         optim_dict = {"experts": {eid: make(m.parameters()) for eid, m in self.module.experts.items()},
                       "vae": make(self.module.vae.parameters())}

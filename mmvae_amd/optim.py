@@ -29,10 +29,11 @@ class ParamArena:
     """Contiguous storage for a list of parameters (+ grads and Adam moments).  Device (HIP) or CPU plumbing."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], pack: Optional[list] = None):
-        """`pack`: groups of parameters to be laid out back to back WITHOUT padding, in the order given (the heads of an
-        adversary: their weights form one [sum of classes, width] matrix and their biases one vector, so that all heads
-        run as one GEMM).  Placement only: the parameter order -- and with it the optimiser's state_dict -- is that of
-        `params`."""
+        """`pack`: groups of parameters to be laid out back to back in the order given -- a list of parameters, or
+        (list, alignment in elements) to start every member on a multiple of the alignment inside the group (the heads
+        of an adversary: their weights form one [sum of padded class counts, width] matrix and their biases one vector,
+        so that all heads run as one GEMM; rows padded to multiples of 4 keep that GEMM on the 16-byte loaders; the
+        holes stay zero).  Placement only: the parameter order -- and the optimiser's state_dict -- is that of `params`."""
         self.params: List[torch.nn.Parameter] = [p for p in params]
         if not self.params:
             raise ValueError("empty parameter list")
@@ -40,7 +41,8 @@ class ParamArena:
         if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
             raise ValueError("all parameters of an arena must be fp32 on one device")
         self.device = dev
-        group_of = {id(q): gi for gi, grp in enumerate(pack or []) for q in grp}
+        groups = [(g if isinstance(g, tuple) else (g, 1)) for g in (pack or [])]  # (members, member alignment)
+        group_of = {id(q): gi for gi, (grp, _) in enumerate(groups) for q in grp}
         placed: Dict[int, int] = {}
         n = 0
         for p in self.params:
@@ -50,10 +52,14 @@ class ParamArena:
             if gi is None:
                 placed[id(p)] = n
                 n += _pad4(p.numel())
-            else:  # the whole group here, unpadded between members
-                for q in pack[gi]:
+            else:  # the whole group here: members back to back, each starting on a multiple of the group's alignment
+                members, align = groups[gi]
+                start = n
+                for q in members:
+                    n = start + (n - start + align - 1) // align * align  # (holes stay zero: data, grads, moments)
                     placed[id(q)] = n
                     n += q.numel()
+                n = start + (n - start + align - 1) // align * align
                 n = _pad4(n)
         self.offsets: List[int] = [placed[id(p)] for p in self.params]
         self.numel = n
