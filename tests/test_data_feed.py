@@ -164,3 +164,26 @@ def test_prefetcher_keeps_order_and_reraises(tmp_path):
     n = len(produced)
     time.sleep(0.3)
     assert len(produced) == n and threading.active_count() <= before + 1
+
+
+@pytest.mark.gpu
+def test_prefetched_gpu_batches_equal_the_direct_feed(tmp_path):
+    """Prefetcher on the GPU: batches staged by the background thread on its own copy stream are, once the consumer's
+    stream has joined them, exactly the batches the feed yields directly -- also while other work keeps the device busy."""
+    m, meta = _dataset(200, 96, 5)
+    D.write_chunks(str(tmp_path), "human", m, meta, chunk_rows=64, compressed=False)
+
+    def feed():
+        return D.SpeciesChunks(str(tmp_path), "human_train_counts_*.npz", "human_train_metadata_*.pkl", 16, "human",
+                               seed=7, device="cuda")
+
+    direct = [(x.to_dense().cpu(), md["row"].tolist()) for x, md, _ in feed()]
+    busy = torch.randn(2048, 2048, device="cuda")
+    got = []
+    for x, md, eid in D.Prefetcher(feed(), depth=3, device="cuda"):
+        busy = busy @ busy * 1e-3  # the consumer's stream has work queued while the producer copies
+        assert x.is_cuda and x.layout == torch.sparse_csr and eid == "human"
+        got.append((x.to_dense().cpu(), md["row"].tolist()))
+    assert len(got) == len(direct) == 12  # chunks of 64, 64, 64, 8 rows: 4 + 4 + 4 + 0 batches of 16
+    for (a, ra), (b, rb) in zip(got, direct):
+        assert ra == rb and torch.equal(a, b)
