@@ -1,0 +1,69 @@
+"""The rows of SURVEY 8 in one user journey on the GPU: chunk files on disk -> SpeciesChunks / MultiModalBatches /
+Prefetcher -> Trainer.fit through the captured engine (CSR batches densified on the device) -> validate -> predict
+into predictions.h5.  Checks plumbing and invariants, not numerics (those are pinned by the golden-vector tests)."""
+import math
+
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sp
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_species(root, name, n_rows, genes, seed):
+    from mmvae_amd import data as D, synthetic
+
+    x = synthetic.synthetic_counts(n_rows, genes, seed=seed, device="cpu").numpy()
+    meta = pd.DataFrame({"cell": [f"{name}_{i}" for i in range(n_rows)], "assay": [f"assay_{i % 3}" for i in range(n_rows)]})
+    D.write_chunks(str(root / name), name, sp.csr_matrix(x), meta, chunk_rows=64, compressed=False)
+    D.write_chunks(str(root / name), name, sp.csr_matrix(x[:64]), meta.iloc[:64], chunk_rows=64, split="val",
+                   compressed=False)
+    return x
+
+
+def test_fit_validate_predict_from_chunk_files(tmp_path):
+    from mmvae_amd import data as D, predictions as P, synthetic
+    from mmvae_amd.trainer import MultiModalBatches, Trainer
+
+    genes = {"human": 203, "mouse": 96}  # 203: not a multiple of 4 (the staged, slack-padded input path)
+    raw = {name: _write_species(tmp_path, name, 192, g, seed=11 + i) for i, (name, g) in enumerate(genes.items())}
+    B = 32
+
+    def feeds(split):
+        return {name: D.SpeciesChunks(str(tmp_path / name), f"{name}_{split}_counts_*.npz", f"{name}_{split}_metadata_*.pkl",
+                                      B, name, seed=3, device="cuda") for name in genes}
+
+    model = synthetic.build_model(genes, latent_dim=16, h1=64, h2=32, hv=24, dropout=0.1, seed=0).cuda()
+    before = {k: v.detach().clone() for k, v in model.module.state_dict().items()}
+    trainer = Trainer(max_epochs=2, check_val_every_n_epoch=1)
+    train = D.Prefetcher(MultiModalBatches(feeds("train"), seed=1), depth=2, device="cuda")
+    val = MultiModalBatches(feeds("val"), seed=1)
+    history = trainer.fit(model, train, val)
+    assert model._engine, "the captured engine must have run the steps"
+    assert trainer.global_step == 2 * (192 // B) * 2  # 2 epochs x 6 batches x 2 modalities
+    train_rows = [h for h in history if h.get("stage") == "training"]
+    val_rows = [h for h in history if h.get("stage") == "validation"]
+    assert len(train_rows) == 2 and len(val_rows) == 2
+    for h in train_rows + val_rows:
+        losses = [v for k, v in h.items() if k.startswith("loss/")]
+        assert losses and all(math.isfinite(v) for v in losses)
+    after = model.module.state_dict()
+    moved = [k for k in before if before[k].dtype.is_floating_point and not torch.equal(before[k], after[k])]
+    assert any("experts.human" in k for k in moved) and any("experts.mouse" in k for k in moved) and any(
+        k.startswith("vae.") for k in moved)
+
+    # predict: embeddings of the validation cells of one modality, appended batch by batch to predictions.h5
+    writer = P.PredictionWriter(str(tmp_path), "exp", "run")
+    batches = list(feeds("val")["human"])
+    trainer.predict(model, batches, writer=writer)
+    data, meta, _ = P.load_from_hdf5(writer.hdf5_filepath, "z")
+    assert data.shape == (64, 16) and np.isfinite(data).all()
+    assert [c.decode() for c in meta["cell"]] == [c for _, md, _ in batches for c in md["cell"]]
+    assert set(meta["species"]) == {b"human"}
+    # same cells again through the model directly: the file holds what predict_step returns (fixed eval noise aside,
+    # the embedding is a sample: compare the posterior mean path instead -> deterministic encoder output shape only)
+    z_again = model.predict_step((batches[0][0], batches[0][1].copy(), "human"))["z"][0]
+    assert z_again.shape == (B, 16)
+    del raw
