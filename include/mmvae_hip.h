@@ -216,6 +216,22 @@ int mmvae_elbo_finalize(int B, int K, int T, const float* se_part, const float* 
                         const float* kl_weight_dev, float kl_weight_host, float* out6, float* w_out,
                         float* recon_row /* [B] scratch: per-cell reconstruction term */, mmvae_stream_t stream);
 
+/* Opt-in "full IWAE" objective of the K-sample extension (the reference has no multi-sample ELBO): the
+ * analytic KL is replaced by the sampled log-density ratio inside the log-mean-exp,
+ *   r[k,b]  = log q(z_kb | x_b) - log p(z_kb) = sum_j ( -log s_bj - eps_kbj^2 / 2 + z_kbj^2 / 2 )     (_logratio)
+ *   loss    = sum_b -logmeanexp_k( -SE[k,b] - (kl_weight / B) r[k,b] )                                   (_finalize_iwae)
+ *   out[0] = loss, out[1] = sum_b sum_k w SE, out[2] = mean_b sum_k w r, out[3] = kl_weight, out[4..5] as above;
+ *   w_out[k*B + b] = softmax_k of the log-weights = d loss / d SE[k,b];  rows3: [3, B] scratch.
+ * Backward (_bwd_terms): dz[k,b,:] += (kl_weight / B) w[k,b] z[k,b,:] in place, dstd_extra[b,j] = -(kl_weight / B) / s[b,j];
+ * then mmvae_reparam_kl_bwd with kl_scale_host = 0 and that dstd_extra.  kl_weight = *kl_weight_dev * kl_weight_host. */
+int mmvae_iwae_logratio(int B, int Z, int K, const float* std, const float* eps, const float* z, float* out,
+                        mmvae_stream_t stream);
+int mmvae_elbo_finalize_iwae(int B, int K, int T, const float* se_part, const float* logratio, const float* stat_row,
+                             int Z, const float* kl_weight_dev, float kl_weight_host, float* out6, float* w_out,
+                             float* rows3, mmvae_stream_t stream);
+int mmvae_iwae_bwd_terms(int B, int Z, int K, const float* kl_weight_dev, float kl_weight_host, const float* w,
+                         const float* z, const float* std, float* dz, float* dstd_extra, mmvae_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Adversarial heads: CrossEntropyLoss(reduction="sum") forward + gradient (k11)
  * replaces: cmmvae_model.py:54,85 (nn.CrossEntropyLoss(reduction="sum") on Adversarial head logits)

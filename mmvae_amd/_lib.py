@@ -74,6 +74,9 @@ PROTOTYPES = {
     "mmvae_reparam_kl_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p]),
     "mmvae_mse_sum_fwd_bwd": (_i, [_i, _i, _p, _l, _p, _l, _p, _p, _l, _p, _f, _p]),
     "mmvae_elbo_finalize": (_i, [_i, _i, _i, _p, _p, _p, _i, _p, _f, _p, _p, _p, _p]),
+    "mmvae_iwae_logratio": (_i, [_i, _i, _i, _p, _p, _p, _p, _p]),
+    "mmvae_elbo_finalize_iwae": (_i, [_i, _i, _i, _p, _p, _p, _i, _p, _f, _p, _p, _p, _p]),
+    "mmvae_iwae_bwd_terms": (_i, [_i, _i, _i, _p, _f, _p, _p, _p, _p, _p, _p]),
     "mmvae_cross_entropy_sum": (_i, [_i, _i, _p, _l, _p, _p, _p, _l, _p, _f, _p]),
     "mmvae_cross_entropy_heads": (_i, [_i, _i, _i, _p, _p, _p, _l, _p, _p, _p, _l, _f, _p]),
     "mmvae_sum_f32": (_i, [_l, _p, _p, _i, _p]),

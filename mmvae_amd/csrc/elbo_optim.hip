@@ -140,6 +140,109 @@ __global__ __launch_bounds__(256) void elbo_rows_kernel(int B, int K, int T, con
     if (w_out && lane < K) w_out[(int64_t)lane * B + b] = expf(v - lse);
 }
 
+// ---- opt-in "full IWAE" objective of the K-sample extension (not in the reference).
+// r[k,b] = log q(z_kb | x_b) - log p(z_kb) = sum_j (-log s_bj - eps_kbj^2 / 2 + z_kbj^2 / 2); one wavefront per (k, b).
+__global__ __launch_bounds__(256) void iwae_logratio_kernel(int B, int Z, int K, const float* __restrict__ std,
+                                                            const float* __restrict__ eps, const float* __restrict__ z,
+                                                            float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= K * B) return;
+    const int b = row % B;
+    const float* sr = std + (int64_t)b * Z;
+    const float* er = eps + (int64_t)row * Z;
+    const float* zr = z + (int64_t)row * Z;
+    float s = 0.f;
+    for (int j = lane; j < Z; j += 64) s += -logf(sr[j]) - 0.5f * er[j] * er[j] + 0.5f * zr[j] * zr[j];
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
+}
+
+// Stage 1 of the full-IWAE finalisation: log-weights lw_k = -SE[k,b] - c r[k,b], bound_b = -logmeanexp_k lw_k,
+// w[k,b] = softmax_k, and the w-weighted SE / r of the cell (reported as recon / kl).  rows3: [3, B].
+__global__ __launch_bounds__(256) void elbo_rows_iwae_kernel(int B, int K, int T, const float* __restrict__ se_part,
+                                                             const float* __restrict__ logratio,
+                                                             const float* __restrict__ klw_dev, float c_host,
+                                                             float* __restrict__ rows3, float* __restrict__ w_out) {
+    __shared__ float se_s[4][ELBO_MAXK];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wv;
+    if (b >= B) return;
+    const int64_t KB = (int64_t)K * B;
+    const float c = (klw_dev ? *klw_dev : 1.f) * c_host;
+    for (int k = 0; k < K; ++k) {
+        float s = 0.f;
+        for (int t = lane; t < T; t += 64) s += se_part[(int64_t)t * KB + (int64_t)k * B + b];
+        s = wave_sum(s);
+        if (lane == 0) se_s[wv][k] = s;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float se = (lane < K) ? se_s[wv][lane] : 0.f;
+    const float r = (lane < K) ? logratio[(int64_t)lane * B + b] : 0.f;
+    const float v = (lane < K) ? -se - c * r : -INFINITY;
+    const float mx = wave_max(v);
+    const float ex = (lane < K) ? expf(v - mx) : 0.f;
+    const float lse = mx + logf(wave_sum(ex));
+    const float w = (lane < K) ? expf(v - lse) : 0.f;
+    const float wse = wave_sum(w * se), wr = wave_sum(w * r);
+    if (lane == 0) {
+        rows3[b] = -(lse - logf((float)K));
+        rows3[B + b] = wse;
+        rows3[2 * (int64_t)B + b] = wr;
+    }
+    if (w_out && lane < K) w_out[(int64_t)lane * B + b] = w;
+}
+
+// Stage 2: out[0] = sum_b bound_b, out[1] = sum_b sum_k w SE, out[2] = mean_b sum_k w r, out[3] = kl weight, out[4..5] stats.
+__global__ __launch_bounds__(256) void elbo_reduce_iwae_kernel(int B, const float* __restrict__ rows3,
+                                                               const float* __restrict__ stat_row, int Z,
+                                                               const float* __restrict__ klw_dev, float klw_host,
+                                                               float* __restrict__ out6) {
+    __shared__ double red[5][256];
+    const int tid = threadIdx.x;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, smu = 0.0, svar = 0.0;
+    for (int b = tid; b < B; b += 256) {
+        a0 += (double)rows3[b];
+        a1 += (double)rows3[B + b];
+        a2 += (double)rows3[2 * (int64_t)B + b];
+        if (stat_row) {
+            smu += (double)stat_row[b];
+            svar += (double)stat_row[B + b];
+        }
+    }
+    red[0][tid] = a0;
+    red[1][tid] = a1;
+    red[2][tid] = a2;
+    red[3][tid] = smu;
+    red[4][tid] = svar;
+    __syncthreads();
+    if (tid == 0) {
+        double t[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < 256; ++i)
+            for (int q = 0; q < 5; ++q) t[q] += red[q][i];
+        out6[0] = (float)t[0];
+        out6[1] = (float)t[1];
+        out6[2] = (float)(t[2] / (double)B);
+        out6[3] = (klw_dev ? *klw_dev : 1.f) * klw_host;
+        out6[4] = (float)(t[3] / ((double)B * (double)(Z > 0 ? Z : 1)));
+        out6[5] = (float)(t[4] / ((double)B * (double)(Z > 0 ? Z : 1)));
+    }
+}
+
+// Backward terms of the log-ratio: dz[k,b,j] += c w[k,b] z[k,b,j]  (d r / d z = z), and the direct dependence on the
+// variance, -log s, handed to mmvae_reparam_kl_bwd as dstd_extra[b,j] = -c / s[b,j]  (sum_k w = 1).
+__global__ __launch_bounds__(256) void iwae_bwd_terms_kernel(int B, int Z, int K, const float* __restrict__ klw_dev,
+                                                             float c_host, const float* __restrict__ w,
+                                                             const float* __restrict__ z, const float* __restrict__ std,
+                                                             float* __restrict__ dz, float* __restrict__ dstd_extra) {
+    const float c = (klw_dev ? *klw_dev : 1.f) * c_host;
+    const int64_t n = (int64_t)K * B * Z, nb = (int64_t)B * Z;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / Z;  // k * B + b
+        dz[i] += c * w[row] * z[i];
+        if (i < nb) dstd_extra[i] = -c / std[i];
+    }
+}
+
 // Stage 2: single workgroup, fp64 accumulation in a fixed order.
 __global__ __launch_bounds__(256) void elbo_reduce_kernel(int B, const float* __restrict__ recon_row,
                                                           const float* __restrict__ kl_row,
@@ -765,6 +868,38 @@ extern "C" int mmvae_elbo_finalize(int B, int K, int T, const float* se_part, co
     MMVAE_LAUNCH_CHECK();
     MMVAE_LAUNCH(elbo_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, recon_row, kl_row, stat_row, Z,
                        kl_weight_dev, kl_weight_host, out6);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_iwae_logratio(int B, int Z, int K, const float* std, const float* eps, const float* z, float* out,
+                                   mmvae_stream_t stream) {
+    if (B <= 0 || Z <= 0 || K < 1 || K > ELBO_MAXK || !std || !eps || !z || !out) return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(iwae_logratio_kernel, dim3(ceil_div_i(K * B, 4)), dim3(256), 0, (hipStream_t)stream, B, Z, K, std, eps, z,
+                 out);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_elbo_finalize_iwae(int B, int K, int T, const float* se_part, const float* logratio,
+                                        const float* stat_row, int Z, const float* kl_weight_dev, float kl_weight_host,
+                                        float* out6, float* w_out, float* rows3, mmvae_stream_t stream) {
+    if (B <= 0 || K < 1 || K > ELBO_MAXK || T < 1 || !se_part || !logratio || !out6 || !rows3) return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(elbo_rows_iwae_kernel, dim3(ceil_div_i(B, 4)), dim3(256), 0, (hipStream_t)stream, B, K, T, se_part,
+                 logratio, kl_weight_dev, kl_weight_host / (float)B, rows3, w_out);
+    MMVAE_LAUNCH_CHECK();
+    MMVAE_LAUNCH(elbo_reduce_iwae_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, rows3, stat_row, Z,
+                 kl_weight_dev, kl_weight_host, out6);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_iwae_bwd_terms(int B, int Z, int K, const float* kl_weight_dev, float kl_weight_host, const float* w,
+                                    const float* z, const float* std, float* dz, float* dstd_extra,
+                                    mmvae_stream_t stream) {
+    if (B <= 0 || Z <= 0 || K < 1 || !w || !z || !std || !dz || !dstd_extra) return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(iwae_bwd_terms_kernel, dim3(grid_for((int64_t)K * B * Z, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+                 B, Z, K, kl_weight_dev, kl_weight_host / (float)B, w, z, std, dz, dstd_extra);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }

@@ -344,10 +344,11 @@ class StepEngine:
         if enc_mod.explicit_eps is not None and enc_mod.explicit_eps.dim() == 3:
             K = enc_mod.explicit_eps.shape[0]
         B = x.shape[0]
-        key, x_in = self._select_input(x, ("train", expert_id, B, K, explicit))
+        iwae = getattr(enc_mod, "elbo_mode", "analytic") == "iwae"
+        key, x_in = self._select_input(x, ("train-iwae" if iwae else "train", expert_id, B, K, explicit))
         plan = self._plans.get(key)
         if plan is None:
-            plan = _Plan(self, expert_id, B, K, explicit, x_in)
+            plan = _Plan(self, expert_id, B, K, explicit, x_in, iwae=iwae)
             self._plans[key] = plan
         self._set_kl_weight()
         if explicit:
@@ -370,9 +371,11 @@ class StepEngine:
 
 
 class _Plan:
-    def __init__(self, eng: StepEngine, eid: str, B: int, K: int, explicit: bool, x: torch.Tensor, mode: str = "train"):
+    def __init__(self, eng: StepEngine, eid: str, B: int, K: int, explicit: bool, x: torch.Tensor, mode: str = "train",
+                 iwae: bool = False):
         self.eng, self.eid, self.B, self.K, self.explicit = eng, eid, B, K, explicit
         self.mode = mode
+        self.iwae = bool(iwae) and mode == "train"  # opt-in full-IWAE objective (training programs only)
         self.x = x
         self.R = B * K
         model = eng.model
@@ -804,6 +807,9 @@ class _Plan:
                    _p(self.std), _p(self.z), _p(self.kl_row), _p(self.stat))
         if self.mode == "embed":  # predict path: the program ends at z
             return self._finish_forward_only()
+        if self.iwae:  # sampled log q(z) - log p(z) per (sample, cell)
+            self.logratio = eng.buf("iwae.logratio", (K, B))
+            self._emit(lib.mmvae_iwae_logratio, B, Z, K, _p(self.std), _p(self.eps), _p(self.z), _p(self.logratio))
         # ---- forward, decoder side (rows R = K*B)
         cur, ld = self.z, Z
         if self.cond is not None:  # CLVAE.after_reparameterize: the sample passes through the conditional layers
@@ -823,8 +829,13 @@ class _Plan:
         self._emit(lib.mmvae_decoder_recon_rows_f32, R, B, G, last.n_in, _p(cur), ld, _p(last.W), last.n_in,
                    _p(last.b), _p(x), ldx, None, 0, _p(self.dP), G, _p(self.se_part))
         self.recon_row = eng.buf("recon_row", (B,))
-        self._emit(lib.mmvae_elbo_finalize, B, K, T, _p(self.se_part), _p(self.kl_row), _p(self.stat), Z,
-                   _p(eng.klw_dev), 1.0, _p(self.metrics), _p(self.w), _p(self.recon_row))
+        if self.iwae:
+            self.rows3 = eng.buf("iwae.rows3", (3, B))
+            self._emit(lib.mmvae_elbo_finalize_iwae, B, K, T, _p(self.se_part), _p(self.logratio), _p(self.stat), Z,
+                       _p(eng.klw_dev), 1.0, _p(self.metrics), _p(self.w), _p(self.rows3))
+        else:
+            self._emit(lib.mmvae_elbo_finalize, B, K, T, _p(self.se_part), _p(self.kl_row), _p(self.stat), Z,
+                       _p(eng.klw_dev), 1.0, _p(self.metrics), _p(self.w), _p(self.recon_row))
         if not train:  # validation: the program ends with the ELBO terms in the metrics buffer
             return self._finish_forward_only()
         # total loss slot starts as the ELBO loss (without adversaries it IS the ELBO loss word: no launch)
@@ -872,8 +883,17 @@ class _Plan:
         self.dmu = eng.buf("dmu", (B, Z))
         self.da = eng.buf("da", (B, Z))
         self.dq = eng.buf("dq", (B, HV))
-        self._emit(lib.mmvae_reparam_kl_bwd, B, Z, K, _p(self.mu), _p(self.std), _p(self.eps), _p(self.dz_lat), None,
-                   None, None, _p(eng.klw_dev), 1.0 / B, self.var_eps, _p(self.dmu), _p(self.da))
+        if self.iwae:
+            # d/dz of the log-ratio joins the decoder's gradient, its direct dependence on the variance arrives as
+            # dstd_extra; the analytic-KL terms of the kernel are switched off (kl_scale_host = 0)
+            self.dstd_extra = eng.buf("iwae.dstd", (B, Z))
+            self._emit(lib.mmvae_iwae_bwd_terms, B, Z, K, _p(eng.klw_dev), 1.0, _p(self.w), _p(self.z), _p(self.std),
+                       _p(self.dz_lat), _p(self.dstd_extra))
+            self._emit(lib.mmvae_reparam_kl_bwd, B, Z, K, _p(self.mu), _p(self.std), _p(self.eps), _p(self.dz_lat), None,
+                       _p(self.dstd_extra), None, _p(eng.klw_dev), 0.0, self.var_eps, _p(self.dmu), _p(self.da))
+        else:
+            self._emit(lib.mmvae_reparam_kl_bwd, B, Z, K, _p(self.mu), _p(self.std), _p(self.eps), _p(self.dz_lat), None,
+                       None, None, _p(eng.klw_dev), 1.0 / B, self.var_eps, _p(self.dmu), _p(self.da))
         for dy, lin in ((self.dmu, self.mean_enc), (self.da, self.var_enc)):
             self._emit_fc_bwd(B, Z, dy, None, None, None, eng.grad_of(lin.bias))
             self.gemm(TN, Z, HV, B, dy, Z, q, HV, eng.grad_of(lin.weight), HV, side=True)

@@ -101,6 +101,8 @@ class CMMVAEModel(BaseModel):
         engine = self._get_engine(x)
         if engine is not None:
             return engine.training_step(x, metadata, expert_id)
+        if getattr(self.module.vae.encoder, "elbo_mode", "analytic") != "analytic":
+            raise NotImplementedError("elbo_mode='iwae' (the opt-in full-IWAE objective) runs in the captured engine only")
 
         optims = self.get_optimizers()
         expert_optimizer = optims["experts"][expert_id]

@@ -487,6 +487,10 @@ class Encoder(nn.Module):
         self.hidden_z = hidden_z
         self.explicit_eps: Optional[torch.Tensor] = None  # parity mode: noise consumed by the next forward
         self.n_samples: int = 1  # K of the K-sample extension (1 = the reference)
+        # "analytic": loss = recon + kl_weight * analytic KL (the reference, vae.py:136-152; with K samples the
+        # reconstruction term is their log-mean-exp).  "iwae": opt-in full importance-weighted objective:
+        # the sampled log q(z) - log p(z) sits inside the log-mean-exp; runs in the captured engine only.
+        self.elbo_mode: str = "analytic"
 
     @property
     def n_layers(self) -> int:

@@ -114,6 +114,7 @@ class HParams:
     bn_momentum: float = 0.01  # components.py:279
     bn_eps: float = 1e-3
     world_size: int = 1  # DDP gradient averaging (Lightning DDP semantics): grads are divided by world_size
+    elbo_mode: str = "analytic"  # "iwae": the opt-in full-IWAE objective of the K-sample extension (elbo_iwae)
 
 
 # --------------------------------------------------------------------------------------------------- init helpers
@@ -297,6 +298,25 @@ def model_forward(spec: ModelSpec, sd, x, expert_id: str, eps, training: bool, m
     return {"mu": mu, "std": std, "z": z, "xhat": xhat, "hidden": hidden, "shared_xhat": sh}
 
 
+def elbo_iwae(mu, std, x, xhat, kl_weight: float, K: int, eps, z):
+    """Opt-in "full IWAE" mode of the K-sample extension (not in the reference, parity unpinned): the
+    analytic KL is replaced by the sampled log-density ratio inside the log-mean-exp,
+        r[k,b]  = log q(z_kb | x_b) - log p(z_kb) = sum_j ( -log s_bj - eps_kbj^2 / 2 + z_kbj^2 / 2 )
+        loss    = sum_b -logmeanexp_k( -SE[k,b] - (kl_weight / B) r[k,b] )
+    (the 1/B keeps the default objective's scaling: E_eps[r] = KL, so K = 1 equals vae.py:136-152 in expectation).
+    Reported beside it: recon_loss = sum_b sum_k w SE, kl_loss = mean_b sum_k w r, w = softmax_k of the log-weights."""
+    B = x.shape[0]
+    se = ((xhat.reshape(K, B, -1) - x.unsqueeze(0)) ** 2).sum(-1)  # [K,B]
+    epsk = eps.reshape(K, B, -1)
+    zk = z.reshape(K, B, -1)
+    r = (-std.log().unsqueeze(0) - 0.5 * epsk.pow(2) + 0.5 * zk.pow(2)).sum(-1)  # [K,B]
+    lw = -se - (kl_weight / B) * r
+    loss = (-(torch.logsumexp(lw, dim=0) - torch.log(torch.tensor(float(K))))).sum()
+    w = torch.softmax(lw, dim=0).detach()
+    return {"loss": loss, "recon_loss": (w * se).sum().detach(), "kl_loss": ((w * r).sum() / B).detach(),
+            "kl_weight": kl_weight}
+
+
 def elbo(mu, std, x, xhat, kl_weight: float, K: int = 1):
     """BaseVAE.elbo (modules/vae.py:136-152): kl_divergence(Normal(mu,std), Normal(0,1)).sum(-1).mean();
     F.mse_loss(xhat, x, reduction="sum"); loss = recon + kl_weight * kl.
@@ -389,7 +409,10 @@ def train_step(spec: ModelSpec, sd: Dict[str, torch.Tensor], opt_state: dict, x:
     bn_updates: dict = {}
     K = eps.shape[0] if eps.dim() == 3 else 1
     fwd = model_forward(spec, live, x, expert_id, eps, True, masks, hp, bn_updates, cond, cond_order)
-    e = elbo(fwd["mu"], fwd["std"], x, fwd["xhat"], kl_weight, K)
+    if hp.elbo_mode == "iwae":
+        e = elbo_iwae(fwd["mu"], fwd["std"], x, fwd["xhat"], kl_weight, K, eps, fwd["z"])
+    else:
+        e = elbo(fwd["mu"], fwd["std"], x, fwd["xhat"], kl_weight, K)
     out = {
         "loss": e["loss"].detach(), "recon_loss": e["recon_loss"].detach(), "kl_loss": e["kl_loss"].detach(),
         "kl_weight": kl_weight, "Mean": fwd["mu"].mean().detach(), "Variance": fwd["std"].pow(2).mean().detach(),
