@@ -1464,7 +1464,9 @@ void plan(int layout, int M, int N, int K, int* tile_id, int* splitk) {
     const int tbig = ceil_div_i(M, tb.bm) * ceil_div_i(N, tb.bn);
     if (tbig >= 192) {
         *tile_id = best;
-        *splitk = 1;
+        // a chip-filling product whose K is not a multiple of the k-tile (dX of a 30 000-gene decoder over K x B
+        // rows): two slabs -- the whole k-tiles on the pipelined kernel, the K tail on the guarded one (gemm_f32_impl)
+        *splitk = (K % X3_BK != 0 && K >= 8 * X3_BK) ? 2 : 1;
         return;
     }
     const int kt = ceil_div_i(K, 32);
@@ -1641,12 +1643,13 @@ static int gemm_f32_impl(int layout, int M, int N, int K, float alpha, const flo
                            s) != hipSuccess)
             return MMVAE_ERR_LAUNCH;
     }
-    auto launch = [&](const GemmArgs& ga, int slabs) {
+    auto launch_tile = [&](int tid_, const GemmArgs& ga, int slabs) {
         const int nblocks = ga.mt * ga.nt * slabs;
-        if (layout == MMVAE_GEMM_NT) return launch_gemm_forms<FORM_KC, FORM_KC, EPI_STD>(tile_id, ga, nblocks, s);
-        if (layout == MMVAE_GEMM_NN) return launch_gemm_forms<FORM_KC, FORM_RC, EPI_STD>(tile_id, ga, nblocks, s);
-        return launch_gemm_forms<FORM_RC, FORM_RC, EPI_STD>(tile_id, ga, nblocks, s);
+        if (layout == MMVAE_GEMM_NT) return launch_gemm_forms<FORM_KC, FORM_KC, EPI_STD>(tid_, ga, nblocks, s);
+        if (layout == MMVAE_GEMM_NN) return launch_gemm_forms<FORM_KC, FORM_RC, EPI_STD>(tid_, ga, nblocks, s);
+        return launch_gemm_forms<FORM_RC, FORM_RC, EPI_STD>(tid_, ga, nblocks, s);
     };
+    auto launch = [&](const GemmArgs& ga, int slabs) { return launch_tile(tile_id, ga, slabs); };
     int rc;
     // Tail slab: slab outputs of a bf16x3 split over 16-byte-regular operands whose K is not a multiple of the k-tile.
     // The pipelined kernel needs whole k-tiles, so slabs 0 .. splitk-2 cover the whole k-tiles [0, K_main) and run on
@@ -1659,7 +1662,15 @@ static int gemm_f32_impl(int layout, int M, int N, int K, float alpha, const flo
         gm.ktiles_per_split = ceil_div_i(gm.ktiles, splitk - 1);
         int sk_main = splitk - 1;
         if (!raw) sk_main = ceil_div_i(gm.ktiles, gm.ktiles_per_split);
-        rc = launch(gm, sk_main);
+        if (sk_main == 1) {  // one slab over the whole k-tiles: free to take the tile shape that fills the chip best
+            const int t_main = x3_tile_for(M, N, true);
+            const TileShape tm = tile_shape(layout, t_main);
+            gm.mt = ceil_div_i(M, tm.bm);
+            gm.nt = ceil_div_i(N, tm.bn);
+            rc = launch_tile(t_main, gm, 1);
+        } else {
+            rc = launch(gm, sk_main);
+        }
         if (rc != MMVAE_OK) return rc;
         GemmArgs gt = g;
         const bool a_kc = layout != MMVAE_GEMM_TN, b_kc = layout == MMVAE_GEMM_NT;

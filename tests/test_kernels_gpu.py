@@ -125,7 +125,8 @@ def test_gemm_raw_slabs(ops, layout):
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
-@pytest.mark.parametrize("M,N,K", [(512, 1024, 30000), (512, 1024, 20016), (512, 1024, 60532)])
+@pytest.mark.parametrize("M,N,K", [(512, 1024, 30000), (512, 1024, 20016), (512, 1024, 60532), (5120, 1024, 3000),
+                                   (2560, 1024, 30002)])
 def test_gemm_raw_slabs_with_k_tail(ops, layout, M, N, K):
     """The engine's K = G reductions (encoder forward, decoder dX) at gene counts that are not a multiple of the k-tile:
     the planner's slab count includes the tail slab; slabs sum to the product; the tail slab holds only the last
