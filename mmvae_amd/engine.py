@@ -203,12 +203,15 @@ class StepEngine:
         key = (name, tuple(int(s) for s in shape), dtype)
         t = self._pool.get(key)
         if t is None:
-            # 16 spare elements behind every buffer: a rows-contiguous GEMM operand whose extent is not a multiple of 4
-            # (60 530 genes) is read in 16-byte groups up to its last row's end + 12 bytes (MMVAE_GEMM_OPERAND_SLACK)
+            # Slack behind every buffer, zero and never written: 16 elements for a rows-contiguous GEMM operand whose
+            # extent is not a multiple of 4 (60 530 genes: 16-byte groups reach 12 bytes past the last row,
+            # MMVAE_GEMM_OPERAND_SLACK), and 32 more ROWS behind a matrix, so that a weight-gradient GEMM whose K is the
+            # batch can run K up to the next multiple of 32 over zero rows instead of taking a K-tail path (kpad)
             n = 1
             for d in key[1]:
                 n *= d
-            t = torch.zeros(n + 16, dtype=dtype, device=self.device)[:n].view(key[1])
+            extra = 16 + (32 * key[1][-1] if len(key[1]) >= 2 else 0)
+            t = torch.zeros(n + extra, dtype=dtype, device=self.device)[:n].view(key[1])
             self._pool[key] = t
         return t
 
@@ -267,8 +270,9 @@ class StepEngine:
         seen = self._ptr_seen.get(pkey, 0)
         self._ptr_seen[pkey] = seen + 1
         n_ptr_plans = sum(1 for k in self._plans if k[-2] != 0)
-        # a caller's tensor has no slack behind it: with a gene count that is not a multiple of 4 it is always staged
-        if x.shape[1] % 4 == 0 and (pkey in self._plans or (seen >= 1 and n_ptr_plans < MAX_POINTER_PLANS)):
+        # a caller's tensor has no slack behind it: with a gene count that is not a multiple of 4, or a batch that is
+        # not a multiple of 32 (kpad reads zero rows behind the batch), it is always staged
+        if x.shape[1] % 4 == 0 and B % 32 == 0 and (pkey in self._plans or (seen >= 1 and n_ptr_plans < MAX_POINTER_PLANS)):
             return pkey, x
         x_in = self.buf(f"x_static.{base_key[1]}", (B, x.shape[1]))
         if x.is_contiguous():  # own 16-byte copy kernel: the runtime's blit kernel reaches < 1 TB/s here
@@ -455,6 +459,13 @@ class _Plan:
 
     def mptr(self, name: str) -> int:
         return self.metrics.data_ptr() + 4 * self.slot(name)
+
+    @staticmethod
+    def kpad(rows: int) -> int:
+        """K of a weight-gradient GEMM over `rows` batch rows: the next multiple of 32.  Both operands are engine
+        buffers with 32 zero rows of slack behind them (StepEngine.buf), so the extra rows contribute exact zeros and
+        the GEMM stays on the pipelined whole-k-tile kernel for any batch size."""
+        return (rows + 31) // 32 * 32
 
     def _plan_gemm(self, layout, M, N, K):
         tile, sk = C.c_int(0), C.c_int(0)
@@ -682,7 +693,9 @@ class _Plan:
 
         self._cur.append(call)
         # dW[n_out, n_in] = dz^T[n_out, rows] . inp[rows, n_in]  -> straight into the gradient arena
-        self.gemm(TN, l.n_out, l.n_in, rows, l.dz, l.n_out, l.inp, l.ld_inp, l.gW, l.n_in, side=True)
+        # (an adversary reading the first of K > 1 samples: the rows behind its B input rows are the next sample, not slack)
+        k_rows = rows if (self.K > 1 and l.inp is self.z and rows != self.R) else self.kpad(rows)
+        self.gemm(TN, l.n_out, l.n_in, k_rows, l.dz, l.n_out, l.inp, l.ld_inp, l.gW, l.n_in, side=True)
         if need_dx == "raw":
             return self.gemm_raw(NN, rows, l.n_in, l.n_out, l.dz, l.n_out, l.W, l.n_in)
         if need_dx == "full":
@@ -861,7 +874,7 @@ class _Plan:
             self._emit_fc_bwd(R, G, self.dP, None, self.w, self.dP, last.gb)
         else:
             self._emit_fc_bwd(R, G, self.dP, None, None, None, last.gb)
-        self.gemm(TN, G, last.n_in, R, self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True)
+        self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True)
         S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
         rest = self.dec_layers[:-1]
         for j in range(len(rest) - 1, -1, -1):
@@ -896,7 +909,7 @@ class _Plan:
                        None, None, _p(eng.klw_dev), 1.0 / B, self.var_eps, _p(self.dmu), _p(self.da))
         for dy, lin in ((self.dmu, self.mean_enc), (self.da, self.var_enc)):
             self._emit_fc_bwd(B, Z, dy, None, None, None, eng.grad_of(lin.bias))
-            self.gemm(TN, Z, HV, B, dy, Z, q, HV, eng.grad_of(lin.weight), HV, side=True)
+            self.gemm(TN, Z, HV, self.kpad(B), dy, Z, q, HV, eng.grad_of(lin.weight), HV, side=True)
         self.gemm(NN, B, HV, Z, self.dmu, Z, self.mean_enc.weight, HV, self.dq, HV)
         self.gemm(NN, B, HV, Z, self.da, Z, self.var_enc.weight, HV, self.dq, HV, flags=ACC)
         # ---- backward, encoder side
@@ -1057,7 +1070,7 @@ class _Plan:
                                        None, gscale)
                             col += (Cn + 3) // 4 * 4
                     self._emit_fc_bwd(B, Ct, fused["dlogits"], None, None, None, fused["gb"])
-                    self.gemm(TN, Ct, n_e, B, fused["dlogits"], Ct, e, n_e, fused["gW"], n_e, side=True)
+                    self.gemm(TN, Ct, n_e, self.kpad(B), fused["dlogits"], Ct, e, n_e, fused["gW"], n_e, side=True)
                     self.gemm(NN, B, n_e, Ct, fused["dlogits"], Ct, fused["W"], n_e, de, n_e)
                 for ci, c in enumerate(self.conditions if fused is None else []):
                     lin = heads[c]
@@ -1067,7 +1080,7 @@ class _Plan:
                                _p(dlogits[c]), Cn, None, gscale)
                     # head backward
                     self._emit_fc_bwd(B, Cn, dlogits[c], None, None, None, g(lin.bias))
-                    self.gemm(TN, Cn, n_e, B, dlogits[c], Cn, e, n_e, g(lin.weight), n_e, side=True)
+                    self.gemm(TN, Cn, n_e, self.kpad(B), dlogits[c], Cn, e, n_e, g(lin.weight), n_e, side=True)
                     self.gemm(NN, B, n_e, Cn, dlogits[c], Cn, lin.weight, n_e, de, n_e, flags=ACC if ci > 0 else 0)
                 # the heads' losses and their sum: consecutive metrics words, one launch
                 first = self.slot(f"{phase}_{i}/{self.conditions[0]}") if H else None
