@@ -169,3 +169,20 @@ def test_csr_batches_train_like_dense_ones(use_engine, monkeypatch):
     monkeypatch.setattr(MU.H, "step_inputs", csr_inputs)
     case, z, results = MU.replay_training("two_mod_odd", "cuda", use_engine=use_engine)
     MU.check_against_golden(case, z, results)
+
+
+@pytest.mark.parametrize("name", ["two_mod_odd", "adversarial", "cond_adv"])
+def test_slack_behind_engine_buffers_stays_zero(name):
+    """The engine's GEMMs rely on it (StepEngine.buf): 16 elements + 32 rows of zeros behind every buffer, which no
+    kernel ever writes -- a weight-gradient GEMM over B = 33 cells reads rows 33..63 of its operands as zeros."""
+    MU.replay_training(name, "cuda", use_engine=True)
+    engine = MU.replay_training.last_engine
+    torch.cuda.synchronize()
+    checked = 0
+    for key, t in engine._pool.items():
+        full = torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage())
+        tail = full[t.storage_offset() + t.numel():]
+        assert tail.numel() >= 16
+        assert not bool(tail.ne(0).any()), f"slack behind engine buffer {key} was written"
+        checked += 1
+    assert checked > 20
