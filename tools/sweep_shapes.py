@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Step time of the captured engine over a grid of batch sizes and gene counts (2 modalities, K = 1): looks for shape
-cliffs -- sizes at which a kernel falls off its fast path.  Prints ms / step and fp32-equivalent TFLOP/s."""
+"""Step time of the captured engine over a grid of batch sizes, gene counts and sample counts K (2 modalities): looks for
+shape cliffs -- sizes at which a kernel falls off its fast path.  Prints ms / step and fp32-equivalent TFLOP/s.
+usage: sweep_shapes.py [B,B,...] [G,G,...] [K,K,...]"""
 import os
 import sys
 import time
@@ -13,8 +14,8 @@ import torch  # noqa: E402
 from mmvae_amd import synthetic  # noqa: E402
 
 
-def run(B, G, steps=12, warm=6):
-    model = synthetic.build_model({"human": G, "mouse": G}, seed=0).cuda()
+def run(B, G, K=1, steps=12, warm=6):
+    model = synthetic.build_model({"human": G, "mouse": G}, n_samples=K, seed=0).cuda()
     model.train()
     model.trainer.set_stage("training")
     xs = {e: synthetic.synthetic_counts(B, G, seed=3 + i, device="cuda") for i, e in enumerate(("human", "mouse"))}
@@ -27,7 +28,7 @@ def run(B, G, steps=12, warm=6):
         model.training_step((xs[eid], md, eid), i)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    tf = synthetic.flops_per_cell(G) * B / ms / 1e9
+    tf = synthetic.flops_per_cell(G, K) * B / ms / 1e9
     del model, xs
     torch.cuda.empty_cache()
     return ms, tf
@@ -36,10 +37,12 @@ def run(B, G, steps=12, warm=6):
 if __name__ == "__main__":
     Bs = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "256,500,512,1000,1024,2048".split(","))]
     Gs = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "5000,20000,33333,60530".split(","))]
-    print("B \\ G  " + "".join(f"{g:>22d}" for g in Gs))
-    for B in Bs:
-        cells = []
-        for G in Gs:
-            ms, tf = run(B, G)
-            cells.append(f"{ms:8.3f} ms {tf:6.1f} TF")
-        print(f"{B:6d}  " + "".join(f"{c:>22s}" for c in cells), flush=True)
+    Ks = [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["1"])]
+    for K in Ks:
+        print(f"K = {K}   B \\ G  " + "".join(f"{g:>22d}" for g in Gs))
+        for B in Bs:
+            cells = []
+            for G in Gs:
+                ms, tf = run(B, G, K)
+                cells.append(f"{ms:8.3f} ms {tf:6.1f} TF")
+            print(f"{B:6d}  " + "".join(f"{c:>22s}" for c in cells), flush=True)
