@@ -347,7 +347,8 @@ typedef struct {
     uint32_t flags;
     uint32_t reserved;
 } mmvae_sum_job;
-int mmvae_sum_parts_batch(int n_jobs, const mmvae_sum_job* jobs, mmvae_stream_t stream);
+int mmvae_sum_parts_batch(int n_jobs, const mmvae_sum_job* jobs, int64_t max_elems /* rows * cols of the largest job,
+                          sizes the grid; 0 = unknown */, mmvae_stream_t stream);
 
 /* Unsplit GEMM that also leaves the sum of squares of everything it stores, one partial per output tile, in
  * sq_partials[0 .. sq_capacity) (slots beyond the tiles it uses are zeroed): the weight-gradient GEMMs of the G-wide

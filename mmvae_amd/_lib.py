@@ -94,7 +94,7 @@ PROTOTYPES = {
     "mmvae_philox_fill_jobs": (_i, [_i, _p, _l, _p, _p]),
     "mmvae_axpby": (_i, [_l, _f, _p, _f, _p, _p]),
     "mmvae_scale_rows": (_i, [_i, _i, _p, _l, _p, _p, _l, _p]),
-    "mmvae_sum_parts_batch": (_i, [_i, _p, _p]),
+    "mmvae_sum_parts_batch": (_i, [_i, _p, _l, _p]),
     "mmvae_gemm_sq_partials": (_i, [_i, _i, _i, _i, _i]),
     "mmvae_gemm_f32_sq": (_i, [_i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _u, _p, _l, _p]),
     "mmvae_csr_to_dense_f32": (_i, [_i, _i, _l, _p, _p, _p, _p, _l, _p]),

@@ -770,8 +770,7 @@ __global__ __launch_bounds__(256) void axpby4_kernel(int64_t n4, float alpha, co
 __global__ __launch_bounds__(256) void sum_parts_batch_kernel(const mmvae_sum_job* __restrict__ jobs) {
     const mmvae_sum_job j = jobs[blockIdx.y];
     const bool acc = j.flags & MMVAE_GEMM_ACCUMULATE;
-    const bool vec = (j.cols % 4 == 0) && (j.ld_src % 4 == 0) && (j.ld_dst % 4 == 0) && (j.part_stride % 4 == 0) &&
-                     ((reinterpret_cast<uintptr_t>(j.src) | reinterpret_cast<uintptr_t>(j.dst)) & 15) == 0;
+    const bool vec = j.cols % 4 == 0;  // whole 16-byte groups per row (global accesses need no alignment on gfx950)
     if (vec) {
         const int c4n = j.cols / 4;
         const int64_t total = (int64_t)j.rows * c4n;
@@ -1113,9 +1112,12 @@ extern "C" int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, f
     return MMVAE_OK;
 }
 
-extern "C" int mmvae_sum_parts_batch(int n_jobs, const mmvae_sum_job* jobs, mmvae_stream_t stream) {
-    if (n_jobs <= 0 || n_jobs > 65535 || !jobs) return MMVAE_ERR_ARG;
-    MMVAE_LAUNCH(sum_parts_batch_kernel, dim3(64, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
+extern "C" int mmvae_sum_parts_batch(int n_jobs, const mmvae_sum_job* jobs, int64_t max_elems, mmvae_stream_t stream) {
+    if (n_jobs <= 0 || n_jobs > 65535 || !jobs || max_elems < 0) return MMVAE_ERR_ARG;
+    // workgroups per job: sized for the largest job (4 groups of 4 elements per thread), 64 when the caller cannot say
+    const int gx = max_elems > 0 ? grid_for((max_elems + 15) / 16, 256, 2048) : 64;
+    MMVAE_LAUNCH(sum_parts_batch_kernel, dim3(gx < 64 ? (gx < 1 ? 1 : gx) : gx, n_jobs), dim3(256), 0, (hipStream_t)stream,
+                 jobs);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }

@@ -32,7 +32,12 @@ def init_from_env(backend: Optional[str] = None) -> int:
             backend = os.environ.get("MMVAE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group(backend=backend)
+        kwargs = {}
+        if os.environ.get("MMVAE_DIST_TIMEOUT_S"):  # tests: a lost peer fails the collective instead of hanging for 30 min
+            import datetime
+
+            kwargs["timeout"] = datetime.timedelta(seconds=float(os.environ["MMVAE_DIST_TIMEOUT_S"]))
+        dist.init_process_group(backend=backend, **kwargs)
     return world
 
 

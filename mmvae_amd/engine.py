@@ -598,7 +598,8 @@ class _Plan:
         arr = (_lib.SumJob * len(self._sum_jobs))(*self._sum_jobs)
         jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.eng.device)
         self._job_tables.append(jobs_dev)  # lives as long as the plan (the captured graph reads it on every replay)
-        self._emit(self.lib.mmvae_sum_parts_batch, len(self._sum_jobs), jobs_dev.data_ptr())
+        self._emit(self.lib.mmvae_sum_parts_batch, len(self._sum_jobs), jobs_dev.data_ptr(),
+                   max(int(j.rows) * int(j.cols) for j in self._sum_jobs))
         self._sum_jobs = []
 
     def gemm_raw(self, layout, M, N, K, A, lda, Bm, ldb) -> int:

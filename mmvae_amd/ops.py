@@ -518,7 +518,8 @@ def sum_parts_batch(jobs) -> None:
         arr[k] = _lib.SumJob(_ptr(src), _ptr(dst), R * Cn, Cn, dst.stride(0) if R > 1 else Cn, P, R, Cn, float(alpha),
                              _lib.GEMM_ACCUMULATE if accumulate else 0, 0)
     jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-    _lib.check(lib.mmvae_sum_parts_batch(len(jobs), _ptr(jobs_dev), _stream()), "mmvae_sum_parts_batch")
+    _lib.check(lib.mmvae_sum_parts_batch(len(jobs), _ptr(jobs_dev), max(int(j.rows) * int(j.cols) for j in arr), _stream()),
+               "mmvae_sum_parts_batch")
     torch.cuda.current_stream().synchronize()  # jobs_dev must outlive the launch
 
 

@@ -50,7 +50,8 @@ def _flat_params(model, case):
 
 
 def _worker(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      MMVAE_DIST_TIMEOUT_S="120")
     torch.set_num_threads(1)
     from mmvae_amd import backend, dist as mdist
 

@@ -27,7 +27,8 @@ def _free_port():
 
 
 def _run(rank, world, port, out_dir, use_engine, name="two_mod_odd"):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      MMVAE_DIST_TIMEOUT_S="120")  # a stuck collective fails this test after 2 minutes
     from mmvae_amd import dist as mdist
 
     assert mdist.init_from_env("gloo") == world
