@@ -16,6 +16,7 @@ from __future__ import annotations
 
 from typing import Dict, Iterable, List, Optional
 
+import numpy as np
 import torch
 
 from . import backend, ops

@@ -186,3 +186,62 @@ def test_slack_behind_engine_buffers_stays_zero(name):
         assert not bool(tail.ne(0).any()), f"slack behind engine buffer {key} was written"
         checked += 1
     assert checked > 20
+
+
+@pytest.mark.parametrize("name", ["two_mod_odd", "adversarial", "cond_adv"])
+def test_checkpoint_and_resume_continue_bit_for_bit(name, tmp_path):
+    """Stop after the first steps, save module + optimiser state_dicts, rebuild everything from the files and continue:
+    the resumed run must end on exactly the parameters of the uninterrupted one (engine path; optimiser moments, step
+    counts -- per parameter for the conditional blocks --, BatchNorm buffers all travel through the state_dicts)."""
+    import copy
+    import random
+
+    import pandas as pd
+
+    case, z = H.load_case(name)
+    T = len(case["schedule"])
+
+    def run_steps(model, first, last):
+        for t in range(first, last):
+            eid = case["schedule"][t]
+            x, eps, masks, labels = H.step_inputs(z, t)
+            model.kl_annealing_fn.kl_weight = case["kl_weights"][t]
+            model.module.vae.encoder.explicit_eps = eps.cuda()
+            enc = model.module.experts[eid].encoder
+            enc.explicit_masks = {int(k.split(".")[4]): m.cuda() for k, m in masks.items()
+                                  if k.startswith(f"experts.{eid}.encoder.fc_layers.")}
+            meta = {c: [f"{c}_{int(i)}" for i in idx] for c, idx in labels.items()}
+            if case.get("cond"):
+                meta.update(H.cond_inputs(case, z, t, eid)[0])
+                random.seed(case["seed"] * 100 + t)
+            model.training_step((x.cuda(), pd.DataFrame(meta if meta else {"dummy": [0] * x.shape[0]}), eid), t)
+
+    def fresh(sub):
+        model = MU.build_mirror(case, "cuda", str(tmp_path / sub), use_engine=True)
+        MU.load_state(model, z, "sd0/")
+        model.train()
+        model.trainer.set_stage("training")
+        model.optimizers()
+        return model
+
+    (tmp_path / "a").mkdir(), (tmp_path / "b").mkdir(), (tmp_path / "c").mkdir()
+    straight = fresh("a")
+    run_steps(straight, 0, T)
+    want = {k: v.detach().clone() for k, v in straight.state_dict().items()}
+
+    first = fresh("b")
+    run_steps(first, 0, T - 1)
+    torch.save({"model": first.state_dict(), "optim": [copy.deepcopy(o.state_dict()) for o in first.optimizers()]},
+               tmp_path / "ckpt.pt")
+    del first
+
+    ckpt = torch.load(tmp_path / "ckpt.pt", weights_only=False)
+    resumed = fresh("c")
+    resumed.load_state_dict(ckpt["model"])
+    for o, sd in zip(resumed.optimizers(), ckpt["optim"]):
+        o.load_state_dict(sd)
+    run_steps(resumed, T - 1, T)
+    got = resumed.state_dict()
+    assert got.keys() == want.keys()
+    for k in want:
+        assert torch.equal(got[k], want[k]), f"{k} differs after resume"
