@@ -67,3 +67,30 @@ def test_fit_validate_predict_from_chunk_files(tmp_path):
     z_again = model.predict_step((batches[0][0], batches[0][1].copy(), "human"))["z"][0]
     assert z_again.shape == (B, 16)
     del raw
+
+
+def test_changing_batch_sizes_and_partial_batches(tmp_path):
+    """A feed with allow_partials yields a short last batch per chunk: the engine builds one program per batch size and
+    goes back and forth between them; results stay finite and every batch size keeps its own captured program."""
+    from mmvae_amd import data as D, synthetic
+    from mmvae_amd.trainer import MultiModalBatches
+
+    genes = {"human": 130, "mouse": 77}
+    for i, (name, g) in enumerate(genes.items()):
+        _write_species(tmp_path, name, 150, g, seed=21 + i)  # chunks of 64, 64, 22 rows
+    feeds = {name: D.SpeciesChunks(str(tmp_path / name), f"{name}_train_counts_*.npz", f"{name}_train_metadata_*.pkl", 24,
+                                   name, allow_partials=True, seed=5, device="cuda") for name in genes}
+    model = synthetic.build_model(genes, latent_dim=12, h1=48, h2=32, hv=20, dropout=0.1, seed=1).cuda()
+    model.train()
+    model.trainer.set_stage("training")
+    sizes = []
+    for epoch in range(2):
+        for i, (x, md, eid) in enumerate(MultiModalBatches(feeds, seed=epoch)):
+            sizes.append(x.shape[0])
+            model.training_step((x, md, eid), i)
+            loss = float(model.logged[f"loss/training/{eid}"])
+            assert math.isfinite(loss), (epoch, i, eid, x.shape)
+    assert set(sizes) == {24, 16, 22}  # 64 = 24 + 24 + 16; 22 = the short chunk
+    plans = model._engine._plans
+    assert {k[2] for k in plans if k[0] == "train"} == {24, 16, 22}
+    assert all(p._graphs is not None for p in plans.values()), "every batch size replays its own captured program"
