@@ -242,6 +242,8 @@ def main():
         step(n_setup + a.warmup + i)
     sync()
     el = time.perf_counter() - t0
+    if feed is not None:
+        feed.close()  # stops the feed's background threads before the interpreter shuts down
     if world > 1:
         t = torch.tensor([el], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -5,7 +5,7 @@
  * (data/local/cellxgene_datapipe.py:110-122) followed by a row slice and torch.sparse_csr_tensor(...)
  * (:169-193).  This library does the one memory-bound step of that chain natively and without the interpreter
  * lock: gather B rows of a CSR chunk (given by index, i.e. the permutation is never materialised) into three
- * caller-owned staging arrays in the layout torch.sparse_csr uses (int64 row pointers and column indices, fp32
+ * caller-owned staging arrays in the layout torch.sparse_csr uses (int64 or int32 row pointers and column indices, fp32
  * values) -- typically page-locked buffers that are then copied to the GPU asynchronously.
  *
  * Plain C, host pointers only, no allocation, no global state; thread-safe (distinct output buffers per call).
@@ -37,6 +37,13 @@ int64_t mmvae_feed_rows_nnz(const void* indptr, int index_bytes, int64_t n_chunk
 int mmvae_feed_gather_rows(const void* indptr, const void* indices, int index_bytes, const float* data,
                            int64_t n_chunk_rows, const int64_t* rows, int64_t n_rows, int64_t* out_crow,
                            int64_t* out_col, float* out_val, int64_t capacity, int n_threads, int64_t* out_nnz);
+
+/* Same with int32 row pointers / column indices in the output -- the index type of the reference's batches
+ * (torch.sparse_csr_tensor keeps the int32 arrays of the scipy slice, cellxgene_datapipe.py:178-183) and a third less
+ * data to copy to the GPU.  MMVAE_FEED_ERR_CAPACITY when the batch holds more than 2^31 - 1 stored elements. */
+int mmvae_feed_gather_rows_i32(const void* indptr, const void* indices, int index_bytes, const float* data,
+                               int64_t n_chunk_rows, const int64_t* rows, int64_t n_rows, int32_t* out_crow,
+                               int32_t* out_col, float* out_val, int64_t capacity, int n_threads, int64_t* out_nnz);
 
 #ifdef __cplusplus
 }

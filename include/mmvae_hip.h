@@ -395,6 +395,10 @@ int mmvae_gemm_batch_f32(int n_jobs, const mmvae_gemm_job* jobs_dev, int total_b
  * path densifies straight into the step's input buffer: one pass, 4*B*G bytes written, 16*nnz bytes read. */
 int mmvae_csr_to_dense_f32(int B, int G, int64_t nnz, const int64_t* crow_indices, const int64_t* col_indices,
                            const float* values, float* out, int64_t ldo, mmvae_stream_t stream);
+/* Same for int32 index arrays -- what the reference's batches carry: torch.sparse_csr_tensor keeps the int32 indptr /
+ * indices of the scipy slice it is built from (cellxgene_datapipe.py:178-183) -- a third less data on the wire. */
+int mmvae_csr_to_dense_i32_f32(int B, int G, int64_t nnz, const int32_t* crow_indices, const int32_t* col_indices,
+                               const float* values, float* out, int64_t ldo, mmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Conditional layers: y[b] = W[c_b] x[b] + bias[c_b], the Linear of each cell's OWN condition.

@@ -1061,15 +1061,16 @@ extern "C" int mmvae_philox_advance(uint64_t* rng_state, uint64_t by, mmvae_stre
 // the workgroup.  Out-of-range column indices are dropped (never written), so a malformed matrix cannot fault.
 constexpr int CSR_CHUNK = 8192;  // columns per workgroup
 
-__global__ __launch_bounds__(256) void csr_to_dense_kernel(int G, int64_t nnz, const int64_t* __restrict__ crow,
-                                                           const int64_t* __restrict__ col,
+template <typename I>  // index type of the CSR arrays: int64 (torch's default) or int32 (what scipy-built tensors carry)
+__global__ __launch_bounds__(256) void csr_to_dense_kernel(int G, int64_t nnz, const I* __restrict__ crow,
+                                                           const I* __restrict__ col,
                                                            const float* __restrict__ val, float* __restrict__ out,
                                                            int64_t ldo, int vec) {
     const int row = blockIdx.y;
     const int c0 = blockIdx.x * CSR_CHUNK;
     const int c1 = min(c0 + CSR_CHUNK, G);
     float* o = out + (int64_t)row * ldo;
-    if (vec) {  // row base and chunk bounds 16-byte regular
+    if (vec) {  // 16-byte zero fill (no alignment needed on gfx950)
         const int n4 = (c1 - c0) >> 2;
         f32x4* o4 = reinterpret_cast<f32x4*>(o + c0);
         for (int i = threadIdx.x; i < n4; i += 256) o4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1078,11 +1079,11 @@ __global__ __launch_bounds__(256) void csr_to_dense_kernel(int G, int64_t nnz, c
         for (int c = c0 + threadIdx.x; c < c1; c += 256) o[c] = 0.f;
     }
     __syncthreads();
-    int64_t beg = crow[row], end = crow[row + 1];
+    int64_t beg = (int64_t)crow[row], end = (int64_t)crow[row + 1];
     beg = beg < 0 ? 0 : beg;
     end = end > nnz ? nnz : end;  // a malformed row pointer cannot read past the index / value arrays
     for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
-        const int64_t c = col[i];
+        const int64_t c = (int64_t)col[i];
         if (c >= c0 && c < c1) o[c] = val[i];
     }
 }
@@ -1093,9 +1094,20 @@ extern "C" int mmvae_csr_to_dense_f32(int B, int G, int64_t nnz, const int64_t* 
     if (B <= 0 || G <= 0 || nnz < 0 || !crow_indices || !out || ldo < G) return MMVAE_ERR_ARG;
     if (nnz > 0 && (!col_indices || !values)) return MMVAE_ERR_ARG;
     if (B > 65535) return MMVAE_ERR_ARG;
-    const int vec = aligned16(out) && (ldo % 4 == 0) ? 1 : 0;
-    MMVAE_LAUNCH(csr_to_dense_kernel, dim3(ceil_div_i(G, CSR_CHUNK), B), dim3(256), 0, (hipStream_t)stream, G,
-                       nnz, crow_indices, col_indices, values, out, ldo, vec);
+    MMVAE_LAUNCH(csr_to_dense_kernel<int64_t>, dim3(ceil_div_i(G, CSR_CHUNK), B), dim3(256), 0, (hipStream_t)stream, G,
+                       nnz, crow_indices, col_indices, values, out, ldo, 1);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_csr_to_dense_i32_f32(int B, int G, int64_t nnz, const int32_t* crow_indices,
+                                          const int32_t* col_indices, const float* values, float* out, int64_t ldo,
+                                          mmvae_stream_t stream) {
+    if (B <= 0 || G <= 0 || nnz < 0 || nnz > 0x7fffffffLL || !crow_indices || !out || ldo < G) return MMVAE_ERR_ARG;
+    if (nnz > 0 && (!col_indices || !values)) return MMVAE_ERR_ARG;
+    if (B > 65535) return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(csr_to_dense_kernel<int32_t>, dim3(ceil_div_i(G, CSR_CHUNK), B), dim3(256), 0, (hipStream_t)stream, G,
+                       nnz, crow_indices, col_indices, values, out, ldo, 1);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }

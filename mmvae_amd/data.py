@@ -6,7 +6,7 @@ Mirrors the reference's local datapipes without torchdata (not installed here; d
     directory matched by fnmatch masks, sorted, counts chunk i paired with metadata chunk i;
   * chunk loading    -- `scipy.sparse.load_npz` + `pickle.load` of a DataFrame (:60-86);
   * shuffling        -- chunk order and, per chunk, one row permutation applied to matrix and DataFrame alike (:110-122);
-  * batching         -- consecutive `batch_size` rows as `torch.sparse_csr_tensor(indptr, indices, data)` (int64 indices,
+  * batching         -- consecutive `batch_size` rows as `torch.sparse_csr_tensor(indptr, indices, data)` (int32 indices by default,
     fp32 values) or, with `return_dense`, its dense form; partial batches dropped unless `allow_partials` (:169-193);
   * tagging          -- `(tensor, metadata, species_name)` (data/local/cellxgene_manager.py:76-88).
 Differences, all on purpose: the shuffles draw from a seeded `numpy.random.Generator` (the reference uses the global
@@ -18,6 +18,7 @@ staged to the device as CSR components from pinned memory (12 B per stored eleme
 from __future__ import annotations
 
 import fnmatch
+import atexit
 import os
 import pickle
 import queue
@@ -123,20 +124,23 @@ def feed_lib():
         lib.mmvae_feed_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                                C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                                C.c_void_p]
-        assert lib.mmvae_feed_abi_version() == 1
+        lib.mmvae_feed_gather_rows_i32.restype = C.c_int
+        lib.mmvae_feed_gather_rows_i32.argtypes = lib.mmvae_feed_gather_rows.argtypes
+        assert lib.mmvae_feed_abi_version() == 2
         _FEED = lib
     return _FEED
 
 
 class _Slot:
-    """Staging arrays of one batch in flight: int64 row pointers / column indices and fp32 values in the layout
+    """Staging arrays of one batch in flight: row pointers / column indices (int32 or int64) and fp32 values in the layout
     torch.sparse_csr uses.  Page-locked when the batches go to a GPU; reused once the asynchronous H2D copies that
     read it have completed (`event`)."""
 
-    def __init__(self, n_rows: int, pinned: bool):
+    def __init__(self, n_rows: int, pinned: bool, index_dtype=torch.int32):
         self.pinned = pinned
-        self.crow = self._alloc(n_rows + 1, torch.int64)
-        self.col = self._alloc(16, torch.int64)
+        self.index_dtype = index_dtype
+        self.crow = self._alloc(n_rows + 1, index_dtype)
+        self.col = self._alloc(16, index_dtype)
         self.val = self._alloc(16, torch.float32)
         self.event = None
 
@@ -147,7 +151,7 @@ class _Slot:
     def reserve(self, nnz: int) -> None:
         if self.col.numel() < nnz:
             cap = (int(nnz * 1.25) + 16) if self.pinned else max(nnz, 1)  # pinned buffers are reused: leave headroom
-            self.col, self.val = self._alloc(cap, torch.int64), self._alloc(cap, torch.float32)
+            self.col, self.val = self._alloc(cap, self.index_dtype), self._alloc(cap, torch.float32)
 
 
 class SpeciesChunks:
@@ -164,7 +168,7 @@ class SpeciesChunks:
     def __init__(self, directory_path: str, npz_masks, metadata_masks, batch_size: int, name: str,
                  allow_partials: bool = False, shuffle: bool = True, return_dense: bool = False, seed: int = 0,
                  device: Optional[Union[str, torch.device]] = None, prefetch: bool = True, rank: int = 0, world: int = 1,
-                 workers: int = 3, gather_threads: int = 2):
+                 workers: int = 3, gather_threads: int = 2, index_dtype: torch.dtype = torch.int32):
         self.chunks = list_chunks(directory_path, npz_masks, metadata_masks)
         self.batch_size = int(batch_size)
         self.name = name
@@ -177,6 +181,11 @@ class SpeciesChunks:
         self.rank, self.world = rank, world
         self.workers = max(1, int(workers))
         self.gather_threads = max(1, int(gather_threads))
+        # int32: what the reference's batches carry (torch.sparse_csr_tensor keeps the int32 indptr / indices of the scipy
+        # slice, cellxgene_datapipe.py:178-183) and a third less data per batch on the wire; int64 on request
+        if index_dtype not in (torch.int32, torch.int64):
+            raise ValueError("index_dtype must be torch.int32 or torch.int64")
+        self.index_dtype = index_dtype
         self.epoch = 0
         self._slots: List[_Slot] = []
 
@@ -191,26 +200,44 @@ class SpeciesChunks:
             yield matrix, metadata, rows.astype(np.int64)
 
     def _background(self, gen: Iterator) -> Iterator:
-        """Run `gen` in a thread, one item ahead (loading a chunk overlaps the training on the last one)."""
+        """Run `gen` in a thread, one item ahead (loading a chunk overlaps the training on the last one).  The thread
+        stops when the consumer is closed or collected."""
         q: "queue.Queue" = queue.Queue(maxsize=1)
-        done = object()
+        done, stop = object(), threading.Event()
+
+        def put(item) -> bool:
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
 
         def work():
             try:
                 for item in gen:
-                    q.put(item)
-                q.put(done)
+                    if not put(item):
+                        return
+                put(done)
             except BaseException as e:  # noqa: BLE001 -- re-raised in the consumer
-                q.put(e)
+                put(e)
 
-        threading.Thread(target=work, daemon=True).start()
-        while True:
-            item = q.get()
-            if item is done:
-                return
-            if isinstance(item, BaseException):
-                raise item
-            yield item
+        thread = threading.Thread(target=work, daemon=True)
+        thread.start()
+        _LIVE_PRODUCERS.append((stop, thread))
+        try:
+            while True:
+                item = q.get()
+                if item is done:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+            if (stop, thread) in _LIVE_PRODUCERS:
+                _LIVE_PRODUCERS.remove((stop, thread))
 
     # ---- one batch: native gather into a staging slot (worker thread), tensors + H2D (consumer thread)
     def _gather(self, slot: _Slot, matrix, rows: np.ndarray):
@@ -227,16 +254,18 @@ class SpeciesChunks:
         import ctypes as C
 
         got = C.c_int64(0)
-        rc = lib.mmvae_feed_gather_rows(matrix.indptr.ctypes.data, matrix.indices.ctypes.data if nnz else None, ib,
-                                        matrix.data.ctypes.data if nnz else None, matrix.shape[0], rows.ctypes.data,
-                                        len(rows), slot.crow.data_ptr(), slot.col.data_ptr(), slot.val.data_ptr(),
-                                        slot.col.numel(), self.gather_threads, C.byref(got))
+        if slot.index_dtype == torch.int32 and matrix.shape[1] > 0x7fffffff:
+            raise ValueError("a chunk with more than 2^31 - 1 columns needs index_dtype=torch.int64")
+        fn = lib.mmvae_feed_gather_rows_i32 if slot.index_dtype == torch.int32 else lib.mmvae_feed_gather_rows
+        rc = fn(matrix.indptr.ctypes.data, matrix.indices.ctypes.data if nnz else None, ib,
+                matrix.data.ctypes.data if nnz else None, matrix.shape[0], rows.ctypes.data, len(rows), slot.crow.data_ptr(),
+                slot.col.data_ptr(), slot.val.data_ptr(), slot.col.numel(), self.gather_threads, C.byref(got))
         if rc != 0 or got.value != nnz:
             raise RuntimeError(f"mmvae_feed_gather_rows failed with code {rc}")
         return slot, int(nnz), len(rows)
 
     def _tensor(self, slot: _Slot, nnz: int, n_rows: int, n_cols: int) -> torch.Tensor:
-        """Staging slot -> torch.sparse_csr (int64 indices as torch stores them, fp32 values), on the device when one
+        """Staging slot -> torch.sparse_csr (int32 / int64 indices, fp32 values), on the device when one
         was given (three non-blocking copies out of page-locked memory; the slot is reusable once they are done)."""
         crow, col, val = slot.crow[:n_rows + 1], slot.col[:nnz], slot.val[:nnz]
         if self.device is not None and self.device.type == "cuda":
@@ -263,8 +292,9 @@ class SpeciesChunks:
             chunks = self._background(chunks)
         pinned = self.device is not None and self.device.type == "cuda"
         depth = self.workers + 1
-        if len(self._slots) != depth or (self._slots and self._slots[0].pinned != pinned):
-            self._slots = [_Slot(self.batch_size, pinned) for _ in range(depth)]
+        if (len(self._slots) != depth or (self._slots and self._slots[0].pinned != pinned)
+                or (self._slots and self._slots[0].index_dtype != self.index_dtype)):
+            self._slots = [_Slot(self.batch_size, pinned, self.index_dtype) for _ in range(depth)]
         free = deque(self._slots)
         inflight: deque = deque()
 
@@ -291,7 +321,7 @@ class SpeciesChunks:
                     yield finish()
                 slot = free.popleft()
                 if not pinned:  # host batches keep the arrays they were gathered into
-                    slot.crow = torch.empty(self.batch_size + 1, dtype=torch.int64)
+                    slot.crow = torch.empty(self.batch_size + 1, dtype=self.index_dtype)
                 if slot.event is not None:  # the H2D copies that read this slot (depth batches ago) must be done
                     slot.event.synchronize()
                     slot.event = None
@@ -301,6 +331,24 @@ class SpeciesChunks:
 
     def __len__(self) -> int:
         raise TypeError("SpeciesChunks streams chunk files: its length is not known without reading them")
+
+
+_LIVE_PRODUCERS: list = []  # (stop event, thread) of running Prefetcher producers, stopped and joined at interpreter exit
+
+
+def _stop_producers() -> None:
+    """A daemon thread that is still inside torch when the interpreter finalises is torn down by a forced unwind through
+    C++ frames (`terminate called without an active exception`): stop and join the producers first."""
+    for stop, thread in list(_LIVE_PRODUCERS):
+        stop.set()
+    for stop, thread in list(_LIVE_PRODUCERS):
+        thread.join(timeout=10.0)
+    _LIVE_PRODUCERS.clear()
+
+
+atexit.register(_stop_producers)
+if hasattr(threading, "_register_atexit"):  # also before the interpreter starts joining threads
+    threading._register_atexit(_stop_producers)
 
 
 class Prefetcher:
@@ -349,6 +397,8 @@ class Prefetcher:
 
         thread = threading.Thread(target=work, daemon=True)
         thread.start()
+        entry = (stop, thread)
+        _LIVE_PRODUCERS.append(entry)
         try:
             while True:
                 got = q.get()
@@ -368,6 +418,8 @@ class Prefetcher:
                 yield item
         finally:
             stop.set()
+            if entry in _LIVE_PRODUCERS:
+                _LIVE_PRODUCERS.remove(entry)
 
 
 def write_chunks(directory: str, name: str, matrix, metadata: pd.DataFrame, chunk_rows: int, split: str = "train",

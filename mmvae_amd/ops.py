@@ -531,8 +531,9 @@ def csr_to_dense(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
     crow, col, val = x.crow_indices(), x.col_indices(), x.values()
     if not val.is_cuda:
         raise _lib.HipLibraryError("csr_to_dense: CPU tensors have no HIP path")
-    if crow.dtype != torch.int64 or col.dtype != torch.int64:
+    if crow.dtype != col.dtype or crow.dtype not in (torch.int32, torch.int64):
         crow, col = crow.long(), col.long()
+    fn = lib.mmvae_csr_to_dense_i32_f32 if crow.dtype == torch.int32 else lib.mmvae_csr_to_dense_f32
     if val.dtype != torch.float32:
         val = val.float()
     B, G = x.shape
@@ -543,9 +544,8 @@ def csr_to_dense(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
         raise ValueError(f"out {tuple(out.shape)} != {(B, G)}")
     nnz = int(val.numel())
     crow, col, val = crow.contiguous(), col.contiguous(), val.contiguous()
-    _lib.check(lib.mmvae_csr_to_dense_f32(B, G, nnz, crow.data_ptr(), col.data_ptr() if nnz else None,
-                                          val.data_ptr() if nnz else None, _ptr(out), _mat(out, "out")[2], _stream()),
-               "mmvae_csr_to_dense_f32")
+    _lib.check(fn(B, G, nnz, crow.data_ptr(), col.data_ptr() if nnz else None, val.data_ptr() if nnz else None, _ptr(out),
+                  _mat(out, "out")[2], _stream()), "mmvae_csr_to_dense")
     return out
 
 

@@ -44,7 +44,8 @@ def test_batches_keep_rows_and_metadata_index_matched(tmp_path, shuffle, return_
             dense = x
         else:
             assert x.layout == torch.sparse_csr and x.dtype == torch.float32
-            assert x.crow_indices().dtype == torch.int64 and x.col_indices().dtype == torch.int64
+            # int32 indices, as the reference's torch.sparse_csr_tensor over a scipy slice carries them
+            assert x.crow_indices().dtype == torch.int32 and x.col_indices().dtype == torch.int32
             dense = x.to_dense()
         rows = (dense[:, 0] - 1).long().tolist()  # column 0 carries the original row number
         assert rows == md["row"].tolist(), "matrix rows and metadata rows must stay index-matched"
@@ -187,3 +188,34 @@ def test_prefetched_gpu_batches_equal_the_direct_feed(tmp_path):
     assert len(got) == len(direct) == 12  # chunks of 64, 64, 64, 8 rows: 4 + 4 + 4 + 0 batches of 16
     for (a, ra), (b, rb) in zip(got, direct):
         assert ra == rb and torch.equal(a, b)
+
+
+def test_index_dtype_option_and_int32_gather(tmp_path):
+    """index_dtype=torch.int64 yields the same batches with int64 indices; the int32 gather entry point of the native
+    helper is bit-exact against scipy."""
+    import ctypes as C
+
+    m, meta = _dataset(70, 24, 9)
+    D.write_chunks(str(tmp_path), "human", m, meta, chunk_rows=32)
+    kw = dict(directory_path=str(tmp_path), npz_masks="human_train_counts_*.npz", metadata_masks="human_train_metadata_*.pkl",
+              batch_size=8, name="human", seed=3)
+    a = list(D.SpeciesChunks(**kw))
+    b = list(D.SpeciesChunks(index_dtype=torch.int64, **kw))
+    assert len(a) == len(b) == 8
+    for (xa, ma, _), (xb, mb, _) in zip(a, b):
+        assert xa.col_indices().dtype == torch.int32 and xb.col_indices().dtype == torch.int64
+        assert torch.equal(xa.to_dense(), xb.to_dense()) and ma.equals(mb)
+    with pytest.raises(ValueError):
+        D.SpeciesChunks(index_dtype=torch.int16, **kw)
+    lib = D.feed_lib()
+    rows = np.random.default_rng(1).permutation(70)[:33].astype(np.int64)
+    ref = m[rows]
+    crow, col = np.empty(34, np.int32), np.full(ref.nnz + 3, -1, np.int32)
+    val, got = np.zeros(ref.nnz + 3, np.float32), C.c_int64(0)
+    mi = m.copy()
+    rc = lib.mmvae_feed_gather_rows_i32(mi.indptr.ctypes.data, mi.indices.ctypes.data, mi.indptr.dtype.itemsize,
+                                        mi.data.ctypes.data, 70, rows.ctypes.data, 33, crow.ctypes.data, col.ctypes.data,
+                                        val.ctypes.data, len(col), 2, C.byref(got))
+    assert rc == 0 and got.value == ref.nnz
+    assert np.array_equal(crow, ref.indptr) and np.array_equal(col[:ref.nnz], ref.indices)
+    assert np.array_equal(val[:ref.nnz], ref.data) and (col[ref.nnz:] == -1).all()

@@ -481,7 +481,13 @@ def test_csr_to_dense(ops, B, G, density):
     out = ops.csr_to_dense(x.cuda())
     assert torch.equal(out.cpu(), d)
     base = torch.full((B, G + 3), 7.0, device="cuda")
-    ops.csr_to_dense(x.cuda(), out=base[:, :G])  # unaligned leading dimension: scalar zero fill
+    ops.csr_to_dense(x.cuda(), out=base[:, :G])  # leading dimension that is not a multiple of 4
+    assert torch.equal(base[:, :G].cpu(), d) and bool((base[:, G:] == 7.0).all())
+    # int32 index arrays: what a torch.sparse_csr_tensor built from a scipy slice carries (the reference's batches)
+    x32 = torch.sparse_csr_tensor(x.crow_indices().int(), x.col_indices().int(), x.values(), size=x.shape).cuda()
+    assert x32.col_indices().dtype == torch.int32
+    base.fill_(7.0)
+    ops.csr_to_dense(x32, out=base[:, :G])
     assert torch.equal(base[:, :G].cpu(), d) and bool((base[:, G:] == 7.0).all())
 
 
