@@ -236,3 +236,11 @@ def test_cond_tables_cover_every_cell_once_in_batch_order(B, C):
     assert (seg[lay["chunk_dst"] + n:lay["chunk_dst"] + CT.max_chunks(B)] == -1).all()
     assert (seg[lay["red_cond"] + len(t["red_cond"]):lay["red_cond"] + CT.max_reductions(B)] == -1).all()
     assert not (seg == 12345).any(), "every word of the padded set is written"
+
+
+def test_graft_entry_build_passes():
+    """`__graft_entry__.build()` is the driver's "does it build" check: compile both libraries (a no-op when they are up
+    to date), load them, verify ABI versions and the target architecture."""
+    import __graft_entry__ as entry
+
+    entry.build()
