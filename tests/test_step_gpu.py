@@ -245,3 +245,49 @@ def test_checkpoint_and_resume_continue_bit_for_bit(name, tmp_path):
     assert got.keys() == want.keys()
     for k in want:
         assert torch.equal(got[k], want[k]), f"{k} differs after resume"
+
+
+@pytest.mark.parametrize("name", ["two_mod_odd", "cond_adv"])
+def test_reloading_a_snapshot_into_a_live_engine_repeats_the_step(name, tmp_path):
+    """Rollback with the captured programs alive: snapshot (module + optimisers), take a step, load the snapshot back into
+    the SAME model and take the step again -- bit for bit the same parameters (state_dicts copy in place into the arenas
+    the graphs point at; optimiser step counts are re-read from the loaded state)."""
+    import copy
+    import random
+
+    import pandas as pd
+
+    case, z = H.load_case(name)
+    T = len(case["schedule"])
+    model = MU.build_mirror(case, "cuda", str(tmp_path), use_engine=True)
+    MU.load_state(model, z, "sd0/")
+    model.train()
+    model.trainer.set_stage("training")
+    model.optimizers()
+
+    def step(t):
+        eid = case["schedule"][t]
+        x, eps, masks, labels = H.step_inputs(z, t)
+        model.kl_annealing_fn.kl_weight = case["kl_weights"][t]
+        model.module.vae.encoder.explicit_eps = eps.cuda()
+        enc = model.module.experts[eid].encoder
+        enc.explicit_masks = {int(k.split(".")[4]): m.cuda() for k, m in masks.items()
+                              if k.startswith(f"experts.{eid}.encoder.fc_layers.")}
+        meta = {c: [f"{c}_{int(i)}" for i in idx] for c, idx in labels.items()}
+        if case.get("cond"):
+            meta.update(H.cond_inputs(case, z, t, eid)[0])
+            random.seed(case["seed"] * 100 + t)
+        model.training_step((x.cuda(), pd.DataFrame(meta if meta else {"dummy": [0] * x.shape[0]}), eid), t)
+
+    for t in range(T):  # every plan built and captured (the last expert of the schedule has run at least once before)
+        step(t)
+    snap = {"model": copy.deepcopy(model.state_dict()), "optim": [copy.deepcopy(o.state_dict()) for o in model.optimizers()]}
+    step(T - 1)
+    want = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.load_state_dict(snap["model"])
+    for o, sd in zip(model.optimizers(), snap["optim"]):
+        o.load_state_dict(sd)
+    step(T - 1)
+    got = model.state_dict()
+    for k in want:
+        assert torch.equal(got[k], want[k]), f"{k} differs after the rollback"
