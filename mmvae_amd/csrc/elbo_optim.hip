@@ -778,7 +778,15 @@ __global__ __launch_bounds__(256) void sum_parts_batch_kernel(const mmvae_sum_jo
             const int r = (int)(i / c4n), c = (int)(i - (int64_t)r * c4n) * 4;
             const float* sp = j.src + (int64_t)r * j.ld_src + c;
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            for (int p = 0; p < j.n_parts; ++p) s += *reinterpret_cast<const f32x4*>(sp + (int64_t)p * j.part_stride);
+            int p = 0;
+            for (; p + 8 <= j.n_parts; p += 8) {  // 8 loads in flight, added in part order (160 row-chunk partials at K x B rows)
+                f32x4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(sp + (int64_t)(p + u) * j.part_stride);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += t[u];
+            }
+            for (; p < j.n_parts; ++p) s += *reinterpret_cast<const f32x4*>(sp + (int64_t)p * j.part_stride);
             f32x4 v = s * j.alpha;
             float* dp = j.dst + (int64_t)r * j.ld_dst + c;
             if (acc) v += *reinterpret_cast<const f32x4*>(dp);
@@ -1126,8 +1134,8 @@ extern "C" int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, f
 
 extern "C" int mmvae_sum_parts_batch(int n_jobs, const mmvae_sum_job* jobs, int64_t max_elems, mmvae_stream_t stream) {
     if (n_jobs <= 0 || n_jobs > 65535 || !jobs || max_elems < 0) return MMVAE_ERR_ARG;
-    // workgroups per job: sized for the largest job (4 groups of 4 elements per thread), 64 when the caller cannot say
-    const int gx = max_elems > 0 ? grid_for((max_elems + 15) / 16, 256, 2048) : 64;
+    // workgroups per job: sized for the largest job, 64 when the caller cannot say
+    const int gx = max_elems > 0 ? grid_for((max_elems + 3) / 4, 256, 2048) : 64;  // one 16-byte group per thread
     MMVAE_LAUNCH(sum_parts_batch_kernel, dim3(gx < 64 ? (gx < 1 ? 1 : gx) : gx, n_jobs), dim3(256), 0, (hipStream_t)stream,
                  jobs);
     MMVAE_LAUNCH_CHECK();

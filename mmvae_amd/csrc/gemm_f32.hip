@@ -1464,9 +1464,27 @@ void plan(int layout, int M, int N, int K, int* tile_id, int* splitk) {
     const int tbig = ceil_div_i(M, tb.bm) * ceil_div_i(N, tb.bn);
     if (tbig >= 192) {
         *tile_id = best;
-        // a chip-filling product whose K is not a multiple of the k-tile (dX of a 30 000-gene decoder over K x B
-        // rows): two slabs -- the whole k-tiles on the pipelined kernel, the K tail on the guarded one (gemm_f32_impl)
-        *splitk = (K % X3_BK != 0 && K >= 8 * X3_BK) ? 2 : 1;
+        // Fewer tiles than the chip's 512 resident slots and a long K (dX of the last decoder layer over K x B sample
+        // rows: 320 tiles, K = 20 000): one round would leave slots idle for its whole length.  Take the split whose
+        // rounds-per-slice is smallest (320 tiles x 3 slices = 1.9 rounds of a third of the work each: -33 %).
+        int s = 1;
+        const int t128b = ceil_div_i(M, 128) * ceil_div_i(N, 128);  // split launches use the square tile
+        if (t128b < 512) {
+            const int ktl = K / X3_BK;
+            double best_cost = 1.0;
+            for (int c = 2; c <= 8; ++c) {
+                if (ktl / c < 16) break;  // keep slices long enough to amortise prologue and epilogue
+                const double cost = (double)ceil_div_i(t128b * c, 512) / c;
+                if (cost < best_cost - 0.05) {
+                    best_cost = cost;
+                    s = c;
+                }
+            }
+        }
+        // a K that is not a multiple of the k-tile (30 000 genes): one more slab for the K tail, so that the others
+        // cover whole k-tiles on the pipelined kernel (gemm_f32_impl, "tail slab")
+        if (K % X3_BK != 0 && K >= 8 * X3_BK) s += 1;
+        *splitk = s;
         return;
     }
     const int kt = ceil_div_i(K, 32);
