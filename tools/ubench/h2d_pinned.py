@@ -1,3 +1,6 @@
+"""Host-to-device copy rate of a 24 MB batch from page-locked and from pageable memory (data feed): on this
+pool the asynchronous copy out of page-locked memory runs on the SDMA path at ~21 GB/s, `HSA_ENABLE_SDMA=0` (shader
+copies) reaches ~52 GB/s at the price of compute units."""
 import time, torch, numpy as np
 n = 24 * 1024 * 1024 // 4
 dev = torch.zeros(n, device="cuda")
