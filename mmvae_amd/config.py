@@ -2,31 +2,28 @@
 
 Mirrors reference `cmmvae/config.py:4-26` (class names, argument names and iteration behaviour are part of the
 YAML schema: configs/model/human_only.yaml:10-27)."""
-from typing import Literal, Optional, Union
+from dataclasses import dataclass, fields
+from typing import Iterator, Optional, Union
+
+Number = Union[int, float]
 
 
+@dataclass
 class GradientClipConfig:
-    """(val, algorithm) pair; iterable so it can be splatted into clip_gradients(optimizer, *cfg)."""
+    """How one optimiser's gradients are clipped.  Iterating yields (val, algorithm), so that the object can be
+    splatted into `clip_gradients(optimizer, *cfg)` the way the reference's training step does."""
 
-    def __init__(self, val: Optional[Union[int, float]] = None,
-                 algorithm: Optional[Literal["norm", "value"]] = None):
-        self.val = val
-        self.algorithm = algorithm
+    val: Optional[Number] = None
+    algorithm: Optional[str] = None  # "norm" | "value"
 
-    def __iter__(self):
-        yield self.val
-        yield self.algorithm
-
-    def __repr__(self):
-        return f"GradientClipConfig(val={self.val!r}, algorithm={self.algorithm!r})"
+    def __iter__(self) -> Iterator:
+        return (getattr(self, f.name) for f in fields(self))
 
 
+@dataclass
 class AutogradConfig:
-    """Per-optimiser-family clipping: adversaries, the shared VAE, the active expert."""
+    """One clipping rule per optimiser family; None = no clipping for that family."""
 
-    def __init__(self, adversarial_gradient_clip: Optional[GradientClipConfig] = None,
-                 vae_gradient_clip: Optional[GradientClipConfig] = None,
-                 expert_gradient_clip: Optional[GradientClipConfig] = None):
-        self.adversarial_gradient_clip = adversarial_gradient_clip
-        self.vae_gradient_clip = vae_gradient_clip
-        self.expert_gradient_clip = expert_gradient_clip
+    adversarial_gradient_clip: Optional[GradientClipConfig] = None  # every adversary's optimiser
+    vae_gradient_clip: Optional[GradientClipConfig] = None          # the shared VAE
+    expert_gradient_clip: Optional[GradientClipConfig] = None       # the expert that is active in the step

@@ -2,40 +2,34 @@
 
 
 class KLAnnealingFn:
-    """Constant KL weight; `step()` is the per-training-step hook subclasses override."""
+    """A KL weight that stays what it was set to; `step()` is the once-per-training-step hook of the schedules."""
 
     def __init__(self, kl_weight: float):
         self._kl_weight = kl_weight
 
-    @property
-    def kl_weight(self):
-        return self._kl_weight
-
-    @kl_weight.setter
-    def kl_weight(self, weight):
-        self._kl_weight = weight
+    kl_weight = property(lambda self: self._kl_weight,
+                         lambda self, value: setattr(self, "_kl_weight", value),
+                         doc="current weight of the KL term (read by the step, settable by the user)")
 
     def step(self) -> None:
-        pass
+        """Constant schedule: nothing to advance."""
 
 
 class LinearKLAnnealingFn(KLAnnealingFn):
-    """min for `warmup_steps` steps, then a linear ramp of slope (max - min) / climax_steps, clamped to [min, max].
-    The step counter starts at -warmup_steps; the weight only changes once the counter is >= 0
-    (annealing_fn.py:34-42)."""
+    """`min_kl_weight` during the first `warmup_steps` calls of `step()`, then a straight ramp that reaches
+    `max_kl_weight` after `climax_steps` more calls and stays there (annealing_fn.py:17-42: a counter that starts at
+    -warmup_steps; the weight is only recomputed once the counter is non-negative)."""
 
     def __init__(self, min_kl_weight: float = 1e-7, max_kl_weight: float = 1e-5, warmup_steps: float = 1e3,
                  climax_steps: float = 1e4):
         super().__init__(min_kl_weight)
-        self._min = min_kl_weight
-        self._max = max_kl_weight
-        self._warmup_steps = warmup_steps
-        self._climax_steps = climax_steps
-        self.m = (max_kl_weight - min_kl_weight) / climax_steps
-        self.b = min_kl_weight
-        self.x = -warmup_steps
+        self.bounds = (min_kl_weight, max_kl_weight)
+        self.slope = (max_kl_weight - min_kl_weight) / climax_steps
+        self.position = -warmup_steps  # steps since the end of the warm-up (negative: still warming up)
 
     def step(self) -> None:
-        self.x += 1
-        if self.x >= 0:
-            self.kl_weight = min(max(self.m * self.x + self.b, self._min), self._max)
+        self.position += 1
+        if self.position < 0:
+            return
+        low, high = self.bounds
+        self.kl_weight = min(max(self.slope * self.position + low, low), high)
