@@ -15,8 +15,10 @@
  *   - Caller owns all buffers, including `workspace`.  Required sizes come from the *_workspace_bytes helpers.
  *   - Return value: MMVAE_OK, or an MMVAE_ERR_* code.  No exceptions cross the ABI.  Shapes are validated on the
  *     host BEFORE anything is launched, so a bad call never reaches the GPU.
- *   - Arithmetic is fp32 end to end (reference: `precision: 32`, configs/trainer/config.yaml:5).  GEMMs use the
- *     exact-f32 MFMA (v_mfma_f32_32x32x2_f32): one rounding per product, f32 accumulate.
+ *   - Arithmetic is fp32 end to end (reference: `precision: 32`, configs/trainer/config.yaml:5): fp32 operands,
+ *     fp32 accumulation, fp32-GEMM accuracy.  Chip-filling GEMMs evaluate every fp32 product as six exact bf16 x bf16
+ *     MFMA products of a three-way bf16 split of both operands (MMVAE_GEMM_PRECISION_BF16X3, the default; dropped
+ *     terms < 2^-24 |ab|); small GEMMs and MMVAE_GEMM_PRECISION_F32 use v_mfma_f32_32x32x2_f32 (an fmaf chain).
  */
 #ifndef MMVAE_HIP_H
 #define MMVAE_HIP_H
@@ -35,7 +37,10 @@ typedef void* mmvae_stream_t; /* hipStream_t */
 #define MMVAE_ERR_LAUNCH 2    /* hipLaunch / hipMemsetAsync reported an error */
 #define MMVAE_ERR_WORKSPACE 3 /* workspace too small */
 
-/* ABI version (bumped on any signature change) and the gfx arch string the code objects were built for. */
+/* ABI version: bumped whenever an entry point is added or a signature changes (mmvae_abi_version() returns the
+ * value the library was built with; bindings compare it with the header they were written against).
+ *   1  round-1 surface (first 20 entry points)      2  end of round 1 (50 entry points)      3+  round 2 */
+#define MMVAE_ABI_VERSION 3
 int mmvae_abi_version(void);
 const char* mmvae_build_arch(void);
 

@@ -46,7 +46,8 @@ class BnParams(C.Structure):
     ]
 
 
-# name -> (restype, argtypes).  Kept in the order of include/mmvae_hip.h; tests/test_abi.py checks that every
+# name -> (restype, argtypes).  Kept in the order of include/mmvae_hip.h; tests/test_host_logic.py
+# (test_abi_header_symbols_are_exported_and_bound) checks that every
 # symbol the header declares is listed here and exported by the .so.
 PROTOTYPES = {
     "mmvae_abi_version": (_i, []),

@@ -826,7 +826,7 @@ inline int grid_for(int64_t n, int per_block, int cap) {
 
 }  // namespace
 
-extern "C" int mmvae_abi_version(void) { return 1; }
+extern "C" int mmvae_abi_version(void) { return MMVAE_ABI_VERSION; }
 extern "C" const char* mmvae_build_arch(void) { return "gfx950"; }
 
 extern "C" int mmvae_reparam_kl_fwd(int B, int Z, int K, const float* mu, const float* a_raw, const float* eps,

@@ -8,8 +8,9 @@ and logged scalar names as the reference.  `training_step` has two executions of
     captured once per expert in a hipGraph and replayed; nothing is traced, nothing is allocated per step, and no
     value is read back to the host unless logging asks for it.
   * module path (any FCBlock configuration, CPU plumbing): torch autograd sequences the same kernels through
-    mmvae_amd.functional.  This is the code below; it follows the reference line by line in behaviour:
-    training_step :138-217, grf :59-101, gradient_reversal_domain_classifier :103-136.
+    mmvae_amd.functional.  This is the code below, written as the sections of the engine's program; behaviour pinned
+    against the reference's training_step :138-217, grf :59-101, gradient_reversal_domain_classifier :103-136 by the
+    golden vectors (tests/test_step_gpu.py, tests/test_mirror_cpu.py).
 """
 from __future__ import annotations
 
@@ -50,52 +51,71 @@ class CMMVAEModel(BaseModel):
         self.optimizer_map = None
 
     # ------------------------------------------------------------------------------------------ adversarial phases
+    # The module path states the step the way DESIGN.md section 2 and the engine's program do: sections
+    # (forward + ELBO) -> (discriminator round: learn on detached features) -> (generator round: same nets behind the
+    # gradient-reversal layer, added to the ELBO) -> backward -> per-optimiser (norm, clip, Adam).  The three public
+    # methods of the reference's surface (grf, gradient_reversal_domain_classifier, training_step) are entry points
+    # into these sections.
+    _ROUNDS = {True: "discriminator", False: "generator"}
+
+    def _adversary_round(self, features, labels: dict, expert_id: str, learn: bool) -> list:
+        """One loss per (feature, adversary) pair: the sum over the adversary's heads of CE(sum) against the cells'
+        class indices.  learn=True feeds detached features (the adversary's own update); learn=False feeds them
+        through GradientReversalFunction(alpha = 1), so the loss pushes the encoder the other way.  Logged as
+        `{round}_{n}/{stage}/{expert}/adversarial_loss/{condition|summed}` (cmmvae_model.py:87-98)."""
+        totals = []
+        for number, (feature, adversary) in enumerate(zip(features, self.module.adversarials), start=1):
+            source = feature.detach() if learn else GradientReversalFunction.apply(feature, 1)
+            code = adversary.encoder(source)
+            per_head = {condition: _ce_sum(adversary.heads[condition](code), classes)
+                        for condition, classes in labels.items()}
+            per_head["summed"] = torch.stack(tuple(per_head.values())).sum()
+            self.auto_log(per_head, tags=[f"{self._ROUNDS[learn]}_{number}", self.stage_name, expert_id, RK.ADV_LOSS],
+                          key_pos="last")
+            totals.append(per_head["summed"])
+        return totals
+
     def grf(self, hidden_representations, labels: dict, expert_id: str, detach: bool = False):
-        """Per adversary: CE(sum) of every head on (detached | gradient-reversed) hidden features, summed (:59-101)."""
-        adv_losses = []
-        for i, (hidden_rep, adversary) in enumerate(zip(hidden_representations, self.module.adversarials), start=1):
-            if detach:
-                hidden_rep = hidden_rep.detach()
-                loss_tag = f"discriminator_{i}"
-            else:
-                hidden_rep = GradientReversalFunction.apply(hidden_rep, 1)
-                loss_tag = f"generator_{i}"
-            encoded = adversary.encoder(hidden_rep)
-            head_losses = []
-            for condition, label in labels.items():
-                disc_loss = _ce_sum(adversary.heads[condition](encoded), label)
-                head_losses.append(disc_loss)
-                self.auto_log({condition: disc_loss}, tags=[loss_tag, self.stage_name, expert_id, RK.ADV_LOSS],
-                              key_pos="last")
-            summed = torch.sum(torch.stack(head_losses))
-            self.auto_log({"summed": summed}, tags=[loss_tag, self.stage_name, expert_id, RK.ADV_LOSS], key_pos="last")
-            adv_losses.append(summed)
-        return adv_losses
+        """Reference entry point (cmmvae_model.py:59-101): the round's per-adversary losses."""
+        return self._adversary_round(hidden_representations, labels, expert_id, learn=detach)
 
     @staticmethod
     def adversarial_labels(metadata: pd.DataFrame, device) -> dict:
-        """metadata columns -> int64 class-index tensors via the class-level Adversarial.labels maps (:111-115)."""
-        return {cond: torch.tensor([mp[v] for v in metadata[cond].values], dtype=torch.int64, device=device)
-                for cond, mp in Adversarial.labels.items()}
+        """Metadata columns -> int64 class-index tensors through the class-level Adversarial.labels tables
+        (cmmvae_model.py:111-115), one vectorised lookup per condition."""
+        out = {}
+        for condition, table in Adversarial.labels.items():
+            classes = metadata[condition].map(table)
+            if classes.isna().any():
+                raise KeyError(f"{condition}: {metadata[condition][classes.isna()].iloc[0]!r} is not a known class")
+            out[condition] = torch.as_tensor(classes.to_numpy(dtype="int64"), device=device)
+        return out
+
+    def _norm_clip(self, name: str, optimizer, rule) -> None:
+        """Log the optimiser's gradient norm as grad_norms/{name}, then apply its clipping rule (HipAdam folds both into
+        its fused update)."""
+        self.log_gradient_norms({name: optimizer}, tag_prefix="grad_norms")
+        if rule:
+            self.clip_gradients(optimizer, *rule)
 
     def gradient_reversal_domain_classifier(self, hidden_representations, metadata: pd.DataFrame, expert_id: str,
                                             adversarial_optimizers: dict):
+        """Discriminator round (each adversary: backward, norm, clip, Adam, gradients cleared) followed by the generator
+        round on the just-updated adversaries; returns the generator losses (cmmvae_model.py:103-136)."""
         assert len(self.module.adversarials) > 0
         labels = self.adversarial_labels(metadata, hidden_representations[0].device)
-        # D phase: every adversary learns on detached features, one backward/clip/step each (:118-131)
-        adv_losses = self.grf(hidden_representations, labels, expert_id, detach=True)
-        for i, (adv_loss, adv_optimizer) in enumerate(zip(adv_losses, adversarial_optimizers.values()), start=1):
-            self.manual_backward(adv_loss)
-            self.log_gradient_norms({f"discriminator_{i}": adv_optimizer}, tag_prefix="grad_norms")
-            if self.autograd_config.adversarial_gradient_clip:
-                self.clip_gradients(adv_optimizer, *self.autograd_config.adversarial_gradient_clip)
-            adv_optimizer.step()
-            adv_optimizer.zero_grad()
-        # G phase: same nets (just updated) behind a gradient-reversal layer (:134-136)
-        return self.grf(hidden_representations, labels, expert_id, detach=False)
+        learned = self._adversary_round(hidden_representations, labels, expert_id, learn=True)
+        for number, (loss, optimizer) in enumerate(zip(learned, adversarial_optimizers.values()), start=1):
+            self.manual_backward(loss)
+            self._norm_clip(f"discriminator_{number}", optimizer, self.autograd_config.adversarial_gradient_clip)
+            optimizer.step()
+            optimizer.zero_grad()
+        return self._adversary_round(hidden_representations, labels, expert_id, learn=False)
 
     # ------------------------------------------------------------------------------------------------ step methods
     def training_step(self, batch, batch_idx: int) -> None:
+        """One training step on one expert's batch (cmmvae_model.py:138-217).  Device batches run the captured engine
+        program; what follows is the autograd statement of the same program."""
         x, metadata, expert_id = batch
         metadata["species"] = expert_id
         engine = self._get_engine(x)
@@ -104,46 +124,37 @@ class CMMVAEModel(BaseModel):
         if getattr(self.module.vae.encoder, "elbo_mode", "analytic") != "analytic":
             raise NotImplementedError("elbo_mode='iwae' (the opt-in full-IWAE objective) runs in the captured engine only")
 
-        optims = self.get_optimizers()
-        expert_optimizer = optims["experts"][expert_id]
-        vae_optimizer = optims["vae"]
-        adversarial_optimizers = optims.get("adversarials")
-        vae_optimizer.zero_grad()
-        expert_optimizer.zero_grad()
-        if adversarial_optimizers:
-            for optim in adversarial_optimizers.values():
-                optim.zero_grad()
+        live = self.get_optimizers()
+        adversary_optims = live.get("adversarials") or {}
+        stepped = {"vae": (live["vae"], self.autograd_config.vae_gradient_clip),
+                   f"expert_{expert_id}": (live["experts"][expert_id], self.autograd_config.expert_gradient_clip)}
+        for optimizer in [o for o, _ in stepped.values()] + list(adversary_optims.values()):
+            optimizer.zero_grad()
 
-        qz, pz, z, xhats, hidden_representations = self.module(x=x, metadata=metadata, expert_id=expert_id)
-        if x.layout == torch.sparse_csr:
-            x = backend.to_dense(x)
-        main_loss_dict = self.module.vae.elbo(qz, pz, x, xhats[expert_id], self.kl_annealing_fn.kl_weight)
-        main_loss_dict["Mean"], main_loss_dict["Variance"] = self._posterior_stats(qz)
-        total_loss = main_loss_dict[RK.LOSS]
-
-        adv_losses = None
+        # forward + ELBO
+        qz, pz, z, xhats, features = self.module(x=x, metadata=metadata, expert_id=expert_id)
+        dense_x = backend.to_dense(x) if x.layout == torch.sparse_csr else x
+        terms = self.module.vae.elbo(qz, pz, dense_x, xhats[expert_id], self.kl_annealing_fn.kl_weight)
+        terms["Mean"], terms["Variance"] = self._posterior_stats(qz)
+        objective = terms[RK.LOSS]
+        # adversarial rounds: the generator losses join the objective with weight adv_weight
         if len(self.module.adversarials) > 0:
-            adv_losses = self.gradient_reversal_domain_classifier(hidden_representations, metadata, expert_id,
-                                                                  adversarial_optimizers)
-        if adv_losses:
-            for adv_loss in adv_losses:
-                total_loss = total_loss + adv_loss * self.adv_weight
+            for loss in self.gradient_reversal_domain_classifier(features, metadata, expert_id, adversary_optims):
+                objective = objective + self.adv_weight * loss
+        terms[RK.LOSS] = objective
 
-        self.manual_backward(total_loss)
-        main_loss_dict[RK.LOSS] = total_loss
-        self.log_gradient_norms({"vae": vae_optimizer, f"expert_{expert_id}": expert_optimizer},
-                                tag_prefix="grad_norms")
-        if adversarial_optimizers:
-            for key, optim in adversarial_optimizers.items():
-                self.log_gradient_norms({f"generator_{key}": optim}, tag_prefix="grad_norms")
-        if self.autograd_config.vae_gradient_clip:
-            self.clip_gradients(vae_optimizer, *self.autograd_config.vae_gradient_clip)
-        if self.autograd_config.expert_gradient_clip:
-            self.clip_gradients(expert_optimizer, *self.autograd_config.expert_gradient_clip)
-        vae_optimizer.step()
-        expert_optimizer.step()
+        self.manual_backward(objective)
+        for name, (optimizer, rule) in stepped.items():  # norms of both are logged before either is clipped
+            self.log_gradient_norms({name: optimizer}, tag_prefix="grad_norms")
+        for key, optimizer in adversary_optims.items():  # gradients the main backward left on the adversaries: logged,
+            self.log_gradient_norms({f"generator_{key}": optimizer}, tag_prefix="grad_norms")  # never stepped
+        for optimizer, rule in stepped.values():
+            if rule:
+                self.clip_gradients(optimizer, *rule)
+        for optimizer, _ in stepped.values():
+            optimizer.step()
         self.kl_annealing_fn.step()
-        self.auto_log(main_loss_dict, tags=[self.stage_name, expert_id])
+        self.auto_log(terms, tags=[self.stage_name, expert_id])
 
     @staticmethod
     def _posterior_stats(qz):
@@ -196,17 +207,13 @@ class CMMVAEModel(BaseModel):
 
     # -------------------------------------------------------------------------------------------------- optimisers
     def get_optimizers(self, zero_all: bool = False):
-        optimizers = self.optimizers()
+        """The optimisers in the shape of `optimizer_map`: {"experts": {id: opt}, "vae": opt, "adversarials": {n: opt}}
+        (cmmvae_model.py:267-297)."""
+        flat = self.optimizers()
         if zero_all:
-            for optim in optimizers:
-                optim.zero_grad()
-
-        def resolve(mapping):
-            if isinstance(mapping, dict):
-                return {k: resolve(v) for k, v in mapping.items()}
-            return optimizers[mapping]
-
-        return resolve(self.optimizer_map)
+            for optimizer in flat:
+                optimizer.zero_grad()
+        return _map_leaves(self.optimizer_map, lambda index: flat[index])
 
     def configure_optimizers(self, optim_cls="Adam"):
         """One Adam(lr=5e-3, weight_decay=1e-6) per expert, one for the VAE, one per adversary, as a flat list plus
@@ -251,15 +258,18 @@ class CMMVAEModel(BaseModel):
         return self._engine or None
 
 
+def _map_leaves(tree, fn):
+    """Same-shaped copy of a nested dict with fn applied to every leaf."""
+    return {k: _map_leaves(v, fn) if isinstance(v, dict) else fn(v) for k, v in tree.items()}
+
+
 def convert_to_flat_list_and_map(d: dict, flat_list: Optional[list] = None) -> dict:
-    """Nested dict of optimisers -> same-shaped dict of indices into `flat_list` (appended in traversal order)."""
-    if flat_list is None:
-        flat_list = []
-    mapping = {}
-    for key, value in d.items():
-        if isinstance(value, dict):
-            mapping[key] = convert_to_flat_list_and_map(value, flat_list)
-        else:
-            flat_list.append(value)
-            mapping[key] = len(flat_list) - 1
-    return mapping
+    """Nested dict of optimisers -> same-shaped dict of positions in `flat_list`, which receives the optimisers in
+    traversal order (the list Lightning's `configure_optimizers` wants; cmmvae_model.py:326-351)."""
+    flat_list = [] if flat_list is None else flat_list
+
+    def place(optimizer):
+        flat_list.append(optimizer)
+        return len(flat_list) - 1
+
+    return _map_leaves(d, place)

@@ -1,6 +1,6 @@
 """Per-kernel parity tests: every C-ABI entry point of libmmvae_hip.so against a CPU computation of the same math
 (fp64 matmuls / torch autograd on CPU).  These call THROUGH the C-ABI (mmvae_amd.ops -> ctypes -> .so).
-Tolerances: GEMM outputs rel-L2 <= 2e-6 vs fp64 (exact-f32 MFMA, one rounding per product); elementwise 1e-5."""
+Tolerances: GEMM outputs rel-L2 <= 2e-6 vs fp64 (bf16x3 and exact-f32 MFMA paths alike); elementwise 1e-5."""
 import numpy as np
 import pytest
 import torch
@@ -16,7 +16,7 @@ def ops():
     from mmvae_amd import ops as _ops, _lib
 
     lib = _lib.load()
-    assert lib.mmvae_abi_version() == 1
+    assert lib.mmvae_abi_version() >= 3
     return _ops
 
 
