@@ -161,9 +161,11 @@ class SpeciesChunks:
     index list, the chunk itself is never permuted or sliced in Python -- into a ring of staging slots, `workers`
     batches ahead of the consumer and off the interpreter lock.
 
-    `rank` / `world`: data-parallel sharding -- every rank walks the same (seeded) chunk order and row permutations
-    and keeps batches rank, rank + world, ... of each chunk, so that all ranks see the same number of batches of the
-    same modality schedule (the reference has no distributed sampler)."""
+    `rank` / `world`: data-parallel sharding -- every rank walks the same (seeded) chunk order and row permutations;
+    the epoch's kept batches (across chunks, dropped partial batches not counted) are dealt out in rounds of `world`,
+    rank r takes the r-th batch of every COMPLETE round and the incomplete last round is dropped, so every rank yields
+    exactly floor(n_batches / world) batches of the same modality schedule -- a rank that ran short would leave the
+    others blocked in the gradient all-reduce (the reference has no distributed sampler)."""
 
     def __init__(self, directory_path: str, npz_masks, metadata_masks, batch_size: int, name: str,
                  allow_partials: bool = False, shuffle: bool = True, return_dense: bool = False, seed: int = 0,
@@ -299,14 +301,16 @@ class SpeciesChunks:
         inflight: deque = deque()
 
         def jobs():
+            dealt = []  # the current round of `world` consecutive kept batches of the epoch
             for matrix, metadata, order in chunks:
                 n = matrix.shape[0]
-                for b, i in enumerate(range(0, n, self.batch_size)):
+                for i in range(0, n, self.batch_size):
                     if i + self.batch_size > n and not self.allow_partials:
                         continue
-                    if b % self.world != self.rank:
-                        continue
-                    yield matrix, metadata, order[i:i + self.batch_size]
+                    dealt.append((matrix, metadata, order[i:i + self.batch_size]))
+                    if len(dealt) == self.world:
+                        yield dealt[self.rank]
+                        dealt = []
 
         with ThreadPoolExecutor(max_workers=self.workers) as pool:
             def finish():

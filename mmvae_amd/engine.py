@@ -79,7 +79,8 @@ class _PinnedRing:
 class _LayerRef:
     """One FCBlock layer bound to its parameter / gradient-arena tensors."""
 
-    def __init__(self, seq: nn.Sequential, grad_of, return_hidden: bool):
+    def __init__(self, seq: nn.Sequential, grad_of, return_hidden: bool, block=None, index: int = 0):
+        self.block, self.index = block, index  # the FCBlock it belongs to: explicit keep masks are looked up there
         lin = seq.lin
         self.n_in, self.n_out = lin.in_features, lin.out_features
         self.W, self.b = lin.weight, lin.bias
@@ -162,7 +163,6 @@ class StepEngine:
         self._ptr_seen: Dict[tuple, int] = {}
         self.klw_dev = torch.ones(1, dtype=torch.float32, device=self.device)
         self._klw_host = None
-        self.world = mdist.world_size()
         # weight-gradient GEMMs run on a side stream inside the captured graph (fork/join edges)
         self.batch_finish = os.environ.get("MMVAE_BATCH_FINISH", "1") != "0"
         self.batch_gemms = os.environ.get("MMVAE_BATCH_GEMMS", "1") != "0"
@@ -172,20 +172,10 @@ class StepEngine:
         self.side_stream = torch.cuda.Stream(device=self.device) if side_stream else None
         # only the small (latency-bound) weight-gradient GEMMs go aside; chip-filling ones stay in order on the main stream
         self.side_max_elems = int(os.environ.get("MMVAE_SIDE_MAX_ELEMS", 2 * 1024 * 1024))
-        # Overlapped data parallelism (default whenever gradients are exchanged).  The active expert's parameters are
-        # not read again until that expert's NEXT step (modalities alternate), so its gradient all-reduce (~170 MB
-        # over xGMI at C2) and the clip + Adam update that needs the reduced gradients run on a communication stream,
-        # concurrently with the next step's compute for another modality; the next step of the SAME expert waits for
-        # the event recorded behind that update.  The shared-VAE gradients (a few MB, needed every step) are final
-        # before the expert-encoder backward starts: their all-reduce is issued there, on a second stream and a second
-        # communicator, and hides behind the remaining backward GEMMs.  MMVAE_DP_OVERLAP=0 restores the in-order
-        # exchange; =1 forces the overlapped program on one rank (measured slower at N = 1: Adam is HBM-bound).
-        if defer_expert_adam is None:
-            ov = os.environ.get("MMVAE_DP_OVERLAP", os.environ.get("MMVAE_DEFER_EXPERT_ADAM", ""))
-            defer_expert_adam = (ov != "0") if ov != "" else mdist.collectives_active()
-        self.overlap = bool(defer_expert_adam)
-        self.comm_stream = torch.cuda.Stream(device=self.device) if self.overlap else None
-        self.small_stream = torch.cuda.Stream(device=self.device) if self.overlap else None
+        self._defer_arg = defer_expert_adam
+        self.comm_stream = self.small_stream = None
+        self._configure_parallel()
+        self._sig = self._signature()
         self._pending: Dict[str, torch.cuda.Event] = {}
         # Lazy expert update (MMVAE_DP_LAZY_ADAM=1, off by default): only the expert's all-reduce runs beside the next
         # step; its clip + Adam (HBM-bound, 1.15 GB of traffic at C2) is run on the MAIN stream at the start of that
@@ -195,6 +185,47 @@ class StepEngine:
         # gradient norm and parameters are final after a device synchronisation rather than after engine.flush().
         self.lazy_adam = os.environ.get("MMVAE_DP_LAZY_ADAM", "0") != "0"
         self._lazy: Dict[str, tuple] = {}
+
+    def _configure_parallel(self) -> None:
+        """Overlapped data parallelism (default whenever gradients are exchanged).  The active expert's parameters are
+        not read again until that expert's NEXT step (modalities alternate), so its gradient all-reduce (~170 MB over
+        xGMI at C2) and the clip + Adam update that needs the reduced gradients run on a communication stream,
+        concurrently with the next step's compute for another modality; the next step of the SAME expert waits for the
+        event recorded behind that update.  The shared-VAE gradients (a few MB, needed every step) are final before the
+        expert-encoder backward starts: their all-reduce is issued there, on a second stream and a second communicator,
+        and hides behind the remaining backward GEMMs.  MMVAE_DP_OVERLAP=0 restores the in-order exchange; =1 forces
+        the overlapped program on one rank (measured slower at N = 1: Adam is HBM-bound)."""
+        self.world = mdist.world_size()
+        defer = self._defer_arg
+        if defer is None:
+            ov = os.environ.get("MMVAE_DP_OVERLAP", os.environ.get("MMVAE_DEFER_EXPERT_ADAM", ""))
+            defer = (ov != "0") if ov != "" else mdist.collectives_active()
+        self.overlap = bool(defer)
+        if self.overlap and self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(device=self.device)
+            self.small_stream = torch.cuda.Stream(device=self.device)
+
+    def _signature(self) -> tuple:
+        """Everything a captured training program freezes at build time: optimiser hyper-parameters, clip values, the
+        adversarial weight, world size / gradient exchange.  Compared on every training step; a change (dist.attach()
+        after the first step, a new learning rate through param_groups or HipAdam.load_state_dict, an edited
+        autograd_config) drops the plans and their graphs, which are then rebuilt with the current values."""
+        ac = self.model.autograd_config
+        clip = lambda c: float(c.val) if (c and c.val) else 0.0  # noqa: E731
+        per_opt = tuple((g["lr"], g["eps"], g["weight_decay"], tuple(g["betas"]), o.reducer is not None, o.grad_scale)
+                        for o in self.model.optimizers() for g in o.param_groups[:1])
+        return (per_opt, clip(ac.vae_gradient_clip), clip(ac.expert_gradient_clip), clip(ac.adversarial_gradient_clip),
+                float(self.model.adv_weight), mdist.world_size(), mdist.collectives_active())
+
+    def _check_signature(self) -> None:
+        sig = self._signature()
+        if sig != self._sig:
+            self.flush()
+            torch.cuda.current_stream().synchronize()
+            self._plans = {k: p for k, p in self._plans.items() if not str(k[0]).startswith("train")}
+            self._ptr_seen.clear()
+            self._configure_parallel()
+            self._sig = sig
 
     # ------------------------------------------------------------------------------------------------ buffers
     def buf(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
@@ -340,6 +371,7 @@ class StepEngine:
     # --------------------------------------------------------------------------------------------------- step
     def training_step(self, x: torch.Tensor, metadata, expert_id: str) -> None:
         model = self.model
+        self._check_signature()
         x = self._dense_f32(x)
         enc_mod = model.module.vae.encoder
         expert = model.module.experts[expert_id]
@@ -389,7 +421,7 @@ class _Plan:
         exp = m.experts[eid]
 
         def refs(block: FCBlock):
-            return [_LayerRef(seq, g, block.config.return_hidden[i]) for i, seq in enumerate(block.fc_layers)]
+            return [_LayerRef(seq, g, block.config.return_hidden[i], block, i) for i, seq in enumerate(block.fc_layers)]
 
         self.enc_layers = refs(exp.encoder) + refs(m.vae.encoder.fc)
         self.n_expert_enc = len(exp.encoder.fc_layers)
@@ -416,6 +448,7 @@ class _Plan:
         self._cur: List = []
         self._sq_used: Dict[int, int] = {}    # per optimiser: norm-partial slots taken by fused GEMM epilogues
         self._sq_cover: Dict[int, list] = {}  # per optimiser: (offset, length) of the arena ranges they cover
+        self._mask_layers: List = []   # (layer, Philox stream id) of every dropout keep mask of the program
         self._gemm_jobs: List = []     # small weight-gradient GEMMs queued for the next mmvae_gemm_batch_f32 launch
         self._sum_jobs: List = []      # reductions queued for the next mmvae_sum_parts_batch launch
         self._sum_keep: List = []
@@ -631,14 +664,19 @@ class _Plan:
         self._cur.append(call)
 
     # ---- one FCBlock layer forward: cur [rows, n_in] -> l.d
-    def fwd_layer(self, tag: str, l: _LayerRef, cur: torch.Tensor, ld_cur: int, rows: int, training: bool = True):
+    def fwd_layer(self, tag: str, l: _LayerRef, cur: torch.Tensor, ld_cur: int, rows: int, training: bool = True,
+                  mask_tag: Optional[str] = None, mask_stream: Optional[int] = None):
+        """`mask_tag`: name of the keep-mask buffer when it must differ from the layer's other buffers (the two phases
+        of an adversary share activations but draw fresh masks); `mask_stream`: its Philox stream id."""
         eng = self.eng
         l.inp, l.ld_inp, l.rows = cur, ld_cur, rows
         l.d = eng.buf(f"{tag}.d", (rows, l.n_out))
         l.z = eng.buf(f"{tag}.z", (rows, l.n_out)) if l.bn is not None else None
         l.mean = eng.buf(f"{tag}.mean", (l.n_out,)) if l.bn is not None else None
         l.invstd = eng.buf(f"{tag}.invstd", (l.n_out,)) if l.bn is not None else None
-        l.mask = eng.buf(f"{tag}.mask", (rows, l.n_out), torch.uint8) if (l.p > 0 and training) else None
+        l.mask = eng.buf(f"{mask_tag or tag}.mask", (rows, l.n_out), torch.uint8) if (l.p > 0 and training) else None
+        if l.mask is not None:
+            self._mask_layers.append((l, mask_stream if mask_stream is not None else len(self._mask_layers)))
         l.a = eng.buf(f"{tag}.a", (rows, l.n_out)) if (l.p > 0 and l.return_hidden and training) else None
         l.dz = eng.buf(f"{tag}.dz", (rows, l.n_out)) if training else None
         p_drop = l.p if training else 0.0
@@ -805,7 +843,7 @@ class _Plan:
         cur, ld = x, ldx
         for i, l in enumerate(self.enc_layers):
             cur = self.fwd_layer(f"{self.eid}.enc{i}" if i < self.n_expert_enc else f"vae.enc{i}", l, cur, ld, B,
-                                 training=train)
+                                 training=train, mask_stream=i)
             ld = l.n_out
         q, HV = cur, self.enc_layers[-1].n_out
         # ---- heads + reparameterisation
@@ -829,7 +867,8 @@ class _Plan:
         if self.cond is not None:  # CLVAE.after_reparameterize: the sample passes through the conditional layers
             cur, ld = self.cond.emit_forward(self.z)
         for i, l in enumerate(self.dec_layers[:-1]):
-            cur = self.fwd_layer(f"{self.eid}.dec{i}.K{K}", l, cur, ld, R, training=train)
+            cur = self.fwd_layer(f"{self.eid}.dec{i}.K{K}", l, cur, ld, R, training=train,
+                                 mask_stream=len(self.enc_layers) + i)
             ld = l.n_out
         last = self.dec_layers[-1]
         fused_last = last.relu and last.bn is None and last.p == 0
@@ -951,10 +990,9 @@ class _Plan:
         if not self.explicit:
             n_max = K * B * Z
             fills = []  # every keep-mask and the rsample noise of the step: one launch (same numbers as one fill each)
-            for i, l in enumerate(self.enc_layers + self.dec_layers[:-1]):
-                if l.mask is not None:
-                    n_max = max(n_max, l.mask.numel())
-                    fills.append(_lib.PhiloxJob(_p(l.mask), l.mask.numel(), rng.STREAM_DROPOUT + i, l.p, 0))
+            for l, stream in self._mask_layers:  # expert / VAE layers and both phases of every adversary
+                n_max = max(n_max, l.mask.numel())
+                fills.append(_lib.PhiloxJob(_p(l.mask), l.mask.numel(), rng.STREAM_DROPOUT + stream, l.p, 0))
             fills.append(_lib.PhiloxJob(_p(self.eps), K * B * Z, rng.STREAM_NORMAL, 0.0, 1))
             if eng.merge_launches:
                 arr = (_lib.PhiloxJob * len(fills))(*fills)
@@ -1013,7 +1051,11 @@ class _Plan:
         self.n_adv = min(len(hidden), len(self.advs))
         for i, (h, adv) in enumerate(zip(hidden, self.advs), start=1):
             g = eng.grad_of
-            layers = [_LayerRef(seq, g, False) for seq in adv.encoder.fc_layers]
+            # one set of layer records per phase: the phases share activations and gradient buffers (same tags) but each
+            # draws its own dropout keep masks, like two forward calls of the reference's nn.Dropout
+            phase_layers = {ph: [_LayerRef(seq, g, False, adv.encoder, j) for j, seq in enumerate(adv.encoder.fc_layers)]
+                            for ph in ("discriminator", "generator")}
+            layers = phase_layers["discriminator"]
             n_e = layers[-1].n_out
             heads = {c: adv.heads[c].fc_layers[0].lin for c in self.conditions}
             logits = {c: eng.buf(f"adv{i}.logits.{c}", (B, heads[c].out_features)) for c in self.conditions}
@@ -1043,9 +1085,11 @@ class _Plan:
                                  logits=eng.buf(f"adv{i}.logits_all", (B, Ct)), dlogits=eng.buf(f"adv{i}.dlogits_all", (B, Ct)))
             for phase in ("discriminator", "generator"):
                 gen = phase == "generator"
+                layers = phase_layers[phase]
                 cur, ld = h, layers[0].n_in
                 for j, l in enumerate(layers):
-                    cur = self.fwd_layer(f"adv{i}.enc{j}", l, cur, ld, B)
+                    cur = self.fwd_layer(f"adv{i}.enc{j}", l, cur, ld, B, mask_tag=f"adv{i}.{phase}.enc{j}",
+                                         mask_stream=1000 + 64 * i + 32 * int(gen) + j)
                     ld = l.n_out
                 e = cur
                 gscale = self.adv_weight if gen else 1.0
@@ -1114,31 +1158,36 @@ class _Plan:
 
     # ------------------------------------------------------------------------------------------------ execution
     def load_explicit_noise(self, enc_mod, expert):
+        """Parity mode: eps and every dropout keep mask of the program come from the caller -- `explicit_eps` of the
+        encoder, `explicit_masks[layer index]` of each FCBlock with dropout (expert encoder, VAE blocks, adversary
+        encoders: one mask per layer, used by both adversarial phases, like the module path)."""
         eps = enc_mod.explicit_eps
         if eps is not None:
             self.eps.copy_(eps.reshape(self.eps.shape))
-        masks = expert.encoder.explicit_masks or {}
-        for i, l in enumerate(self.enc_layers[: self.n_expert_enc]):
-            if l.mask is not None:
-                if i not in masks:
-                    raise KeyError(f"explicit noise mode: no keep mask for encoder layer {i}")
-                l.mask.copy_(masks[i])
+        for l, _ in self._mask_layers:
+            masks = (l.block.explicit_masks or {}) if l.block is not None else {}
+            if l.index not in masks:
+                raise KeyError(f"explicit noise mode: no keep mask for layer {l.index} of a {l.n_in}->{l.n_out} block "
+                               "with dropout (set explicit_masks on that FCBlock)")
+            l.mask.copy_(masks[l.index])
 
     def load_labels(self, metadata):
-        cache = metadata.attrs.get("_mmvae_labels") if hasattr(metadata, "attrs") else None
-        if cache is None:
-            cache = {c: torch.tensor([Adversarial.labels[c][v] for v in metadata[c].values], dtype=torch.int64)
-                     for c in self.conditions}
-            try:
-                metadata.attrs["_mmvae_labels"] = cache
-            except Exception:  # noqa: BLE001
-                pass
+        """The step's class indices: metadata columns -> int64 through the class-level Adversarial.labels tables
+        (cmmvae_model.py:111-115), recomputed on every step like the reference does (nothing is cached on the DataFrame:
+        pandas copies `attrs` into frames derived from it, and a column may be edited in place), written into a
+        page-locked slot and uploaded with one copy."""
+        import numpy as np
+
+        n = len(metadata)
+        if n != self.B:
+            raise ValueError(f"engine: metadata has {n} rows, the batch has {self.B}")
         if getattr(self, "_label_ring", None) is None:
             self._label_ring = _PinnedRing(len(self.conditions) * self.B, torch.int64)
             self._labels_all = self.eng.buf("labels.all", (len(self.conditions), self.B), torch.int64)
         slot = self._label_ring.take()
         for i, c in enumerate(self.conditions):
-            slot[i * self.B:(i + 1) * self.B] = cache[c].numpy()
+            table = Adversarial.labels[c]
+            slot[i * n:(i + 1) * n] = np.fromiter((table[v] for v in metadata[c].values), dtype=np.int64, count=n)
         self._label_ring.upload(self._labels_all.view(-1))
 
     def _exchange(self, marker, tail):

@@ -95,6 +95,49 @@ class LayerNormFn(torch.autograd.Function):
         return ops.layernorm_bwd(gy.contiguous(), y, invstd), None
 
 
+class LayerTailFn(torch.autograd.Function):
+    """[ReLU] -> [Dropout] as a pass of its own (the tail of an FCBlock layer whose LayerNorm separates it from the
+    Linear's column kernel, components.py:281-288).  Returns (d, a): output and pre-dropout activation."""
+
+    @staticmethod
+    def forward(ctx, x, relu, keep_mask, dropout_p):
+        use_mask = keep_mask is not None and dropout_p > 0
+        f = ops.fc_epilogue_fwd(x.contiguous(), None, relu=relu, keep_mask=keep_mask if use_mask else None,
+                                dropout_p=dropout_p if use_mask else 0.0)
+        d, a = f["d"], f["a"]
+        ctx.relu, ctx.p, ctx.use_mask = relu, dropout_p, use_mask
+        ctx.save_for_backward(a if relu else None, keep_mask if use_mask else None)
+        if a is d:
+            return d
+        return d, a
+
+    @staticmethod
+    def backward(ctx, gd, ga=None):
+        a, mask = ctx.saved_tensors
+        gd = gd.contiguous() if gd is not None else None
+        ga = ga.contiguous() if ga is not None else None
+        if gd is None and ga is None:
+            return None, None, None, None
+        addend, mask_arg, p = None, None, 0.0
+        if ctx.use_mask and gd is not None and ga is not None:  # the pre-dropout gradient bypasses the mask
+            gd, _, _, _ = ops.fc_epilogue_bwd(gd, keep_mask=mask, dropout_p=ctx.p, want_dbias=False)
+            addend = ga
+        elif gd is None:
+            gd = ga
+        else:
+            addend = ga
+            if ctx.use_mask:
+                mask_arg, p = mask, ctx.p
+        dx, _, _, _ = ops.fc_epilogue_bwd(gd, addend=addend, keep_mask=mask_arg, dropout_p=p, relu=ctx.relu,
+                                          a=a if ctx.relu else None, want_dbias=False)
+        return dx, None, None, None
+
+
+def layer_tail(x, *, relu: bool, keep_mask=None, dropout_p: float = 0.0):
+    out = LayerTailFn.apply(x, relu, keep_mask, dropout_p)
+    return out if isinstance(out, tuple) else (out, out)
+
+
 class CondLinearFn(torch.autograd.Function):
     """Per-cell conditional Linear, y[b] = W[c_b] x[b] + bias[c_b] (ConditionalLayer.forward, components.py:365-413,
     for single-Linear condition blocks), on the grouped HIP kernels.  The thousands of condition blocks are not autograd

@@ -184,14 +184,25 @@ class FCBlock(nn.Module):
                            training=self.training if bn is not None else True, relu=fuse_act, keep_mask=mask,
                            dropout_p=p)
         if has_ln:
+            # Linear -> [BN] -> LayerNorm -> [ReLU] -> [Dropout] (components.py:279-288; configs/model/configV3.yaml:25-36):
+            # the row normalisation sits between the column kernel and the activation, so ReLU and dropout run as one
+            # more pass of the layer-tail kernels behind it
             d = HF.LayerNormFn.apply(d, layer.ln.eps)
             a = d
+            tail_mask, tail_p = None, 0.0
+            if dr is not None and self.training and (af is None or relu):
+                tail_p = dr.p
+                if self.explicit_masks is not None and i in self.explicit_masks:
+                    tail_mask = self.explicit_masks[i]
+                else:
+                    tail_mask = _draw_keep_mask(d.shape, dr.p, d.device)
+            if relu or tail_mask is not None:
+                d, a = HF.layer_tail(d, relu=relu, keep_mask=tail_mask, dropout_p=tail_p)
+            if af is None or relu:
+                return d, a
         if af is not None and not fuse_act:
             # activations other than ReLU (Softmax / Sigmoid heads of stale configs) are outside the HIP hot path
-            if relu:
-                d = _relu_hip(d)
-            else:
-                d = af(d)
+            d = af(d)
             a = d
         if dr is not None and not fuse_drop:
             if self.training:
@@ -199,7 +210,7 @@ class FCBlock(nn.Module):
                     m = self.explicit_masks[i]
                 else:
                     m = _draw_keep_mask(d.shape, dr.p, d.device)
-                d = _dropout_hip(d, m, dr.p)
+                d, _ = HF.layer_tail(d, relu=False, keep_mask=m, dropout_p=dr.p)
         return d, a
 
     def forward(self, x: torch.Tensor):
@@ -232,33 +243,6 @@ class FCBlock(nn.Module):
                 if name == "af" and self.config.return_hidden[i]:
                     hidden.append(x)
         return x if self.can_bypass else (x, hidden)
-
-
-def _relu_hip(x):
-    raise NotImplementedError("ReLU after LayerNorm is not on the HIP path yet")
-
-
-class _DropoutFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, mask, p):
-        from ... import ops
-
-        ctx.p = p
-        ctx.save_for_backward(mask)
-        d, _, _, _ = ops.fc_epilogue_bwd(x.contiguous(), keep_mask=mask, dropout_p=p, want_dbias=False)
-        return d
-
-    @staticmethod
-    def backward(ctx, g):
-        from ... import ops
-
-        (mask,) = ctx.saved_tensors
-        d, _, _, _ = ops.fc_epilogue_bwd(g.contiguous(), keep_mask=mask, dropout_p=ctx.p, want_dbias=False)
-        return d, None, None
-
-
-def _dropout_hip(x, mask, p):
-    return _DropoutFn.apply(x, mask, p)
 
 
 class ConditionalLayer(nn.Module):

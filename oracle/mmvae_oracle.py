@@ -345,13 +345,15 @@ class _GRL(torch.autograd.Function):
         return g.neg() * ctx.alpha, None
 
 
-def adversarial_losses(spec: ModelSpec, sd, hidden, labels: Dict[str, torch.Tensor], detach: bool, hp: HParams):
+def adversarial_losses(spec: ModelSpec, sd, hidden, labels: Dict[str, torch.Tensor], detach: bool, hp: HParams,
+                       masks: Optional[dict] = None):
     """CMMVAEModel.grf (models/cmmvae_model.py:59-101): per adversary, CE(sum) per head then summed.
-    Heads are iterated in the order of `labels` (cmmvae_model.py:83: `for condition, label in labels.items()`)."""
+    Heads are iterated in the order of `labels` (cmmvae_model.py:83: `for condition, label in labels.items()`).
+    `masks`: explicit dropout keep masks of adversary encoders with dropout (the adversaries run in training mode)."""
     out = []
     for i, (h, adv) in enumerate(zip(hidden, spec.adversarials)):
         h = h.detach() if detach else _GRL.apply(h, 1)
-        e, _ = fcblock_forward(sd, f"adversarials.{i}.encoder", adv.encoder, h, True, None, hp)
+        e, _ = fcblock_forward(sd, f"adversarials.{i}.encoder", adv.encoder, h, True, masks, hp)
         heads = {}
         for cond, y in labels.items():
             p = f"adversarials.{i}.heads.{cond}.fc_layers.0.lin"
@@ -423,7 +425,7 @@ def train_step(spec: ModelSpec, sd: Dict[str, torch.Tensor], opt_state: dict, x:
     total = e["loss"]
     if spec.adversarials:
         assert labels is not None
-        d = adversarial_losses(spec, live, fwd["hidden"], labels, True, hp)
+        d = adversarial_losses(spec, live, fwd["hidden"], labels, True, hp, masks)
         out["discriminator"] = [{"heads": {c: v.detach() for c, v in a["heads"].items()}, "summed": a["summed"].detach()}
                                 for a in d]
         for i, a in enumerate(d):  # cmmvae_model.py:120-131
@@ -435,7 +437,7 @@ def train_step(spec: ModelSpec, sd: Dict[str, torch.Tensor], opt_state: dict, x:
             new_sd.update(upd)
             for n in names:
                 live[n] = upd[n].detach().clone().requires_grad_(True)
-        g = adversarial_losses(spec, live, fwd["hidden"], labels, False, hp)  # :134
+        g = adversarial_losses(spec, live, fwd["hidden"], labels, False, hp, masks)  # :134
         out["generator"] = [{"heads": {c: v.detach() for c, v in a["heads"].items()}, "summed": a["summed"].detach()}
                             for a in g]
         for a in g:  # :182-184
@@ -502,3 +504,67 @@ def synthetic_counts(B: int, G: int, seed: int = 1234) -> torch.Tensor:
     c = torch.poisson(lam.expand(B, G), generator=g)
     rs = c.sum(1, keepdim=True).clamp_min(1.0)
     return torch.log1p(1e4 * c / rs)
+
+
+# ------------------------------------------------------------------------------------- in-place stepping (timing leg)
+class InPlaceStepper:
+    """The same training step as `train_step`, kept the way a trainer keeps it: parameters are leaf tensors updated in
+    place by `torch.optim.Adam` (one per expert, one for the VAE, one per adversary -- cmmvae_model.py:299-324),
+    gradients come from `backward()`, clipping is `clip_grad_norm_`.  `train_step` is the functional statement the parity
+    tests compare against (it clones the whole state every step: fine for checking, wrong for timing); this class is what
+    bench.py's `cpu_baseline` times.  tests/test_oracle_golden.py checks that both give the same numbers."""
+
+    def __init__(self, spec: ModelSpec, sd: Dict[str, torch.Tensor], hp: HParams):
+        self.spec, self.hp = spec, hp
+        self.sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and not _is_buffer(k)
+                       else v.detach().clone()) for k, v in sd.items()}
+        self.groups = {g: [n for n, _ in names] for g, names in group_param_names(spec).items()}
+        self.optim = {g: torch.optim.Adam([self.sd[n] for n in names], lr=hp.lr, betas=(hp.beta1, hp.beta2),
+                                          eps=hp.adam_eps, weight_decay=hp.weight_decay)
+                      for g, names in self.groups.items()}
+
+    def _clip(self, group: str, max_norm: Optional[float]) -> torch.Tensor:
+        params = [self.sd[n] for n in self.groups[group] if self.sd[n].grad is not None]
+        if max_norm is None:
+            return grad_norm([p.grad for p in params])
+        return torch.nn.utils.clip_grad_norm_(params, max_norm)
+
+    def step(self, x, expert_id: str, eps, masks, labels, kl_weight: float) -> dict:
+        spec, hp, sd = self.spec, self.hp, self.sd
+        live = [f"expert_{expert_id}", "vae"] + [g for g in self.groups if g.startswith("adversarial_")]
+        for g in live:
+            self.optim[g].zero_grad(set_to_none=True)
+        bn_updates: dict = {}
+        K = eps.shape[0] if eps.dim() == 3 else 1
+        fwd = model_forward(spec, sd, x, expert_id, eps, True, masks, hp, bn_updates)
+        e = elbo(fwd["mu"], fwd["std"], x, fwd["xhat"], kl_weight, K)
+        out = {"loss": e["loss"].detach(), "recon_loss": e["recon_loss"].detach(), "kl_loss": e["kl_loss"].detach(),
+               "grad_norms": {}}
+        total = e["loss"]
+        if spec.adversarials:
+            d = adversarial_losses(spec, sd, fwd["hidden"], labels, True, hp, masks)
+            for i, a in enumerate(d, start=1):
+                g = f"adversarial_{i}"
+                a["summed"].backward()
+                out["grad_norms"][f"discriminator_{i}"] = self._clip(g, hp.adversarial_clip)
+                self.optim[g].step()
+                self.optim[g].zero_grad(set_to_none=True)
+            for a in adversarial_losses(spec, sd, fwd["hidden"], labels, False, hp, masks):
+                total = total + a["summed"] * hp.adv_weight
+        out["total_loss"] = total.detach()
+        total.backward()
+        out["grad_norms"]["vae"] = self._clip("vae", hp.vae_clip)
+        out["grad_norms"][f"expert_{expert_id}"] = self._clip(f"expert_{expert_id}", hp.expert_clip)
+        self.optim["vae"].step()
+        self.optim[f"expert_{expert_id}"].step()
+        with torch.no_grad():
+            for k, v in bn_updates.items():
+                sd[k].copy_(v)
+        return out
+
+    def state(self) -> Dict[str, torch.Tensor]:
+        return {k: v.detach() for k, v in self.sd.items()}
+
+
+def _is_buffer(name: str) -> bool:
+    return name.endswith(("running_mean", "running_var", "num_batches_tracked"))

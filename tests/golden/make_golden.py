@@ -28,6 +28,9 @@ import torch.nn as nn
 
 REF_SRC = "/root/reference/src"
 OUT_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(OUT_DIR))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 
 class ExplicitDropout(nn.Module):
@@ -106,7 +109,8 @@ def build_reference(case, tmpdir):
         warnings.simplefilter("ignore")
         vae = CLVAE(
             latent_dim=case["Z"],
-            encoder_config=fc_cfg(base, [case["expert_hidden"][-1]] + case["vae_hidden"], bn=True, return_hidden=True),
+            encoder_config=fc_cfg(base, [case["expert_hidden"][-1]] + case["vae_hidden"], bn=True, return_hidden=True,
+                                  dropout=case.get("vae_dropout", 0.0)),
             decoder_config=fc_cfg(base, [case["Z"]] + case["vae_hidden"][::-1] + [case["expert_hidden"][-1]]),
             hidden_z=case["hidden_z"], **cond_kwargs,
         )
@@ -119,7 +123,8 @@ def build_reference(case, tmpdir):
         advs = []
         for enc_layers in case["adversarials"]:
             advs.append(base.Adversarial(
-                encoder=fc_cfg(base, enc_layers), heads=fc_cfg(base, [enc_layers[-1]], relu=False),
+                encoder=fc_cfg(base, enc_layers, dropout=case.get("adv_dropout", 0.0)),
+                heads=fc_cfg(base, [enc_layers[-1]], relu=False),
                 conditions=list(case["conditions"].keys()), labels_dir=tmpdir))
     module = CMMVAE(vae, base.Experts(experts), advs)
     torch.manual_seed(case["seed"])
@@ -166,6 +171,10 @@ def run_case(case):
         ce = nn.CrossEntropyLoss(reduction="sum")
         adv_weight = case.get("adv_weight") or 1.0  # cmmvae_model.py:56
         g = torch.Generator().manual_seed(case["seed"] + 2)
+        if case.get("regen"):
+            from tests import helpers as H
+
+            regen = H.RegenStream(case)
         orig_rsample = Normal.rsample
         eps_holder = {}
         Normal.rsample = lambda self, sample_shape=torch.Size(): self.loc + eps_holder["eps"] * self.scale
@@ -174,7 +183,7 @@ def run_case(case):
                 G = case["experts"][eid]
                 B = case["B"]
                 lam = 0.15 * torch.exp(torch.randn(G, generator=g))
-                c = torch.poisson(lam.expand(B, G) * 8.0, generator=g)
+                c = torch.poisson(lam.expand(B, G) * case.get("lam_scale", 8.0), generator=g)
                 x = torch.log1p(1e4 * c / c.sum(1, keepdim=True).clamp_min(1.0))
                 eps = torch.randn(B, case["Z"], generator=g)
                 eps_holder["eps"] = eps
@@ -202,11 +211,33 @@ def run_case(case):
                     random.seed(case["seed"] * 100 + t)
                 metadata = pd.DataFrame(meta if meta else {"dummy": [0] * B})
                 for name, ed in drops.items():
-                    if name.startswith(f"experts.{eid}."):
+                    if name.startswith((f"experts.{eid}.", "vae.", "adversarials.")):
                         # size of this dropout's input = out_features of the Linear in the same layer
                         lin = dict(module.named_modules())[name.rsplit(".", 1)[0] + ".lin"]
                         ed.mask = (torch.rand(B, lin.out_features, generator=g) >= ed.p).to(torch.uint8)
                         out[f"step{t}/in/mask/{name}"] = ed.mask.numpy()
+
+                if case.get("regen"):  # the tests re-draw these inputs with tests/helpers.RegenStream: same numbers?
+                    rx, reps, rmasks, rlabels = regen.step(t, eid)
+                    assert torch.equal(rx, x) and torch.equal(reps, eps)
+                    assert all(torch.equal(rlabels[k], torch.from_numpy(out[f"step{t}/in/labels/{k}"])) for k in rlabels)
+                    assert {f"step{t}/in/mask/{k}" for k in rmasks} == {k for k in out if k.startswith(f"step{t}/in/mask/")}
+                    assert all(torch.equal(m, torch.from_numpy(out[f"step{t}/in/mask/{k}"])) for k, m in rmasks.items())
+
+                if case.get("regen"):  # independent single steps: every step starts from a regenerated state
+                    from cmmvae.modules.base.init import he_init_weights as ref_init
+
+                    count, moments = H.regen_state(case, t, module, eid, init_fn=ref_init)
+                    by_name = dict(module.named_parameters())
+                    for key in ["vae", f"expert_{eid}"] + [k for k in optims if k.startswith("adversarial_")]:
+                        optims[key].state.clear()
+                        for p_ in optims[key].param_groups[0]["params"]:
+                            n_ = next(n for n, q in by_name.items() if q is p_)
+                            if n_ in moments:
+                                optims[key].state[p_] = {"step": torch.tensor(float(count)), "exp_avg": moments[n_][0].clone(),
+                                                         "exp_avg_sq": moments[n_][1].clone()}
+                    for k_, v_ in module.state_dict().items():
+                        out[f"step{t}/sd_in/{k_}"] = v_.numpy().copy()
 
                 # ---- training_step, cmmvae_model.py:138-217
                 metadata["species"] = eid
@@ -299,8 +330,33 @@ def run_case(case):
             out["eval/out/embedding_z"] = emb["z"][0].numpy().copy()
         finally:
             Normal.rsample = orig_rsample
+    if case.get("regen"):
+        out = compact_outputs(out)
     out["case_json"] = np.array(json.dumps(case))
     return out
+
+
+def compact_outputs(out):
+    """Full-size ("regen") cases: inputs and initial parameters are regenerated from the seeds by the tests, so only
+    checksums + sampled entries of every tensor are kept (tests/helpers.compact); scalars stay as they are."""
+    from tests import helpers as H
+
+    small = {}
+    for k, v in out.items():
+        v = np.asarray(v)
+        if "/in/" in k:
+            if k.endswith("/in/x"):  # guards the regeneration of the batch
+                small[k + "/sumsq"] = np.array((v.astype(np.float64) ** 2).sum())
+            continue
+        if v.ndim == 0:
+            small[k] = v
+            continue
+        if k.startswith("sd0/"):
+            continue  # step 0 starts from step0/sd_in like every other step
+        name = k.split("/", 2)[2]
+        for field, arr in H.compact(name, v, light="/sd_in/" in k).items():
+            small[f"{k}/{field}"] = arr
+    return small
 
 
 def annealing_vectors():
@@ -331,6 +387,12 @@ CASES = {
                         dropout=0.1, hidden_z=True, schedule=["human", "mouse"], kl_weights=[1.0, 1.0],
                         adversarials=[[24, 16, 8], [12, 8]], conditions={"assay": 5, "sex": 2, "donor_id": 37},
                         adv_weight=25),
+    # dropout outside the expert encoder: in the VAE encoder and in both adversary encoders.  One keep mask per Dropout
+    # module and step: the two adversarial phases (discriminator / generator) see the same mask in this fixture
+    "adv_dropout": dict(seed=71, experts={"human": 96, "mouse": 80}, expert_hidden=[64, 32], vae_hidden=[24], Z=12, B=16,
+                        dropout=0.1, vae_dropout=0.1, adv_dropout=0.25, hidden_z=True, schedule=["human", "mouse", "human"],
+                        kl_weights=[1.0, 1.0, 1.0], adversarials=[[24, 16, 8], [12, 8]],
+                        conditions={"assay": 5, "sex": 2, "donor_id": 37}, adv_weight=25),
     # conditional layers after the reparameterisation: shared and species-specific ConditionalLayers plus
     # the per-species block, applied in a fixed order / concatenated in shuffled order ("parallel"); some conditions
     # are absent from a batch, so their parameters have no gradient and torch's Adam skips them (own step counts)
@@ -352,6 +414,28 @@ CASES = {
                      cond=dict(keys=["assay", "donor_id", "species", "sex"], shared={"assay": 4, "sex": 2},
                                species_specific={"donor_id": {"human": 5, "mouse": 3}}, layer_norm=True,
                                parallel=False)),
+    # ---- full-size ("regen") cases: the kernels the benchmark times, pinned to the reference.  Initial parameters and
+    # inputs are regenerated from the seeds (tests/helpers.regen_initial_state / RegenStream); the fixture keeps
+    # checksums and sampled entries.  lam_scale 1.0 = the benchmark's count distribution (~10 % non-zeros).
+    # mid_odd: gene counts / batch that are multiples of nothing (K tails, edge groups, zero-slack rows of the bf16x3 kernels)
+    "mid_odd": dict(seed=53, experts={"human": 10001, "mouse": 8190}, expert_hidden=[1024, 512], vae_hidden=[256], Z=128,
+                    B=500, dropout=0.1, hidden_z=False, schedule=["human", "mouse", "human", "mouse"],
+                    kl_weights=[1.0, 1.0, 0.5, 0.5], regen=True, lam_scale=1.0),
+    # BASELINE config 2: the configuration the metric is quoted on
+    "c2_full": dict(seed=59, experts={"human": 20000, "mouse": 20000}, expert_hidden=[1024, 512], vae_hidden=[256],
+                    Z=128, B=512, dropout=0.1, hidden_z=False, schedule=["human", "mouse", "human", "mouse"],
+                    kl_weights=[1.0, 1.0, 1.0, 1.0], regen=True, lam_scale=1.0),
+    # BASELINE config 4 per GPU: + two adversaries (on h1 and z) with the class counts of data/conditional_layers/*.csv
+    "c4_full": dict(seed=61, experts={"human": 20000, "mouse": 20000}, expert_hidden=[1024, 512], vae_hidden=[256],
+                    Z=128, B=512, dropout=0.1, hidden_z=True, schedule=["human", "mouse", "human"],
+                    kl_weights=[1.0, 1.0, 1.0], adversarials=[[256, 128, 64], [128, 64]],
+                    conditions={"assay": 8, "sex": 2, "dataset_id": 273, "donor_id": 4644}, adv_weight=25,
+                    regen=True, lam_scale=1.0),
+    # BASELINE config 5 per GPU at K = 1 (the reference has no K): three expert channels, 30 000 genes, batch 1024
+    "c5_three_mod": dict(seed=67, experts={"human": 30000, "mouse": 30000, "macaque": 30000}, expert_hidden=[1024, 512],
+                         vae_hidden=[256], Z=128, B=1024, dropout=0.1, hidden_z=False,
+                         schedule=["human", "mouse", "macaque", "human"], kl_weights=[1.0, 1.0, 1.0, 1.0],
+                         regen=True, lam_scale=1.0),
 }
 
 
@@ -360,8 +444,11 @@ def main():
         print(f"{REF_SRC} not present: golden vectors can only be generated in the build container; nothing done.")
         return 0
     sys.path.insert(0, REF_SRC)
-    torch.set_num_threads(1)
+    only = sys.argv[1:]
     for name, case in CASES.items():
+        if only and name not in only:
+            continue
+        torch.set_num_threads(8 if case.get("regen") else 1)
         out = run_case(dict(case))
         path = os.path.join(OUT_DIR, f"{name}.npz")
         if os.path.exists(path):  # regenerated vectors must reproduce the committed ones bit for bit
@@ -370,6 +457,8 @@ def main():
                 assert k in out and np.array_equal(np.asarray(old[k]), np.asarray(out[k])), f"{name}: {k} changed"
         np.savez_compressed(path, **out)
         print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")
+    if only:
+        return 0
     ann = annealing_vectors()
     np.savez_compressed(os.path.join(OUT_DIR, "annealing.npz"), **ann)
     print("wrote annealing.npz")

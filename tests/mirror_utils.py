@@ -47,7 +47,8 @@ def build_mirror(case, device, tmpdir, use_engine=False):
                                                                   use_layer_norm=False, activation_fn=nn.ReLU)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        vae = CLVAE(latent_dim=Z, encoder_config=cfg([eh[-1]] + vh, bn=True, return_hidden=True),
+        vae = CLVAE(latent_dim=Z, encoder_config=cfg([eh[-1]] + vh, bn=True, return_hidden=True,
+                                                     dropout=case.get("vae_dropout", 0.0)),
                     decoder_config=cfg([Z] + vh[::-1] + [eh[-1]]), hidden_z=case["hidden_z"], **cond_kwargs)
     advs = None
     if case.get("adversarials"):
@@ -55,7 +56,7 @@ def build_mirror(case, device, tmpdir, use_engine=False):
         for cond, n in case["conditions"].items():
             pd.Series([f"{cond}_{i}" for i in range(n)]).to_csv(
                 os.path.join(tmpdir, "human", f"unique_expression_{cond}.csv"), header=False, index=False)
-        advs = [base.Adversarial(encoder=cfg(enc), heads=cfg([enc[-1]], relu=False),
+        advs = [base.Adversarial(encoder=cfg(enc, dropout=case.get("adv_dropout", 0.0)), heads=cfg([enc[-1]], relu=False),
                                  conditions=list(case["conditions"].keys()), labels_dir=tmpdir)
                 for enc in case["adversarials"]]
     clip = lambda: GradientClipConfig(val=10, algorithm="norm")
@@ -70,7 +71,21 @@ def load_state(model, z, prefix):
     return missing
 
 
-def replay_training(name, device, use_engine=False, check=True, prepare=None):
+def set_explicit_masks(model, masks, eid, device):
+    """Fixture keep masks ("<block path>.fc_layers.<i>.dr") -> explicit_masks of the FCBlocks they belong to: the active
+    expert's encoder, and -- cases with dropout there -- the VAE blocks and the adversary encoders."""
+    model.module.experts[eid].encoder.explicit_masks = {}
+    for key, m in masks.items():
+        path, rest = key.split(".fc_layers.")
+        if path.startswith("experts.") and not path.startswith(f"experts.{eid}."):
+            continue
+        block = model.module.get_submodule(path)
+        if block.explicit_masks is None:
+            block.explicit_masks = {}
+        block.explicit_masks[int(rest.split(".")[0])] = m.to(device)
+
+
+def replay_training(name, device, use_engine=False, check=True, prepare=None, before_step=None):
     """Runs the golden schedule through CMMVAEModel.training_step; returns list of per-step result dicts."""
     from mmvae_amd import backend
 
@@ -85,13 +100,11 @@ def replay_training(name, device, use_engine=False, check=True, prepare=None):
             prepare(model)
         for t, eid in enumerate(case["schedule"]):
             x, eps, masks, labels = H.step_inputs(z, t)
+            if before_step is not None:
+                before_step(model, t)
             model.kl_annealing_fn.kl_weight = case["kl_weights"][t]
             model.module.vae.encoder.explicit_eps = eps.to(device)
-            enc = model.module.experts[eid].encoder
-            enc.explicit_masks = {}
-            for k, m in masks.items():
-                if k.startswith(f"experts.{eid}.encoder.fc_layers."):
-                    enc.explicit_masks[int(k.split(".")[4])] = m.to(device)
+            set_explicit_masks(model, masks, eid, device)
             meta = {cond: [f"{cond}_{int(i)}" for i in idx] for cond, idx in labels.items()}
             if case.get("cond"):
                 import random
@@ -111,6 +124,36 @@ def replay_training(name, device, use_engine=False, check=True, prepare=None):
     return case, z, results
 
 
+def _check_logged(case, z, t, r, rtol_loss):
+    """Logged scalars of step t (losses, posterior statistics, gradient norms, adversarial losses) against the reference's."""
+    eid = r["eid"]
+    g = lambda k: float(np.array(z[f"step{t}/out/{k}"]))
+    L = r["logged"]
+    worst = {}
+
+    def close(a, b, what, rtol=rtol_loss, atol=1e-5):
+        assert abs(a - b) <= rtol * abs(b) + atol, f"step{t} {what}: got {a}, reference {b}"
+        worst[what] = abs(a - b) / max(abs(b), 1e-30)
+
+    close(L[f"loss/training/{eid}"], g("total_loss"), "loss")
+    close(L[f"recon_loss/training/{eid}"], g("recon_loss"), "recon_loss")
+    close(L[f"kl_loss/training/{eid}"], g("kl_loss"), "kl_loss")
+    close(L[f"Mean/training/{eid}"], g("Mean"), "Mean", atol=1e-6)
+    close(L[f"Variance/training/{eid}"], g("Variance"), "Variance", atol=1e-6)
+    close(L["grad_norms/vae"], g("grad_norms/vae"), "grad_norms/vae", rtol=5e-5)
+    close(L[f"grad_norms/expert_{eid}"], g(f"grad_norms/expert_{eid}"), "grad_norms/expert", rtol=5e-5)
+    for i in range(len(case.get("adversarials", []) or [])):
+        for phase in ("discriminator", "generator"):
+            close(L[f"{phase}_{i + 1}/training/{eid}/adversarial_loss/summed"], g(f"{phase}_{i + 1}/summed"),
+                  f"{phase}_{i + 1}/summed")
+            for cond in case["conditions"]:
+                close(L[f"{phase}_{i + 1}/training/{eid}/adversarial_loss/{cond}"], g(f"{phase}_{i + 1}/{cond}"),
+                      f"{phase}_{i + 1}/{cond}")
+            close(L[f"grad_norms/{phase}_{i + 1}"], g(f"grad_norms/{phase}_{i + 1}"), f"grad_norms/{phase}",
+                  rtol=5e-5)
+    return worst
+
+
 def check_against_golden(case, z, results, rtol_loss=2e-5, tol_param=1e-4):
     from oracle import mmvae_oracle as O  # checker only
 
@@ -118,29 +161,7 @@ def check_against_golden(case, z, results, rtol_loss=2e-5, tol_param=1e-4):
     skip = H.bn_fed_biases(spec)
     lr, mom = 5e-3, 0.01
     for t, r in enumerate(results):
-        eid = r["eid"]
-        g = lambda k: float(np.array(z[f"step{t}/out/{k}"]))
-        L = r["logged"]
-
-        def close(a, b, what, rtol=rtol_loss, atol=1e-5):
-            assert abs(a - b) <= rtol * abs(b) + atol, f"step{t} {what}: got {a}, reference {b}"
-
-        close(L[f"loss/training/{eid}"], g("total_loss"), "loss")
-        close(L[f"recon_loss/training/{eid}"], g("recon_loss"), "recon_loss")
-        close(L[f"kl_loss/training/{eid}"], g("kl_loss"), "kl_loss")
-        close(L[f"Mean/training/{eid}"], g("Mean"), "Mean", atol=1e-6)
-        close(L[f"Variance/training/{eid}"], g("Variance"), "Variance", atol=1e-6)
-        close(L["grad_norms/vae"], g("grad_norms/vae"), "grad_norms/vae", rtol=5e-5)
-        close(L[f"grad_norms/expert_{eid}"], g(f"grad_norms/expert_{eid}"), "grad_norms/expert", rtol=5e-5)
-        for i in range(len(case.get("adversarials", []) or [])):
-            for phase in ("discriminator", "generator"):
-                close(L[f"{phase}_{i + 1}/training/{eid}/adversarial_loss/summed"], g(f"{phase}_{i + 1}/summed"),
-                      f"{phase}_{i + 1}/summed")
-                for cond in case["conditions"]:
-                    close(L[f"{phase}_{i + 1}/training/{eid}/adversarial_loss/{cond}"], g(f"{phase}_{i + 1}/{cond}"),
-                          f"{phase}_{i + 1}/{cond}")
-                close(L[f"grad_norms/{phase}_{i + 1}"], g(f"grad_norms/{phase}_{i + 1}"), f"grad_norms/{phase}",
-                      rtol=5e-5)
+        _check_logged(case, z, t, r, rtol_loss)
         for n, v in r["sd"].items():
             ref = np.array(z[f"step{t}/sd/{n}"])
             if n in skip:
@@ -151,3 +172,109 @@ def check_against_golden(case, z, results, rtol_loss=2e-5, tol_param=1e-4):
                 assert np.abs(v.numpy() - ref).max() <= mom * lr * (t + 1) * (t + 2) + 1e-6, n
             else:
                 assert H.rel_l2(v, ref) < tol_param, f"step{t} param {n}: rel-L2 {H.rel_l2(v, ref)}"
+
+
+# ------------------------------------------------------------------------------------------- full-size ("regen") cases
+def load_regen_state(model, twin, case, z, t, eid):
+    """Regenerates the state step t of a regen case starts from on the CPU twin (tests/helpers.regen_state), verifies
+    it against the fixture, and loads it into the (device) model: parameters and buffers through load_state_dict
+    (in place, into the optimiser arenas), Adam moments and step counts through the optimisers' load_state_dict."""
+    count, moments = H.regen_state(case, t, twin, eid)
+    sd = twin.state_dict()
+    for n, v in sd.items():
+        H.compare_compact(n, v, z, f"step{t}/sd_in/{n}", 1e-7, f"step{t}: regenerated state ")
+    model.module.load_state_dict(sd)
+    names = {id(p): n for n, p in model.module.named_parameters()}
+    for opt in model.optimizers():
+        params = opt.arena.params if hasattr(opt, "arena") else opt.param_groups[0]["params"]
+        mine = [names[id(p)] for p in params]
+        if not mine[0].startswith(("vae.", f"experts.{eid}.", "adversarials.")):
+            continue
+        state = {}
+        for i, n in enumerate(mine):
+            if moments:
+                state[i] = {"step": torch.tensor(float(count)), "exp_avg": moments[n][0], "exp_avg_sq": moments[n][1]}
+            else:
+                state[i] = {"step": torch.tensor(0.0), "exp_avg": torch.zeros_like(sd[n]), "exp_avg_sq": torch.zeros_like(sd[n])}
+        group = {k: v for k, v in opt.param_groups[0].items() if k != "params"}
+        opt.load_state_dict({"state": state, "param_groups": [{**group, "params": list(range(len(mine)))}]})
+    return sd
+
+
+def replay_regen(name, device, use_engine=True, steps=None, after=None):
+    """Runs the independent steps of a regen case through CMMVAEModel.training_step with regenerated states and
+    inputs; returns per-step logged scalars, state_dicts and the gradients left in the optimiser arenas."""
+    from mmvae_amd import backend
+
+    case, z = H.load_case(name)
+    results = []
+    with tempfile.TemporaryDirectory() as tmpdir, backend.cpu_plumbing(device == "cpu"):
+        model = build_mirror(case, "cpu", tmpdir, use_engine=use_engine).to(device)
+        twin = build_mirror(case, "cpu", tmpdir + "/", use_engine=False).module  # regeneration happens on the CPU
+        model.train()
+        model.trainer.set_stage("training")
+        opts = model.optimizers()
+        names = {id(p): n for n, p in model.module.named_parameters()}
+        stream = H.RegenStream(case)
+        schedule = case["schedule"] if steps is None else case["schedule"][:steps]
+        for t, eid in enumerate(schedule):
+            x, eps, masks, labels = stream.step(t, eid)
+            got = float(x.double().pow(2).sum())
+            want = float(np.array(z[f"step{t}/in/x/sumsq"]))
+            assert abs(got - want) <= 1e-6 * want, f"step{t}: the regenerated batch is not the generator's ({got} vs {want})"
+            model._flush_engine()
+            load_regen_state(model, twin, case, z, t, eid)
+            model.kl_annealing_fn.kl_weight = case["kl_weights"][t]
+            model.module.vae.encoder.explicit_eps = eps.to(device)
+            enc = model.module.experts[eid].encoder
+            enc.explicit_masks = {int(k.split(".")[4]): m.to(device) for k, m in masks.items()}
+            meta = {cond: [f"{cond}_{int(i)}" for i in idx] for cond, idx in labels.items()}
+            metadata = pd.DataFrame(meta if meta else {"dummy": [0] * x.shape[0]})
+            model.logged.clear()
+            model.training_step((x.to(device), metadata, eid), t)
+            model._flush_engine()
+            if device != "cpu":
+                torch.cuda.synchronize()
+            logged = {k: (float(v.detach()) if torch.is_tensor(v) else v) for k, v in model.logged.items()}
+            sd = {k: v.detach().cpu().clone() for k, v in model.module.state_dict().items()
+                  if k.startswith(("vae.", f"experts.{eid}.", "adversarials."))}
+            grads = {}
+            for o in opts:
+                if not hasattr(o, "arena"):
+                    continue
+                for i, p in enumerate(o.arena.params):
+                    n = names[id(p)]
+                    if n.startswith(("vae.", f"experts.{eid}.")):
+                        grads[n] = o.arena.grad_view(i).detach().cpu().clone()
+            results.append({"logged": logged, "sd": sd, "eid": eid, "grads": grads})
+        replay_training.last_engine = model._engine
+        if after is not None:
+            after(model, case, z, (x, eps, metadata, eid))
+    return case, z, results
+
+
+def check_against_checksums(case, z, results, rtol_loss=1e-4, tol_param=1e-4, tol_grad=1e-4, report=None):
+    """Regen cases: logged scalars like the small cases (losses rtol 1e-4: sums of 10^7 fp32 terms); gradients and
+    post-step parameters against the fixture's norm + sampled entries (small tensors in full)."""
+    spec = H.spec_from_case(case)
+    skip = H.bn_fed_biases(spec)
+    lr, mom = 5e-3, 0.01
+    worst = {"grad": 0.0, "param": 0.0}
+    ts = H.ADVERSARIAL_SAMPLE_TOL if case.get("adversarials") else None
+    for t, r in enumerate(results):
+        for k, v in _check_logged(case, z, t, r, rtol_loss).items():
+            worst[k] = max(worst.get(k, 0.0), v)
+        for n, gr in r["grads"].items():
+            if n in skip:  # exactly-zero true gradient: rounding noise on both sides
+                continue
+            worst["grad"] = max(worst["grad"], H.compare_compact(n, gr, z, f"step{t}/grad/{n}", tol_grad, f"step{t} grad ", ts))
+        for n, v in r["sd"].items():
+            if n in skip:  # chaotic by construction (helpers.bn_fed_biases): bounded by one Adam step
+                ref = np.array(z[f"step{t}/sd/{n}/full"])
+                assert np.abs(v.numpy() - ref).max() <= 2 * lr + 1e-6, n
+            else:
+                worst["param"] = max(worst["param"],
+                                     H.compare_compact(n, v, z, f"step{t}/sd/{n}", tol_param, f"step{t} param ", ts))
+    if report is not None:
+        report.update(worst)
+    return worst

@@ -76,6 +76,26 @@ def test_partial_batches_and_rank_sharding(tmp_path):
     assert not (rows[0] & rows[1]) and len(rows[0] | rows[1]) == 40
 
 
+@pytest.mark.parametrize("rows,chunk_rows,world", [(50, 50, 2), (50, 50, 8), (130, 30, 4), (95, 25, 3)])
+def test_every_rank_yields_the_same_number_of_batches(tmp_path, rows, chunk_rows, world):
+    """Odd batch counts, and more ranks than batches per chunk: one counter over the epoch's kept batches deals rounds of
+    `world`; every rank gets floor(n / world) batches, disjoint rows, and the ranks together cover whole rounds."""
+    m, meta = _dataset(rows, 8, 4)
+    D.write_chunks(str(tmp_path), "mouse", m, meta, chunk_rows=chunk_rows)
+    feed = lambda **kw: list(D.SpeciesChunks(str(tmp_path), "mouse_*counts*.npz", "mouse_*metadata*.pkl", 10, "mouse",
+                                             seed=5, **kw))
+    whole = feed()
+    shards = [feed(rank=r, world=world) for r in range(world)]
+    assert [len(s) for s in shards] == [len(whole) // world] * world
+    rows_of = [[tuple(md["row"].tolist()) for _, md, _ in s] for s in shards]
+    flat = [r for s in rows_of for b in s for r in b]
+    assert len(flat) == len(set(flat))
+    # round k of the un-sharded stream is the ranks' k-th batches, in rank order
+    for k in range(len(whole) // world):
+        for r in range(world):
+            assert rows_of[r][k] == tuple(whole[k * world + r][1]["row"].tolist())
+
+
 def test_multi_modal_interleave_feeds_the_trainer(tmp_path):
     feeds = {}
     for k, (name, g) in enumerate((("human", 12), ("mouse", 9))):

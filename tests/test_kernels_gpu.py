@@ -246,6 +246,57 @@ def test_layernorm(ops, B, N):
     assert rel_l2(dx, x.grad) < 2e-5
 
 
+@pytest.mark.parametrize("bn,relu,p,hidden", [(False, True, 0.0, False), (False, True, 0.2, True), (True, True, 0.1, True),
+                                              (False, False, 0.3, False), (True, False, 0.0, False)])
+def test_fcblock_layernorm_then_relu_and_dropout(ops, bn, relu, p, hidden):
+    """Linear -> [BN] -> LayerNorm(no affine) -> [ReLU] -> [Dropout] (components.py:279-288, the core of
+    configs/model/configV3.yaml:25-36) on the HIP module path, forward and backward, against the same stack of torch
+    modules in fp64 with the same keep masks; the hidden representation is the post-activation, pre-dropout tensor."""
+    import torch.nn as nn
+
+    from mmvae_amd.modules.base import FCBlock, FCBlockConfig
+
+    B, dims = 33, [40, 56, 24]
+    cfg = FCBlockConfig(layers=dims, dropout_rate=p, use_batch_norm=bn, use_layer_norm=True,
+                        activation_fn=nn.ReLU if relu else None, return_hidden=hidden)
+    torch.manual_seed(3)
+    blk = FCBlock(cfg)
+    ref = FCBlock(FCBlockConfig(layers=dims, dropout_rate=p, use_batch_norm=bn, use_layer_norm=True,
+                                activation_fn=nn.ReLU if relu else None, return_hidden=hidden)).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in blk.state_dict().items()})
+    blk = blk.cuda().train()
+    ref.train()
+    x = rnd(B, dims[0], seed=5)
+    masks = {i: (torch.rand(B, n, generator=torch.Generator().manual_seed(9 + i)) >= p).to(torch.uint8)
+             for i, n in enumerate(dims[1:])} if p > 0 else None
+    # fp64 reference: the reference's own module order, dropout applied with the explicit masks
+    xr = x.double().requires_grad_(True)
+    h, hid_ref = xr, []
+    for i, layer in enumerate(ref.fc_layers):
+        for name, sub in layer.named_children():
+            h = h * masks[i].double() / (1 - p) if name == "dr" else sub(h)
+            if name == "af" and hidden:
+                hid_ref.append(h)
+    gy = rnd(B, dims[-1], seed=6)
+    gh = [rnd(B, n, seed=20 + i) for i, n in enumerate(dims[1:])] if (hidden and relu) else []
+    (h * gy.double()).sum().add(sum((a * g.double()).sum() for a, g in zip(hid_ref, gh))).backward()
+    # HIP module path
+    xd = dev(x).requires_grad_(True)
+    blk.explicit_masks = {i: dev(m) for i, m in masks.items()} if masks else None
+    out = blk(xd)
+    y, hid = (out if isinstance(out, tuple) else (out, []))
+    assert rel_l2(y, h.detach()) < 2e-6
+    assert len(hid) == len(hid_ref)
+    for a, b in zip(hid, hid_ref):
+        assert rel_l2(a, b.detach()) < 2e-6
+    (y * dev(gy)).sum().add(sum((a * dev(g)).sum() for a, g in zip(hid, gh))).backward()
+    assert rel_l2(xd.grad, xr.grad) < 2e-5
+    for (n, pd_), (_, pr) in zip(blk.named_parameters(), ref.named_parameters()):
+        if bn and n.endswith("lin.bias"):
+            continue  # feeds a BatchNorm: exactly-zero true gradient
+        assert rel_l2(pd_.grad, pr.grad) < 2e-5, n
+
+
 # ------------------------------------------------------------------------------------------------ reparam / losses
 @pytest.mark.parametrize("B,Z,K", [(8, 8, 1), (33, 10, 1), (512, 128, 1), (16, 128, 3), (5, 200, 2)])
 def test_reparam_kl(ops, B, Z, K):

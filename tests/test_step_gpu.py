@@ -83,6 +83,30 @@ def test_engine_overlapped_exchange_with_single_rank_rccl(monkeypatch):
         td.destroy_process_group()
 
 
+@pytest.mark.parametrize("name", ["two_mod_odd", "adversarial"])
+def test_engine_follows_settings_changed_after_capture(name):
+    """Learning rate, clip value and adversarial weight edited between steps (param_groups, autograd_config, adv_weight):
+    the captured programs freeze them at build time, so the engine compares a settings signature on every step and
+    rebuilds its plans -- engine and module path must stay together bit for bit in the logged losses."""
+    def edit(model, t):
+        if t == 1:
+            for o in model.optimizers():
+                o.param_groups[0]["lr"] = 1e-3
+            model.autograd_config.expert_gradient_clip.val = 0.5
+        if t == 2:
+            model.adv_weight = 3.0
+            model.autograd_config.vae_gradient_clip.val = 2.0
+
+    _, _, ra = MU.replay_training(name, "cuda", use_engine=True, before_step=edit)
+    _, _, rb = MU.replay_training(name, "cuda", use_engine=False, before_step=edit)
+    for a, b in zip(ra, rb):
+        for k, v in a["sd"].items():
+            if v.is_floating_point() and not k.endswith("lin.bias"):
+                assert H.rel_l2(v, b["sd"][k]) < 1e-5, k
+        la, lb = a["logged"][f"loss/training/{a['eid']}"], b["logged"][f"loss/training/{b['eid']}"]
+        assert abs(la - lb) <= 2e-5 * abs(lb)
+
+
 def _trained_mirror(name, tmpdir, use_engine):
     """The mirror holding the reference's own post-training state of a golden case, in eval mode."""
     case, z = H.load_case(name)
