@@ -8,6 +8,10 @@ A step = zero_grad, forward, ELBO, [adversarial D/G phases], backward, global-no
 the active expert, on a synthetic batch that is already resident in HBM.  Modalities alternate round-robin on a fixed,
 rank-synchronous schedule.  N > 1: data parallel over cells (weak scaling: per-GPU batch fixed), gradients averaged
 with RCCL all-reduce over the flat gradient arenas.  Prints ONE JSON line (rank 0).
+
+Launched plainly with --gpus N > 1 (no torchrun environment) the script starts the N rank processes itself -- fresh
+children, before this process has touched a GPU -- passes rank 0's line through and exits non-zero if any rank fails.
+The model is instantiated from configs/model/<config>.yaml (the reference's LightningCLI schema).
 """
 import argparse
 import json
@@ -40,8 +44,49 @@ def parse():
                                                    "step: that many workgroups holding that much LDS each spin on a side "
                                                    "stream for that long, started with every step (DESIGN.md section 7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline sample (all thread counts)")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                    help="cpu: rehearsal of the launch / exchange / timing logic on the gloo backend with CPU plumbing "
+                         "(module path, plain torch ops; tests/test_bench_entry.py) -- never a measurement")
     return ap.parse_args()
+
+
+CONFIG_FILES = {"c1": "c1_core_vae.yaml", "c2": "c2_two_modality_20k.yaml", "c3": "c3_two_modality_20k_k10.yaml",
+                "c4": "c4_two_modality_20k_adversarial.yaml", "c5": "c5_three_modality_30k_k5.yaml"}
+
+
+def spawn_ranks(argv, n: int) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks as fresh child processes (this
+    process has not touched a GPU), one per GPU, rendezvous on 127.0.0.1.  Rank 0 prints the JSON line on the inherited
+    stdout.  Returns the exit code: non-zero if any rank failed (the others are then terminated)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    code = 0
+    try:
+        while procs:
+            for p in list(procs):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                procs.remove(p)
+                if rc != 0:
+                    code = code or rc
+                    for q in procs:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            q.kill()
+    return code
 
 
 # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks (no sparsity)
@@ -84,72 +129,108 @@ def time_dominant_kernel(cfg, device, iters=10):
 
 
 def cpu_baseline(cfg, seconds):
-    """The oracle (CPU restatement of the reference step, checked against the reference's golden vectors) timed on the
-    host cores of this box on a bounded sample of the same workload."""
+    """The oracle (CPU restatement of the reference step, pinned against the reference's golden vectors) timed on the
+    host cores of this box on a bounded sample of the same workload: parameters and optimiser state updated in place
+    (oracle.InPlaceStepper: leaf tensors, torch.optim.Adam, backward(), clip_grad_norm_ -- a trainer's bookkeeping, no
+    per-step clone of the 84 M parameters), thread counts {8, 16, 32, all available} swept, the best one reported."""
     from oracle import mmvae_oracle as O
 
-    # cores actually available to this process (cgroup / affinity), not the machine's core count
-    try:
+    try:  # cores actually available to this process (cgroup / affinity), not the machine's core count
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(avail, 64)))
     B, K = cfg["batch"], cfg["K"]
     spec = O.ModelSpec(
         experts={eid: (O.FCSpec.make([G, 1024, 512], dropout_rate=0.1, use_batch_norm=True, relu=True),
                        O.FCSpec.make([512, 1024, G], relu=True)) for eid, G in cfg["experts"].items()},
         vae_encoder=O.FCSpec.make([512, 256], use_batch_norm=True, relu=True, return_hidden=True),
         vae_decoder=O.FCSpec.make([128, 256, 512], relu=True), latent_dim=128)
-    hp = O.HParams()
-    sd = O.init_state(spec, seed=0)
-    opt_state = {}
+    stepper = O.InPlaceStepper(spec, O.init_state(spec, seed=0), O.HParams())
     eids = list(cfg["experts"].keys())
     xs = {eid: O.synthetic_counts(B, G, seed=1234 + i) for i, (eid, G) in enumerate(cfg["experts"].items())}
     g = torch.Generator().manual_seed(7)
 
     def one(i):
-        nonlocal sd
         eid = eids[i % len(eids)]
         eps = torch.randn((K, B, 128) if K > 1 else (B, 128), generator=g)
         masks = {f"experts.{eid}.encoder.fc_layers.0.dr": (torch.rand(B, 1024, generator=g) >= 0.1),
                  f"experts.{eid}.encoder.fc_layers.1.dr": (torch.rand(B, 512, generator=g) >= 0.1)}
-        _, sd = O.train_step(spec, sd, opt_state, xs[eid], eid, eps, masks, None, 1.0, hp)
+        stepper.step(xs[eid], eid, eps, masks, None, 1.0)
 
-    one(0)
-    one(1)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        one(n)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or n >= 200:
-            break
-    return {"value": B * n / el, "unit": "cells/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} training steps of the same workload (B={B}, K={K}, modalities alternating) in {el:.1f} s, "
-                      f"torch {torch.__version__} CPU fp32"}
+    counts = sorted({t for t in (8, 16, 32, avail) if t <= avail} or {avail})
+    sweep = {}
+    for threads in counts:
+        torch.set_num_threads(threads)
+        for i in range(len(eids)):
+            one(i)  # untimed: first touch of this thread count
+        n, t0 = 0, time.perf_counter()
+        while True:
+            one(n)
+            n += 1
+            el = time.perf_counter() - t0
+            if (el >= seconds / len(counts) and n >= len(eids)) or n >= 200:
+                break
+        sweep[threads] = (B * n / el, n, el)
+    best = max(sweep, key=lambda t: sweep[t][0])
+    rate, n, el = sweep[best]
+    return {"value": rate, "unit": "cells/s", "cores": best, "kind": "port",
+            "sample": f"{n} training steps of the same workload (B={B}, K={K}, modalities alternating) in {el:.1f} s with "
+                      f"{best} threads of {avail} available, parameters / Adam state in place, torch {torch.__version__} "
+                      f"CPU fp32; sweep " + ", ".join(f"{t} threads: {sweep[t][0]:.0f} cells/s" for t in counts)}
+
+
+def build_model(a, cfg, device):
+    """The benchmark's model: configs/model/<config>.yaml through the class_path / init_args instantiator (the drop-in
+    surface), or -- `--genes` diagnostics -- the same architecture from mmvae_amd.synthetic with other gene counts."""
+    from mmvae_amd import instantiate, synthetic
+
+    torch.manual_seed(0)
+    if a.genes:
+        return synthetic.build_model(cfg["experts"], adversarial=cfg["adversarial"], n_samples=cfg["K"],
+                                     use_engine=not a.no_engine, seed=0)
+    if cfg["adversarial"]:  # unique_expression_<condition>.csv files with the reference's class counts
+        import tempfile
+
+        from mmvae_amd.modules import base
+
+        base.Adversarial.labels.clear()
+        os.environ["MMVAE_LABELS_DIR"] = synthetic.write_label_dir(tempfile.mkdtemp(prefix="mmvae_labels_"))
+    model = instantiate.load_yaml(os.path.join(ROOT, "configs", "model", CONFIG_FILES[a.config]))
+    model.use_engine = not a.no_engine
+    got = {e.id: e.encoder.config.layers[0] for e in model.module.experts.values()}
+    assert got == cfg["experts"] and model.module.vae.encoder.n_samples == cfg["K"], (got, cfg)
+    return model
 
 
 def main():
     a = parse()
-    from mmvae_amd import dist as mdist, synthetic
+    if a.gpus > 1 and "RANK" not in os.environ:  # plain launch: this process becomes the launcher (no GPU call so far)
+        sys.exit(spawn_ranks(sys.argv[1:], a.gpus))
+    from mmvae_amd import backend, dist as mdist, synthetic
 
-    world = mdist.init_from_env()
+    on_gpu = a.device == "cuda"
+    world = mdist.init_from_env(None if on_gpu else "gloo")
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     rank = mdist.rank()
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("MMVAE_SINGLE_DEVICE", "0") != "0":  # rehearsal: every rank on GPU 0 (with MMVAE_DIST_BACKEND=gloo)
         local = 0
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    if on_gpu:
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    else:  # rehearsal of the launch / exchange / timing logic: CPU plumbing, module path
+        device = torch.device("cpu")
+        backend.set_cpu_plumbing(True)
+        a.no_engine = True
+        torch.set_num_threads(max(1, (os.cpu_count() or 2) // max(world, 1)))
     cfg = dict(synthetic.CONFIGS[a.config])
     if a.genes:
         widths = [int(v) for v in a.genes.split(",")]
         cfg["experts"] = {eid: widths[i % len(widths)] for i, eid in enumerate(cfg["experts"])}
     B, K = cfg["batch"], cfg["K"]
 
-    model = synthetic.build_model(cfg["experts"], adversarial=cfg["adversarial"], n_samples=K,
-                                  use_engine=not a.no_engine, seed=0).to(device)
+    model = build_model(a, cfg, device).to(device)
     model.train()
     model.trainer.set_stage("training")
     model.optimizers()
@@ -221,25 +302,34 @@ def main():
             model.predict_step((x, meta, eid), i)
 
     def sync():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
 
     # Engine set-up (untimed, before the W warm-up steps): a step plan is built on its first run and captured into a
     # hipGraph on its second; a resident batch is recognised by its pointer on its second sight.  Step every resident
     # batch until its plan replays, so that neither the warm-up nor the timed steps contain plan builds.
     period = len(eids) * n_res
-    n_setup = 4 * period
+    n_setup = 4 * period if on_gpu else 0
     for i in range(n_setup):
         step(i)
     sync()
     for i in range(a.warmup):
         step(n_setup + i)
     sync()
+    # one event behind every timed step (recorded on the launch stream, read after the run): per-step durations for the
+    # median beside the mean -- the events cost ~1 us each and no synchronisation
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)] if on_gpu else []
     t0 = time.perf_counter()
+    if marks:
+        marks[0].record()
     for i in range(a.steps):
         step(n_setup + a.warmup + i)
+        if marks:
+            marks[i + 1].record()
     sync()
     el = time.perf_counter() - t0
     if feed is not None:
@@ -248,45 +338,60 @@ def main():
         t = torch.tensor([el], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t)
+    if getattr(model, "_engine", None):
+        model._flush_engine()
     loss = {k: float(v.detach() if torch.is_tensor(v) else v) for k, v in model.logged.items()
             if k.startswith(("loss/", "recon_loss/", "kl_loss/"))}
 
     if rank == 0:
         G = max(cfg["experts"].values())
         cells_per_s = B * world * a.steps / el
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)) if marks else []
+        backend_name = torch.distributed.get_backend() if world > 1 or mdist.collectives_active() else "none"
+        one_expert = len(eids) == 1
         out = {
             "metric": {"train": "cells/sec per MMVAE train step", "validate": "cells/sec per MMVAE validation step",
                        "predict": "cells/sec per MMVAE predict step (latent embeddings)"}[a.mode], "value": cells_per_s, "unit": "cells/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
+            "ms_per_step_median": per_step[len(per_step) // 2] if per_step else None, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if a.input != "npz" else "synthetic, streamed from npz-CSR / pkl chunk files",
             "config": {"workload": f"{a.config}: {len(eids)}-modality MMVAE train step, {G} genes each, latent 128, "
                                    f"K={K}, batch {B}/GPU, adversarial={cfg['adversarial']}"
                                    + (", CSR input densified per step" if a.input == "csr" else "")
                                    + (", npz-CSR chunks streamed from disk" if a.input == "npz" else ""),
+                       "model_file": None if a.genes else f"configs/model/{CONFIG_FILES[a.config]}",
                        "global_batch": B * world, "parallelism": f"dp{world}",
+                       "exchange": ("none" if world == 1 and not mdist.collectives_active() else
+                                    "in-order all-reduce (one expert: nothing to overlap the expert's exchange with)"
+                                    if one_expert else "expert all-reduce + update overlapped with the next modality's step"),
                        "path": "module" if (a.no_engine or not model._engine) else "engine(hipGraph)"},
+            "rccl_ranks": torch.distributed.get_world_size() if backend_name == "nccl" else 0,
+            "dist_backend": backend_name,
             "step_flops_per_cell": synthetic.flops_per_cell(G, K),
             "step_tflops": synthetic.flops_per_cell(G, K) * cells_per_s / world / 1e12,
             "last_losses": loss, "setup_steps": n_setup,
         }
-        from mmvae_amd import _lib
+        if on_gpu:
+            from mmvae_amd import _lib
 
-        tk, fl = time_dominant_kernel(cfg, device)
-        x3 = _lib.load().mmvae_gemm_get_precision() == _lib.GEMM_PRECISION_BF16X3
-        # bf16x3: every fp32 product costs 6 bf16 MFMA products, so the matrix-core ceiling for ALGORITHMIC fp32
-        # flops is the dense bf16 peak / 6; the exact-f32 mode is bounded by the fp32 MFMA peak.
-        peak = BF16_DENSE_TFLOPS / 6.0 if x3 else F32_MFMA_TFLOPS
-        out["roofline"] = {"bound": "mfma",
-                           "kernel": ("gemm_x3_kernel<TN,128x160> (bf16x3 MFMA)" if x3 else "gemm_f32_kernel<TN> (f32 MFMA)")
-                                     + ": dW of a G-wide layer",
-                           "achieved": fl / tk / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl / tk / (peak * 1e12),
-                           "traffic": HBM_TRAFFIC_PMC_BYTES, "us_per_launch": tk * 1e6, "flops_per_launch": fl,
-                           "peak_note": "dense bf16 MFMA peak 2500 / 6 MFMA products per fp32 product" if x3
-                                        else "dense fp32 MFMA peak",
-                           "frac_of_f32_mfma_peak": fl / tk / (F32_MFMA_TFLOPS * 1e12)}
+            tk, fl = time_dominant_kernel(cfg, device)
+            x3 = _lib.load().mmvae_gemm_get_precision() == _lib.GEMM_PRECISION_BF16X3
+            # bf16x3: every fp32 product costs 6 bf16 MFMA products, so the matrix-core ceiling for ALGORITHMIC fp32
+            # flops is the dense bf16 peak / 6; the exact-f32 mode is bounded by the fp32 MFMA peak.
+            peak = BF16_DENSE_TFLOPS / 6.0 if x3 else F32_MFMA_TFLOPS
+            out["roofline"] = {"bound": "mfma",
+                               "kernel": ("gemm_x3_kernel<TN,128x160> (bf16x3 MFMA)" if x3 else "gemm_f32_kernel<TN> (f32 MFMA)")
+                                         + ": dW of a G-wide layer",
+                               "achieved": fl / tk / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl / tk / (peak * 1e12),
+                               "traffic": HBM_TRAFFIC_PMC_BYTES, "us_per_launch": tk * 1e6, "flops_per_launch": fl,
+                               "peak_note": "dense bf16 MFMA peak 2500 / 6 MFMA products per fp32 product" if x3
+                                            else "dense fp32 MFMA peak",
+                               "frac_of_f32_mfma_peak": fl / tk / (F32_MFMA_TFLOPS * 1e12)}
+        else:
+            out["rehearsal"] = "CPU plumbing over gloo: launch / exchange / timing logic only, not a measurement"
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_seconds)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

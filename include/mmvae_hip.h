@@ -153,7 +153,9 @@ int mmvae_fc_epilogue_fwd(int B, int N, const float* in, int64_t ld_in, int n_sl
 
 /* Backward of the same layer tail.
  *   dd   = row_scale[b] * (sum_s din[s] + addend)        (grad wrt d; addend/row_scale optional)
- *   da   = mask ? dd * mask / (1 - p) : dd
+ *   da   = (mask ? dd * mask / (1 - p) : dd) + addend_a    (addend_a: optional gradient on the PRE-dropout activation
+ *                                                           a -- the hidden representation FCBlock.forward returns,
+ *                                                           components.py:308-314 -- which bypasses the keep mask)
  *   dy   = relu ? da * 1[a > 0] : da                      (a: forward a_out or d_out when no dropout)
  *   BN training backward: dbeta = sum_b dy, dgamma = sum_b dy*xhat, dz = gamma*invstd*(dy - dbeta/B - xhat*dgamma/B)
  *   no BN: dz = dy
@@ -164,7 +166,7 @@ int mmvae_fc_epilogue_fwd(int B, int N, const float* in, int64_t ld_in, int n_sl
  * they are summed into dbias when dbias is non-NULL.  With dbias == NULL the caller finishes them itself, e.g.
  * together with other pending reductions in one mmvae_sum_parts_batch launch. */
 int mmvae_fc_epilogue_bwd(int B, int N, const float* din, int64_t ld_in, int n_slabs, const float* addend,
-                          const float* row_scale, const uint8_t* keep_mask, float dropout_p, int relu,
+                          const float* addend_a, const float* row_scale, const uint8_t* keep_mask, float dropout_p, int relu,
                           const float* a, const float* z, const float* gamma, const float* save_mean,
                           const float* save_invstd, int has_bn, float* dz_out, int64_t ld_out, float* dbias,
                           float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes,

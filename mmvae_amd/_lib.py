@@ -67,7 +67,7 @@ PROTOTYPES = {
     ),
     "mmvae_fc_epilogue_bwd": (
         _i,
-        [_i, _i, _p, _l, _i, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _i, _p, _l, _p, _p, _p, _p, _z, _p],
+        [_i, _i, _p, _l, _i, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _i, _p, _l, _p, _p, _p, _p, _z, _p],
     ),
     "mmvae_layernorm_fwd": (_i, [_i, _i, _p, _l, _f, _p, _l, _p, _p, _p]),
     "mmvae_layernorm_bwd": (_i, [_i, _i, _p, _l, _p, _l, _p, _p, _l, _p]),

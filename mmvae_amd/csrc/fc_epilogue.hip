@@ -200,6 +200,7 @@ struct BwdArgs {
     int64_t ld_in, slab_stride;
     int n_slabs;
     const float* addend;
+    const float* addend_a;  // gradient on the pre-dropout activation: added behind the keep mask
     const float* row_scale;
     const uint8_t* mask;
     float keep_scale;
@@ -224,6 +225,7 @@ __device__ __forceinline__ float bwd_dy(const BwdArgs& a, int r, int c, float g)
     if (a.addend) g += a.addend[oo];
     if (a.row_scale) g *= a.row_scale[r];
     if (a.mask) g = a.mask[(int64_t)r * a.N + c] ? g * a.keep_scale : 0.f;
+    if (a.addend_a) g += a.addend_a[oo];
     if (a.relu) g = (a.a[oo] > 0.f) ? g : 0.f;
     return g;
 }
@@ -429,7 +431,7 @@ extern "C" int mmvae_fc_epilogue_fwd(int B, int N, const float* in, int64_t ld_i
 }
 
 extern "C" int mmvae_fc_epilogue_bwd(int B, int N, const float* din, int64_t ld_in, int n_slabs, const float* addend,
-                                     const float* row_scale, const uint8_t* keep_mask, float dropout_p, int relu,
+                                     const float* addend_a, const float* row_scale, const uint8_t* keep_mask, float dropout_p, int relu,
                                      const float* a_act, const float* z, const float* gamma, const float* save_mean,
                                      const float* save_invstd, int has_bn, float* dz_out, int64_t ld_out, float* dbias,
                                      float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes,
@@ -447,6 +449,7 @@ extern "C" int mmvae_fc_epilogue_bwd(int B, int N, const float* din, int64_t ld_
     a.slab_stride = (int64_t)B * ld_in;
     a.n_slabs = n_slabs;
     a.addend = addend;
+    a.addend_a = addend_a;
     a.row_scale = row_scale;
     a.mask = keep_mask;
     a.keep_scale = keep_mask ? 1.0f / (1.0f - dropout_p) : 1.f;

@@ -722,8 +722,9 @@ class _Plan:
         def call():
             din_ptr = _p(din) if din is not None else plan.slab.data_ptr()
             ws = own_ws if own_ws is not None else plan.fcws
+            # `addend` is a gradient on the hidden representation = the activation BEFORE dropout: it bypasses the mask
             rc = plan.lib.mmvae_fc_epilogue_bwd(
-                rows, l.n_out, din_ptr, l.n_out, S_in, _p(addend), None, _p(l.mask), l.p, int(l.relu),
+                rows, l.n_out, din_ptr, l.n_out, S_in, None, _p(addend), None, _p(l.mask), l.p, int(l.relu),
                 _p(relu_src) if l.relu else None, _p(l.z), _p(l.bn.weight) if has_bn else None, _p(l.mean),
                 _p(l.invstd), int(has_bn), _p(l.dz), l.n_out, _p(l.gb) if own_ws is None else None,
                 _p(l.ggamma) if has_bn else None, _p(l.gbeta) if has_bn else None, ws.data_ptr(), ws.numel() * 4, _s())
@@ -758,7 +759,7 @@ class _Plan:
 
         def call():
             ws = own_ws if own_ws is not None else plan.fcws
-            rc = plan.lib.mmvae_fc_epilogue_bwd(rows, N, _p(din), N, 1, _p(addend), _p(row_scale), None, 0.0, 0, None, None,
+            rc = plan.lib.mmvae_fc_epilogue_bwd(rows, N, _p(din), N, 1, _p(addend), None, _p(row_scale), None, 0.0, 0, None, None,
                                                 None, None, None, 0, _p(dz_out), N, _p(dbias) if own_ws is None else None,
                                                 None, None, ws.data_ptr(), ws.numel() * 4, _s())
             if rc != 0:

@@ -61,19 +61,14 @@ class FCLayerFn(torch.autograd.Function):
         ga = ga.contiguous() if ga is not None else None
         if gd is None and ga is None:
             return (None,) * 10
-        addend = None
-        if ctx.use_mask and ga is not None and gd is not None:
-            # grad on the pre-dropout tensor bypasses the mask: fold the mask into gd first
-            gd, _, _, _ = ops.fc_epilogue_bwd(gd, keep_mask=mask, dropout_p=ctx.p, want_dbias=False)
-            mask_arg, p = None, 0.0
-            addend = ga
-        elif gd is None:
-            gd, mask_arg, p = ga, None, 0.0
+        # gd: gradient on the layer output d (through the keep mask); ga: gradient on the pre-dropout activation, which
+        # bypasses the mask (addend_a of the layer-tail kernel)
+        if gd is None:
+            gd, ga, mask_arg, p = ga, None, None, 0.0
         else:
             mask_arg, p = (mask, ctx.p) if ctx.use_mask else (None, 0.0)
-            addend = ga
         dz, dbias, dgamma, dbeta = ops.fc_epilogue_bwd(
-            gd, addend=addend, keep_mask=mask_arg, dropout_p=p, relu=ctx.relu, a=a if ctx.relu else None, z=z,
+            gd, addend_a=ga, keep_mask=mask_arg, dropout_p=p, relu=ctx.relu, a=a if ctx.relu else None, z=z,
             gamma=gamma, mean=mean, invstd=invstd, has_bn=ctx.has_bn)
         dw = ops.gemm(ops.GEMM_TN, dz, x) if ctx.needs_input_grad[1] else None
         dx = ops.gemm(ops.GEMM_NN, dz, weight) if ctx.needs_input_grad[0] else None
@@ -118,17 +113,11 @@ class LayerTailFn(torch.autograd.Function):
         ga = ga.contiguous() if ga is not None else None
         if gd is None and ga is None:
             return None, None, None, None
-        addend, mask_arg, p = None, None, 0.0
-        if ctx.use_mask and gd is not None and ga is not None:  # the pre-dropout gradient bypasses the mask
-            gd, _, _, _ = ops.fc_epilogue_bwd(gd, keep_mask=mask, dropout_p=ctx.p, want_dbias=False)
-            addend = ga
-        elif gd is None:
-            gd = ga
+        if gd is None:
+            gd, ga, mask_arg, p = ga, None, None, 0.0
         else:
-            addend = ga
-            if ctx.use_mask:
-                mask_arg, p = mask, ctx.p
-        dx, _, _, _ = ops.fc_epilogue_bwd(gd, addend=addend, keep_mask=mask_arg, dropout_p=p, relu=ctx.relu,
+            mask_arg, p = (mask, ctx.p) if ctx.use_mask else (None, 0.0)
+        dx, _, _, _ = ops.fc_epilogue_bwd(gd, addend_a=ga, keep_mask=mask_arg, dropout_p=p, relu=ctx.relu,
                                           a=a if ctx.relu else None, want_dbias=False)
         return dx, None, None, None
 

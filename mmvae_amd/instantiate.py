@@ -8,6 +8,7 @@ this package's mirror classes (same names, same arguments), so reference YAML fi
 from __future__ import annotations
 
 import importlib
+import os
 from typing import Any
 
 import yaml
@@ -37,6 +38,8 @@ def build(node: Any, key: str = "") -> Any:
         return [build(v, key) for v in node]
     if isinstance(node, str) and key in _CLASS_VALUED_KEYS:
         return resolve(node)
+    if isinstance(node, str) and "$" in node:  # ${VAR} in path-like values (labels_dir, conditionals_directory)
+        return os.path.expandvars(node)
     return node
 
 

@@ -459,7 +459,9 @@ class Encoder(nn.Module):
 
     def __init__(self, latent_dim: int, fc_block_config: FCBlockConfig,
                  distribution: Union[Literal["ln"], Literal["normal"]] = "normal", return_dist: bool = False,
-                 hidden_z: bool = False, var_eps: float = 1e-4):
+                 hidden_z: bool = False, var_eps: float = 1e-4, n_samples: int = 1, elbo_mode: str = "analytic"):
+        """`n_samples`, `elbo_mode`: arguments of the K-sample extension (not in the reference; the defaults are the
+        reference's single-sample ELBO), so that a YAML file can carry BASELINE configs 3 and 5."""
         super().__init__()
         self.fc = FCBlock(fc_block_config)
         n_hidden = fc_block_config.layers[-1]
@@ -470,11 +472,13 @@ class Encoder(nn.Module):
         self.return_dist = return_dist
         self.hidden_z = hidden_z
         self.explicit_eps: Optional[torch.Tensor] = None  # parity mode: noise consumed by the next forward
-        self.n_samples: int = 1  # K of the K-sample extension (1 = the reference)
+        self.n_samples: int = int(n_samples)  # K of the K-sample extension (1 = the reference)
         # "analytic": loss = recon + kl_weight * analytic KL (the reference, vae.py:136-152; with K samples the
         # reconstruction term is their log-mean-exp).  "iwae": opt-in full importance-weighted objective:
         # the sampled log q(z) - log p(z) sits inside the log-mean-exp; runs in the captured engine only.
-        self.elbo_mode: str = "analytic"
+        if elbo_mode not in ("analytic", "iwae"):
+            raise ValueError(f"elbo_mode must be 'analytic' or 'iwae', got {elbo_mode!r}")
+        self.elbo_mode: str = elbo_mode
 
     @property
     def n_layers(self) -> int:

@@ -260,6 +260,7 @@ def fc_epilogue_bwd(
     din: torch.Tensor,
     *,
     addend: Optional[torch.Tensor] = None,
+    addend_a: Optional[torch.Tensor] = None,
     row_scale: Optional[torch.Tensor] = None,
     keep_mask: Optional[torch.Tensor] = None,
     dropout_p: float = 0.0,
@@ -276,7 +277,8 @@ def fc_epilogue_bwd(
     dgamma_out: Optional[torch.Tensor] = None,
     dbeta_out: Optional[torch.Tensor] = None,
 ):
-    """Backward of the layer tail.  din: [B,N] or slabs [S,B,N].  Returns (dz, dbias, dgamma, dbeta)."""
+    """Backward of the layer tail.  din: [B,N] or slabs [S,B,N]; `addend`: further gradient on the layer output d;
+    `addend_a`: gradient on the pre-dropout activation (bypasses the keep mask).  Returns (dz, dbias, dgamma, dbeta)."""
     lib = _lib.load()
     _chk(din, "din")
     if din.dim() == 2:
@@ -285,7 +287,7 @@ def fc_epilogue_bwd(
         raise ValueError("din must be contiguous")
     S, B, N = din.shape
     dev = din.device
-    for name, t in (("addend", addend), ("a", a), ("z", z)):
+    for name, t in (("addend", addend), ("addend_a", addend_a), ("a", a), ("z", z)):
         _chk(t, name)
         if t is not None and (tuple(t.shape) != (B, N) or not t.is_contiguous()):
             raise ValueError(f"{name} must be contiguous [B,N]")
@@ -299,7 +301,7 @@ def fc_epilogue_bwd(
     nws = lib.mmvae_fc_workspace_bytes(B, N)
     ws = workspace(nws, dev, "fc")
     rc = lib.mmvae_fc_epilogue_bwd(
-        B, N, _ptr(din), N, S, _ptr(addend), _ptr(row_scale), _ptr(keep_mask), float(dropout_p), int(relu), _ptr(a),
+        B, N, _ptr(din), N, S, _ptr(addend), _ptr(addend_a), _ptr(row_scale), _ptr(keep_mask), float(dropout_p), int(relu), _ptr(a),
         _ptr(z), _ptr(gamma), _ptr(mean), _ptr(invstd), int(has_bn), _ptr(dz), N, _ptr(dbias), _ptr(dgamma),
         _ptr(dbeta), _ptr(ws), nws, _stream(),
     )

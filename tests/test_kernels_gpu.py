@@ -177,6 +177,7 @@ def test_fc_epilogue_fwd_bwd(ops, B, N, S, has_bn, p):
     mask = (torch.rand(B, N, generator=torch.Generator().manual_seed(7)) >= p).to(torch.uint8) if p > 0 else None
     dd = rnd(2, B, N, seed=8)
     addend = rnd(B, N, seed=9)
+    addend_a = rnd(B, N, seed=10)  # gradient on the pre-dropout activation (a hidden representation): bypasses the mask
     # ---- CPU reference with autograd
     sl = slabs.clone().requires_grad_(True)
     bi, ga, be = (t.clone().requires_grad_(True) for t in (bias, gamma, beta))
@@ -188,7 +189,7 @@ def test_fc_epilogue_fwd_bwd(ops, B, N, S, has_bn, p):
         y = z
     a = torch.relu(y)
     d = a * mask.float() / (1 - p) if mask is not None else a
-    (d * (dd.sum(0) + addend)).sum().backward()
+    ((d * (dd.sum(0) + addend)).sum() + (a * addend_a).sum()).backward()
     # ---- HIP
     bn = None
     rm_d, rv_d = dev(rm.clone()), dev(rv.clone())
@@ -206,7 +207,8 @@ def test_fc_epilogue_fwd_bwd(ops, B, N, S, has_bn, p):
         torch.testing.assert_close(rv_d.cpu(), 0.99 * rv + 0.01 * z.detach().var(0, unbiased=True), rtol=1e-5, atol=1e-6)
         assert int(nbt) == 1
     dz, dbias, dgamma, dbeta = ops.fc_epilogue_bwd(
-        dev(dd), addend=dev(addend), keep_mask=dev(mask) if mask is not None else None, dropout_p=p, relu=True,
+        dev(dd), addend=dev(addend), addend_a=dev(addend_a), keep_mask=dev(mask) if mask is not None else None,
+        dropout_p=p, relu=True,
         a=f["a"], z=f["z"], gamma=dev(gamma) if has_bn else None, mean=f["mean"], invstd=f["invstd"], has_bn=has_bn)
     assert rel_l2(dz, sl.grad[0]) < 2e-5
     if has_bn:
