@@ -397,6 +397,7 @@ class StepEngine:
         ev = self._pending.pop(expert_id, None)
         if ev is not None:  # this expert's previous (deferred) update must land before its parameters are read
             torch.cuda.current_stream().wait_event(ev)
+        self.last_plan = plan  # introspection (tests read the activations the step left in its buffers)
         ev = plan.run()
         if ev is not None:
             self._pending[expert_id] = ev

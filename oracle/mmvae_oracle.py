@@ -200,10 +200,31 @@ def init_state(spec: ModelSpec, seed: int = 0) -> Dict[str, torch.Tensor]:
 
 
 # ------------------------------------------------------------------------------------------------------- forward
+class _ReluWithGivenSlope(torch.autograd.Function):
+    """relu(y) whose backward multiplies by a GIVEN 0/1 slope instead of 1[y > 0].  At a pre-activation within rounding
+    distance of zero the slope an implementation takes is decided by the last bit of a 1000-term dot product; a full-size
+    step has 10^7-10^8 ReLU inputs, so two correct fp32 implementations disagree on a handful of them, and each
+    disagreement moves the gradients by ~1e-3 (measured).  Parity tests therefore hand the oracle
+    the slopes the implementation under test took and check separately that they differ from 1[y > 0] only at
+    pre-activations next to zero."""
+
+    @staticmethod
+    def forward(ctx, y, slope):
+        ctx.save_for_backward(slope)
+        return torch.relu(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        (slope,) = ctx.saved_tensors
+        return g * slope.to(g.dtype), None
+
+
 def fcblock_forward(sd, prefix: str, spec: FCSpec, x, training: bool, masks: Optional[Dict[str, torch.Tensor]],
-                    hp: HParams, bn_updates: Optional[dict] = None):
+                    hp: HParams, bn_updates: Optional[dict] = None, relu_slopes: Optional[dict] = None,
+                    relu_inputs: Optional[dict] = None):
     """FCBlock.forward (components.py:292-314): per layer Linear -> BN -> LN -> act -> Dropout; hidden collected
-    after "af" (pre-dropout) for layers with return_hidden."""
+    after "af" (pre-dropout) for layers with return_hidden.  `relu_slopes` {layer prefix: 0/1 tensor}: backward slopes of
+    the ReLUs given by the caller (_ReluWithGivenSlope); `relu_inputs`: filled with every ReLU's input (detached)."""
     hidden = []
     for i in range(spec.n_layers):
         p = f"{prefix}.fc_layers.{i}"
@@ -229,7 +250,12 @@ def fcblock_forward(sd, prefix: str, spec: FCSpec, x, training: bool, masks: Opt
         if spec.use_layer_norm[i]:  # :281 LayerNorm(elementwise_affine=False)
             x = F.layer_norm(x, (x.shape[-1],))
         if spec.relu[i]:  # :282-286
-            x = torch.relu(x)
+            if relu_inputs is not None:
+                relu_inputs[p] = x.detach()
+            if relu_slopes is not None and p in relu_slopes:
+                x = _ReluWithGivenSlope.apply(x, relu_slopes[p])
+            else:
+                x = torch.relu(x)
             if spec.return_hidden[i]:  # :312-313
                 hidden.append(x)
         if spec.dropout_rate[i] > 0 and training:  # :287-288
@@ -275,13 +301,15 @@ def conditional_layers(spec: CondSpec, sd, z, cond: Dict[str, List[str]], specie
 
 
 def model_forward(spec: ModelSpec, sd, x, expert_id: str, eps, training: bool, masks, hp: HParams, bn_updates=None,
-                  cond: Optional[Dict[str, List[str]]] = None, cond_order: Optional[List[str]] = None):
+                  cond: Optional[Dict[str, List[str]]] = None, cond_order: Optional[List[str]] = None,
+                  relu_slopes: Optional[dict] = None, relu_inputs: Optional[dict] = None):
     """CMMVAE.forward (modules/cmmvae.py:85-113) with BaseVAE.forward (modules/vae.py:98-102) and Encoder.forward
     (components.py:783-809).  eps: [B,Z] (K = 1, the reference) or [K,B,Z] (extension).  cond / cond_order: per-row
     condition names per key and the selection order of this forward (models with conditional layers)."""
     enc, dec = spec.experts[expert_id]
-    shared, _ = fcblock_forward(sd, f"experts.{expert_id}.encoder", enc, x, training, masks, hp, bn_updates)
-    q, hidden = fcblock_forward(sd, "vae.encoder.fc", spec.vae_encoder, shared, training, masks, hp, bn_updates)
+    rk = dict(relu_slopes=relu_slopes, relu_inputs=relu_inputs)
+    shared, _ = fcblock_forward(sd, f"experts.{expert_id}.encoder", enc, x, training, masks, hp, bn_updates, **rk)
+    q, hidden = fcblock_forward(sd, "vae.encoder.fc", spec.vae_encoder, shared, training, masks, hp, bn_updates, **rk)
     mu = F.linear(q, sd["vae.encoder.mean_encoder.weight"], sd["vae.encoder.mean_encoder.bias"])  # :791
     var = torch.exp(F.linear(q, sd["vae.encoder.var_encoder.weight"], sd["vae.encoder.var_encoder.bias"])) + spec.var_eps
     std = var.sqrt()  # :798 Normal(q_m, q_v.sqrt())
@@ -293,8 +321,8 @@ def model_forward(spec: ModelSpec, sd, x, expert_id: str, eps, training: bool, m
         z = conditional_layers(spec.conditionals, sd, z, cond, expert_id, cond_order or spec.conditionals.keys,
                                training, hp)
     zk = z.reshape(-1, z.shape[-1])
-    sh, _ = fcblock_forward(sd, "vae.decoder", spec.vae_decoder, zk, training, masks, hp, bn_updates)
-    xhat, _ = fcblock_forward(sd, f"experts.{expert_id}.decoder", dec, sh, training, masks, hp, bn_updates)
+    sh, _ = fcblock_forward(sd, "vae.decoder", spec.vae_decoder, zk, training, masks, hp, bn_updates, **rk)
+    xhat, _ = fcblock_forward(sd, f"experts.{expert_id}.decoder", dec, sh, training, masks, hp, bn_updates, **rk)
     return {"mu": mu, "std": std, "z": z, "xhat": xhat, "hidden": hidden, "shared_xhat": sh}
 
 
@@ -402,15 +430,19 @@ def clip_and_adam(names, sd, grads, opt_state, group: str, clip: Optional[float]
 # ------------------------------------------------------------------------------------------------------ the step
 def train_step(spec: ModelSpec, sd: Dict[str, torch.Tensor], opt_state: dict, x: torch.Tensor, expert_id: str,
                eps: torch.Tensor, masks: Optional[dict], labels: Optional[Dict[str, torch.Tensor]], kl_weight: float,
-               hp: HParams, cond: Optional[Dict[str, List[str]]] = None, cond_order: Optional[List[str]] = None):
+               hp: HParams, cond: Optional[Dict[str, List[str]]] = None, cond_order: Optional[List[str]] = None,
+               relu_slopes: Optional[dict] = None):
     """CMMVAEModel.training_step (models/cmmvae_model.py:138-217).  Returns (outputs, new_sd); opt_state is updated
     in place.  Order: forward, elbo, [D phase: backward/clip/Adam per adversary], [G phase with updated adversaries],
-    backward of loss + adv_weight * sum(adv), clip vae, clip expert, Adam vae, Adam expert."""
+    backward of loss + adv_weight * sum(adv), clip vae, clip expert, Adam vae, Adam expert.
+    `relu_slopes`: see _ReluWithGivenSlope; the outputs then also carry every ReLU's input as out["relu_inputs"]."""
     groups = group_param_names(spec)
     live = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
     bn_updates: dict = {}
     K = eps.shape[0] if eps.dim() == 3 else 1
-    fwd = model_forward(spec, live, x, expert_id, eps, True, masks, hp, bn_updates, cond, cond_order)
+    relu_inputs = {} if relu_slopes is not None else None
+    fwd = model_forward(spec, live, x, expert_id, eps, True, masks, hp, bn_updates, cond, cond_order, relu_slopes,
+                        relu_inputs)
     if hp.elbo_mode == "iwae":
         e = elbo_iwae(fwd["mu"], fwd["std"], x, fwd["xhat"], kl_weight, K, eps, fwd["z"])
     else:
@@ -421,6 +453,8 @@ def train_step(spec: ModelSpec, sd: Dict[str, torch.Tensor], opt_state: dict, x:
         "z": fwd["z"].detach(), "xhat": fwd["xhat"].detach(), "hidden": [h.detach() for h in fwd["hidden"]],
         "mu": fwd["mu"].detach(), "std": fwd["std"].detach(), "grad_norms": {},
     }
+    if relu_inputs is not None:
+        out["relu_inputs"] = relu_inputs
     new_sd = dict(sd)
     total = e["loss"]
     if spec.adversarials:

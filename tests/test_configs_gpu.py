@@ -7,11 +7,18 @@
   * C3 (K = 10) and C5 (K = 5): the K-sample extension has no counterpart in the reference (parity unpinned); the
     engine is checked against the oracle run on the host with the same explicit eps / masks.
 Tolerances (fp32, stated): losses rtol 1e-4 (sums of 10^7 terms), gradient norms rtol 5e-5 (1e-4 for K > 1), gradients
-and post-Adam parameters rel-L2 <= 1e-4 through norm + 256 sampled entries per tensor (small tensors in full)."""
+and post-Adam parameters rel-L2 <= 1e-4 -- against the reference through norm + 256 sampled entries per tensor (small
+tensors in full), and as FULL tensors against the oracle run on the host at the ReLU slopes the engine took.
+
+ReLU kinks.  A step at these sizes evaluates 10^7-10^8 ReLUs; a handful of their inputs lie within rounding distance of
+zero, where the slope an fp32 implementation takes is decided by the last bit of a 1000-term dot product -- and one
+flipped slope at the output layer moves every encoder gradient by ~5e-4 (measured: 3 of 5 000 500 outputs at mid_odd, the
+reference's own fp32-vs-fp64 gap being 1e-6).  So every step is checked in two ways: (1) against the oracle at the
+engine's own slopes, which must differ from 1[y > 0] only where |y| <= 1e-4 rms(y); (2) against the reference's fixture:
+scalars always, tensors in the steps without such a kink (tests/mirror_utils.check_against_checksums)."""
 import ctypes
 import json
 import os
-import tempfile
 
 import numpy as np
 import pandas as pd
@@ -72,68 +79,38 @@ def test_full_size_engine_steps_match_reference(name):
     assert MU.replay_training.last_engine, "the captured engine must have taken this configuration"
     _x3_planned(case)
     worst = MU.check_against_checksums(case, z, results)
+    assert worst["steps_with_kinks"] < len(results), "no step of this case could be compared with the reference's tensors"
     _note(name, {**worst, **seen})
 
 
-def test_mid_case_module_path_matches_reference():
-    case, z, results = MU.replay_regen("mid_odd", "cuda", use_engine=False)
-    _note("mid_odd(module path)", MU.check_against_checksums(case, z, results))
-
-
-def _k_sample_steps_against_oracle(case, K, steps, seed=5):
-    """Engine steps with K samples vs oracle.train_step on the host: same initial state, same explicit eps / masks."""
-    from oracle import mmvae_oracle as O  # the checker
-
-    spec, hp = H.spec_from_case(case), H.hparams_from_case(case)
-    g = torch.Generator().manual_seed(seed)
-    worst = {}
-    with tempfile.TemporaryDirectory() as d:
-        model = MU.build_regen_mirror(case, "cuda", d, use_engine=True)
-        sd = {k: v.detach().cpu().clone() for k, v in model.module.state_dict().items()}
-        model.train()
-        model.trainer.set_stage("training")
-        model.module.vae.encoder.n_samples = K
-        stream = H.RegenStream(case)
-        opt_state = {}
-        skip = H.bn_fed_biases(spec)
-        for t in range(steps):
-            eid = case["schedule"][t % len(case["schedule"])]
-            x, _, masks, labels = stream.step(t, eid)
-            eps = torch.randn(K, x.shape[0], case["Z"], generator=g)
-            ref, sd = O.train_step(spec, sd, opt_state, x, eid, eps, masks, labels or None, 1.0, hp)
-            model.kl_annealing_fn.kl_weight = 1.0
-            model.module.vae.encoder.explicit_eps = eps.cuda()
-            model.module.experts[eid].encoder.explicit_masks = {int(k.split(".")[4]): m.cuda() for k, m in masks.items()}
-            model.logged.clear()
-            model.training_step((x.cuda(), pd.DataFrame({"dummy": [0] * x.shape[0]}), eid), t)
-            model._flush_engine()
-            torch.cuda.synchronize()
-            got = {k: float(v.detach()) if torch.is_tensor(v) else v for k, v in model.logged.items()}
-            for k, r in (("loss", ref["total_loss"]), ("recon_loss", ref["recon_loss"]), ("kl_loss", ref["kl_loss"])):
-                dev = abs(got[f"{k}/training/{eid}"] - float(r)) / abs(float(r))
-                worst[k] = max(worst.get(k, 0.0), dev)
-                assert dev <= 1e-4, (t, k, got[f"{k}/training/{eid}"], float(r))
-            for k, name in (("vae", "grad_norms/vae"), (f"expert_{eid}", f"grad_norms/expert_{eid}")):
-                dev = abs(got[name] - float(ref["grad_norms"][k])) / float(ref["grad_norms"][k])
-                worst["grad_norm"] = max(worst.get("grad_norm", 0.0), dev)
-                assert dev <= 1e-4, (t, name, got[name], float(ref["grad_norms"][k]))
-            for n, v in model.module.state_dict().items():
-                if n in skip or v.dtype == torch.int64 or n.endswith("running_mean"):
-                    continue
-                dev = H.rel_l2(v, sd[n])
-                worst["param"] = max(worst.get("param", 0.0), dev)
-                assert dev < 1e-4, (t, n, dev)
-        assert model._engine, "the captured engine must have taken this configuration"
+def _k_sample_steps(name, K, steps):
+    """The K-sample extension (no counterpart in the reference, parity unpinned) at a BASELINE size: engine steps against
+    the oracle on the host -- same regenerated states, same explicit eps [K, B, Z] and masks, the oracle at the engine's
+    ReLU slopes (K x B x G outputs: 10^8 ReLU inputs per step at config 3, a dozen of them within rounding of zero)."""
+    case, z, results = MU.replay_regen(name, "cuda", use_engine=True, steps=steps, K=K)
+    assert MU.replay_training.last_engine, "the captured engine must have taken this configuration"
+    worst = {"kinks": 0, "oracle_grad": 0.0, "oracle_param": 0.0}
+    for r in results:
+        eid, ref, L = r["eid"], r["oracle"], r["logged"]
+        for k, v in (("loss", ref["total_loss"]), ("recon_loss", ref["recon_loss"]), ("kl_loss", ref["kl_loss"])):
+            dev = abs(L[f"{k}/training/{eid}"] - float(v)) / abs(float(v))
+            worst[k] = max(worst.get(k, 0.0), dev)
+            assert dev <= 1e-4, (k, L[f"{k}/training/{eid}"], float(v))
+        for key, name in (("vae", "grad_norms/vae"), (f"expert_{eid}", f"grad_norms/expert_{eid}")):
+            dev = abs(L[name] - float(ref["grad_norms"][key])) / float(ref["grad_norms"][key])
+            worst["grad_norm"] = max(worst.get("grad_norm", 0.0), dev)
+            assert dev <= 1e-4, (name, L[name], float(ref["grad_norms"][key]))
+        worst["kinks"] += r["kinks"]
+        worst["oracle_grad"] = max(worst["oracle_grad"], r["oracle_grad"])
+        worst["oracle_param"] = max(worst["oracle_param"], r["oracle_param"])
     return worst
 
 
 def test_config3_k10_engine_matches_oracle():
     """BASELINE config 3: C2 with the K = 10 log-mean-exp ELBO (build-defined extension: parity unpinned by the reference)."""
-    case, _ = H.load_case("c2_full")
-    _note("c3 (K=10) vs oracle", _k_sample_steps_against_oracle(case, K=10, steps=2))
+    _note("c3 (K=10) vs oracle", _k_sample_steps("c2_full", K=10, steps=2))
 
 
 def test_config5_k5_engine_matches_oracle():
     """BASELINE config 5 per GPU: three modalities, 30 000 genes, B = 1 024, K = 5 -- one modality cycle."""
-    case, _ = H.load_case("c5_three_mod")
-    _note("c5 (K=5) vs oracle", _k_sample_steps_against_oracle(case, K=5, steps=3))
+    _note("c5 (K=5) vs oracle", _k_sample_steps("c5_three_mod", K=5, steps=3))
