@@ -14,8 +14,10 @@ ReLU kinks.  A step at these sizes evaluates 10^7-10^8 ReLUs; a handful of their
 zero, where the slope an fp32 implementation takes is decided by the last bit of a 1000-term dot product -- and one
 flipped slope at the output layer moves every encoder gradient by ~5e-4 (measured: 3 of 5 000 500 outputs at mid_odd, the
 reference's own fp32-vs-fp64 gap being 1e-6).  So every step is checked in two ways: (1) against the oracle at the
-engine's own slopes, which must differ from 1[y > 0] only where |y| <= 1e-4 rms(y); (2) against the reference's fixture:
-scalars always, tensors in the steps without such a kink (tests/mirror_utils.check_against_checksums)."""
+engine's own slopes, which must differ from 1[y > 0] only where |y| <= 1e-4 rms(y) -- gradients and post-step parameters
+as full tensors at 1e-4; (2) against the reference's fixture: losses always at 1e-4, tensors at 1e-4 in steps without
+such a kink and at 1e-2 otherwise (tests/mirror_utils.check_against_checksums).  The oracle itself is pinned against
+the same fixtures at 1e-4 on the CPU (tests/test_oracle_golden.py: same host arithmetic as the generator, same slopes)."""
 import ctypes
 import json
 import os
@@ -79,7 +81,6 @@ def test_full_size_engine_steps_match_reference(name):
     assert MU.replay_training.last_engine, "the captured engine must have taken this configuration"
     _x3_planned(case)
     worst = MU.check_against_checksums(case, z, results)
-    assert worst["steps_with_kinks"] < len(results), "no step of this case could be compared with the reference's tensors"
     _note(name, {**worst, **seen})
 
 
