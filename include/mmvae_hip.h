@@ -291,12 +291,6 @@ int mmvae_adam_prepare(int64_t n_partials, const float* partials, float max_norm
 int mmvae_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* state,
                     float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                     mmvae_stream_t stream);
-/* The same update over [0, n) on at most `max_blocks` workgroups (grid-stride): a throttled form for running an expert's
- * update on a second stream beside the latency-bound middle of another modality's step, where
- * the full-width launch would take the chip away from it.  max_blocks <= 0: as mmvae_adam_step. */
-int mmvae_adam_step_throttled(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                              const float* state, float lr, float beta1, float beta2, float eps, float weight_decay,
-                              float grad_scale, int max_blocks, mmvae_stream_t stream);
 
 /* Adam over a list of arena segments in ONE launch (one workgroup per job): the update of a conditional-layer model
  * touches only the parameter tensors that took part in the step -- torch.optim.Adam skips parameters whose .grad is

@@ -87,7 +87,6 @@ PROTOTYPES = {
     "mmvae_grad_sqnorm": (_i, [_l, _p, _p, _p]),
     "mmvae_adam_prepare": (_i, [_l, _p, _f, _f, _f, _f, _p, _u, _p]),
     "mmvae_adam_step": (_i, [_l, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _f, _p]),
-    "mmvae_adam_step_throttled": (_i, [_l, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _f, _i, _p]),
     "mmvae_adam_step_jobs": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _f, _p]),
     "mmvae_grad_sqnorm_jobs": (_i, [_i, _p, _p, _p, _p]),
     "mmvae_philox_keep_mask": (_i, [_l, _f, _p, _p, _u64, _i, _p]),

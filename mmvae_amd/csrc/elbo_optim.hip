@@ -1001,19 +1001,6 @@ extern "C" int mmvae_adam_step(int64_t n, float* param, const float* grad, float
     return MMVAE_OK;
 }
 
-extern "C" int mmvae_adam_step_throttled(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                                         const float* state, float lr, float beta1, float beta2, float eps,
-                                         float weight_decay, float grad_scale, int max_blocks, mmvae_stream_t stream) {
-    if (n <= 0 || !param || !grad || !exp_avg || !exp_avg_sq || !state) return MMVAE_ERR_ARG;
-    const int vec = aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq);
-    int blocks = grid_for(n, 1024, 4096);
-    if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
-    MMVAE_LAUNCH(adam_step_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, param, grad, exp_avg, exp_avg_sq,
-                 state, lr, beta1, beta2, eps, weight_decay, grad_scale, vec);
-    MMVAE_LAUNCH_CHECK();
-    return MMVAE_OK;
-}
-
 extern "C" int mmvae_adam_step_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, float* param, const float* grad,
                                     float* exp_avg, float* exp_avg_sq, const float* state, float lr, float beta1,
                                     float beta2, float eps, float weight_decay, float grad_scale, mmvae_stream_t stream) {

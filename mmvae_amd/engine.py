@@ -185,18 +185,6 @@ class StepEngine:
         # gradient norm and parameters are final after a device synchronisation rather than after engine.flush().
         self.lazy_adam = os.environ.get("MMVAE_DP_LAZY_ADAM", "0") != "0"
         self._lazy: Dict[str, tuple] = {}
-        # Background expert update (one rank, MMVAE_BG_ADAM): the active expert's Adam pass -- 1.15 GB of HBM traffic,
-        # 200 us at C2, nothing but memory -- is not run at the end of its step.  The step ends with the expert's norm
-        # and clip coefficient (logged as before); the update itself is stashed and runs on a second stream beside the
-        # NEXT step's latency-bound middle sections (the core layers between the chip-filling GEMMs of the G-wide
-        # layers, forward and backward), which leave HBM idle and whose expert is a different one (modalities alternate;
-        # the same expert twice in a row runs the stash first).  Throttled to MMVAE_BG_BLOCKS workgroups so that the
-        # core kernels keep their slots.
-        self.bg_adam = (os.environ.get("MMVAE_BG_ADAM", "0") != "0") and not self.overlap and self.world == 1
-        self.bg_blocks = int(os.environ.get("MMVAE_BG_BLOCKS", "512"))
-        self.bg_split = float(os.environ.get("MMVAE_BG_SPLIT", "0.4"))  # share of the arena updated beside the forward core
-        self._bg = None  # (expert id, plan, [chunk 0, chunk 1], launcher)
-        self.bg_stream = torch.cuda.Stream(device=self.device) if self.bg_adam else None
 
     def _configure_parallel(self) -> None:
         """Overlapped data parallelism (default whenever gradients are exchanged).  The active expert's parameters are
@@ -280,23 +268,10 @@ class StepEngine:
         """Make the current stream wait for every deferred expert update (before parameters are read elsewhere)."""
         for eid in list(self._lazy):
             self._finish_lazy(eid)
-        self._finish_bg()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
             torch.cuda.current_stream().wait_stream(self.small_stream)
             self._pending.clear()
-
-    def _finish_bg(self, only: Optional[str] = None) -> None:
-        """Run what is left of the stashed expert update on the current stream (`only`: if it belongs to that expert)."""
-        if self._bg is None or (only is not None and self._bg[0] != only):
-            return
-        _, _, chunks, launch = self._bg
-        self._bg = None
-        if self.bg_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.bg_stream)  # a chunk already started beside the last step
-        for c in chunks:
-            if c is not None:
-                launch(c)
 
     def _finish_lazy(self, expert_id: str) -> None:
         """Run the stashed tail of `expert_id`'s last step (clip + Adam over the reduced gradients) on this stream."""
@@ -362,7 +337,6 @@ class StepEngine:
         dropout, one rsample.  mode "validate": + fused reconstruction / ELBO; mode "embed": stops at z."""
         x = self._dense_f32(x)
         self._finish_lazy(expert_id)
-        self._finish_bg(only=expert_id)
         ev = self._pending.pop(expert_id, None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
@@ -420,7 +394,6 @@ class StepEngine:
         if plan.cond is not None:
             plan.cond.load(metadata)
         self._finish_lazy(expert_id)  # this expert's previous update (lazy: run here, on the reduced gradients)
-        self._finish_bg(only=expert_id)
         ev = self._pending.pop(expert_id, None)
         if ev is not None:  # this expert's previous (deferred) update must land before its parameters are read
             torch.cuda.current_stream().wait_event(ev)
@@ -836,8 +809,7 @@ class _Plan:
         else:
             self._emit(self.lib.mmvae_grad_sqnorm, a.numel, _p(a.grad), _p(opt.partials))
             partials = opt.partials
-        stashed = self.eng.bg_adam and opt is self.opt_exp and not step  # the update follows later: advance the counter now
-        flags = _lib.PREPARE_NORM | (_lib.PREPARE_ADVANCE if (advance and (step or stashed)) else 0)
+        flags = _lib.PREPARE_NORM | (_lib.PREPARE_ADVANCE if (advance and step) else 0)
         self._emit(self.lib.mmvae_adam_prepare, npart, _p(partials), max_norm, gs, b1, b2, _p(opt.state_dev), flags)
         if step:
             self._emit(self.lib.mmvae_adam_step, a.numel, _p(a.data), _p(a.grad), _p(a.exp_avg), _p(a.exp_avg_sq),
@@ -875,8 +847,6 @@ class _Plan:
             cur = self.fwd_layer(f"{self.eid}.enc{i}" if i < self.n_expert_enc else f"vae.enc{i}", l, cur, ld, B,
                                  training=train, mask_stream=i)
             ld = l.n_out
-            if i == 0 and train and eng.bg_adam:
-                self._cut(("bg_fork", 0))  # the core layers follow: the stashed update of the other expert runs beside them
         q, HV = cur, self.enc_layers[-1].n_out
         # ---- heads + reparameterisation
         self.mu = eng.buf("mu", (B, Z))
@@ -911,8 +881,6 @@ class _Plan:
         self.dP = eng.buf(f"dP.{G}", (R, G)) if train else None
         self.se_part = eng.buf(f"se_part.{G}", (T, R))
         self.w = eng.buf("w", (R,))
-        if train and eng.bg_adam:
-            self._cut(("bg_join", 0))  # the chip-filling GEMMs of the decoder's G-wide layer get the chip to themselves
         self._emit(lib.mmvae_decoder_recon_rows_f32, R, B, G, last.n_in, _p(cur), ld, _p(last.W), last.n_in,
                    _p(last.b), _p(x), ldx, None, 0, _p(self.dP), G, _p(self.se_part))
         self.recon_row = eng.buf("recon_row", (B,))
@@ -950,8 +918,6 @@ class _Plan:
             self._emit_fc_bwd(R, G, self.dP, None, None, None, last.gb)
         self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True)
         S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
-        if eng.bg_adam:
-            self._cut(("bg_fork", 1))  # backward through the core layers: second part of the stashed update
         rest = self.dec_layers[:-1]
         for j in range(len(rest) - 1, -1, -1):
             l = rest[j]
@@ -997,8 +963,6 @@ class _Plan:
             l = self.enc_layers[j]
             hid = l.a if l.a is not None else l.d
             addend = self.adv_grad_into.get(id(hid)) if l.return_hidden else None
-            if j == 0 and eng.bg_adam:
-                self._cut(("bg_join", 1))
             S_next = self.bwd_layer(l, din, S, addend=addend, need_dx="raw" if j > 0 else "none")
             din, S = None, S_next
             if early and j == self.n_expert_enc:  # the last VAE layer is done: what remains is the expert's encoder
@@ -1016,23 +980,12 @@ class _Plan:
         self.log_norm(self.opt_vae, "grad_norms/vae")
         if early:  # the expert's exchange + update leave the main stream: its norm is logged from the comm stream
             emit_log_copy()
-        bg = eng.bg_adam and self.cond is None
-        self.optimizer(self.opt_exp, self.clip_exp, exchange="deferred" if early else "inline", step=not bg, advance=True)
+        self.optimizer(self.opt_exp, self.clip_exp, exchange="deferred" if early else "inline")
         if early:
             self.exp_norm_log = torch.zeros(1, dtype=torch.float32, device=eng.device)
         else:
             self.log_norm(self.opt_exp, "grad_norms/expert")
             emit_log_copy()
-        if bg:  # the update itself: two throttled launches over the two parts of the arena, stashed for the next step
-            a, g_ = self.opt_exp.arena, self.opt_exp.param_groups[0]
-            b1, b2 = g_["betas"]
-            n0 = int(a.numel * eng.bg_split) // 4 * 4
-            self._cut(("bg_stash", self.opt_exp))
-            for lo, hi in ((0, n0), (n0, a.numel)):
-                self._emit(lib.mmvae_adam_step_throttled, hi - lo, a.data.data_ptr() + 4 * lo, a.grad.data_ptr() + 4 * lo,
-                           a.exp_avg.data_ptr() + 4 * lo, a.exp_avg_sq.data_ptr() + 4 * lo, _p(self.opt_exp.state_dev),
-                           g_["lr"], b1, b2, g_["eps"], g_["weight_decay"], 1.0 / eng.world, eng.bg_blocks)
-                self._cut(("bg_chunk_end",))
         self.segments.append(self._cur)
         self._cur = []
         # noise: Philox fills (production) or explicit buffers (parity mode), at the head of the program
@@ -1280,25 +1233,6 @@ class _Plan:
                     ev.record(eng.comm_stream)
                 eng._lazy[self.eid] = (self, list(items[idx + 1:]), launch, ev)
                 return None
-            if isinstance(it, tuple) and it[0].startswith("bg_"):
-                eng = self.eng
-                if it[0] == "bg_stash":  # everything behind this marker is the stashed update: chunk, end, chunk, end
-                    eng._finish_bg()  # (a stash nobody consumed: the step in between had no core sections to offer)
-                    rest = [r for r in items[idx + 1:] if not isinstance(r, tuple)]
-                    eng._bg = (self.eid, self, rest, launch)
-                    return None
-                if it[0] == "bg_fork" and eng._bg is not None and eng._bg[0] != self.eid:
-                    c = eng._bg[2][it[1]]
-                    if c is not None:
-                        eng.bg_stream.wait_stream(torch.cuda.current_stream())
-                        with torch.cuda.stream(eng.bg_stream):
-                            eng._bg[3](c)
-                        eng._bg[2][it[1]] = None
-                        if all(x is None for x in eng._bg[2]):
-                            eng._bg = None
-                if it[0] == "bg_join":
-                    torch.cuda.current_stream().wait_stream(eng.bg_stream)
-                continue
             if isinstance(it, tuple):
                 tail = self._exchange(it, tail)
             elif tail is None:
@@ -1322,8 +1256,6 @@ class _Plan:
     def run(self):
         """One step.  Returns the event behind the deferred expert update (overlapped data parallelism) or None."""
         self._runs += 1
-        if self._runs == 1:
-            self.segments = [seg for seg in self.segments if isinstance(seg, tuple) or seg]  # cuts may leave empty sections
         if self._runs == 1 or os.environ.get("MMVAE_NO_GRAPH", "0") != "0":
             # a real step; the first run also loads every code object before capture
             return self._run_program(self.segments, self._launch_eager)

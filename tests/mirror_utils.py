@@ -214,6 +214,8 @@ def engine_relu_slopes(model, eid):
     for j in range(len(plan.dec_layers)):
         names.append(f"vae.decoder.fc_layers.{j}" if j < n_vae_dec else f"experts.{eid}.decoder.fc_layers.{j - n_vae_dec}")
     slopes = {}
+    if plan.K > 1:  # softmax weights of the K samples: a sample whose weight underflowed to 0 has dP = 0 in every gene
+        slopes["__row_weight__"] = plan.w[: plan.R].detach().cpu()
     layers = plan.enc_layers + plan.dec_layers
     for name, l in zip(names, layers):
         if not l.relu:
@@ -255,6 +257,7 @@ def compare_with_oracle_at_given_slopes(model, case, eid, sd_in, count, moments,
     spec = H.spec_from_case(case)
     hp = hp or H.hparams_from_case(case)
     slopes = engine_relu_slopes(model, eid)
+    row_weight = slopes.pop("__row_weight__", None)
     ref, sd_new = O.train_step(spec, sd_in, oracle_opt_state(spec, count, moments), x, eid, eps, masks, labels or None,
                                kl_weight, hp, relu_slopes=slopes)
     n_diff = 0
@@ -267,6 +270,8 @@ def compare_with_oracle_at_given_slopes(model, case, eid, sd_in, count, moments,
         if name == list(slopes)[-1]:
             # output layer: the slope is read off dP = 2 (xhat - x) 1[P > 0], which is also zero where xhat == x exactly
             diff &= ~((y > 0) & ~slope.reshape(y.shape) & (torch.relu(y) == _rows_of(x, y.shape[0])))
+            if row_weight is not None:  # K-sample weights that underflowed: the row's gradient is zero whatever the slope
+                diff &= ~((row_weight < 1e-30).reshape(-1, 1) & ~slope.reshape(y.shape))
         n = int(diff.sum())
         if n:
             rms = float(y.double().pow(2).mean().sqrt())
