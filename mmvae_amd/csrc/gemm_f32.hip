@@ -1337,6 +1337,302 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
 #endif
 }
 
+// =====================================================================================================================
+// Wave-specialised bf16x3 kernel (r2): ONE 512-thread workgroup per CU, two roles.
+//
+//   waves 0-3  "multipliers": fragment reads + MFMAs only.  4 waves = one per SIMD; wave tile (BM/WGM) x (BN/WGN).
+//   waves 4-7  "stagers":     global loads of the fp32 operand tiles, the exact 3-way bf16 split (22 VALU per 4
+//                             elements) and the LDS plane writes -- for the k-tile AFTER the one being multiplied.
+//
+// What the 2 x 4-wave kernel above loses (profiles/r2_stamps: the first-dispatched workgroup of a CU needs 3 550 cycles
+// per k-tile for 1 536 cycles of its own MFMAs; its CU partner gets what is left, finishes 30 us later and runs the last
+// third of the kernel alone at 43 % matrix-core occupancy): every wave alternates between a matrix phase and a
+// 1 450-cycle staging phase (fragment waits, LDS write burst, two barriers), and two independent workgroups only
+// overlap those phases by luck.  Here the phases are different waves of the SAME SIMD: the stager's VALU / LDS-write /
+// VMEM instructions issue beside the multiplier's MFMAs (separate pipes; the SIMD's vector issue is needed 8 of an
+// MFMA's 32 cycles), LDS is double buffered (the whole 160 KiB: two images of (BM + BN) rows x 3 planes x 64 B), there
+// is one barrier per k-tile, placed inside the multiplier's k-tile BEFORE its last streamed block, when all its
+// fragment reads have returned -- the last block's MFMAs then cover the first fragment reads of the next k-tile.
+// The loop is persistent over the workgroup's items, and the stagers run ahead across item boundaries: the prologue of
+// the next output tile (HBM latency) hides behind the epilogue stores of the current one.
+//
+// LDS image: [plane][row][64 B] (32 k as bf16), no padding (2 x 79 872 B would not fit with 80-byte rows); the 16-byte
+// chunk c of row r sits at chunk c ^ ((r >> 2) & 3): conflict-free for the multipliers' ds_read_b128 (its 16-lane
+// groups cover rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}: (r >> 2) & 3 takes each value once per r % 4) and for
+// the stagers' ds_write_b64 (16 lanes = 2 whole rows).  The last 4 KiB of LDS are the epilogue's scratch.
+constexpr int XW_ROWB = 64;                   // bytes per row per plane
+constexpr int XW_SCRATCH = 4096;              // epilogue scratch behind the two images
+__device__ __forceinline__ int xw_off(int row, int chunk) { return row * XW_ROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// One operand of the stager: R rows, NU = R / 32 units per thread (a unit = 4 consecutive-k fp32 values of one row).
+// R = 256 over a rows-contiguous operand is handled as two 128-row halves of the 4 k x 4 row patch scheme of x3p_*.
+template <int FORM, int R>
+struct XwOperand {
+    static constexpr int NU = R / 32;
+    static constexpr bool SPLIT256 = (FORM == FORM_RC && R == 256);
+    unsigned off[NU];
+    f32x4 raw0[NU], raw1[NU];  // two raw register sets (two k-tiles in flight), selected at compile time
+
+    __device__ __forceinline__ void offsets(int64_t ld, int r0, int Rtot, int st) {
+        if constexpr (SPLIT256) {
+            unsigned lo[4], hi[4];
+            // the second half starts at r0 + 128 when that is inside the matrix; otherwise it re-reads the first half
+            // (its rows only reach accumulators that are never stored) -- never an address beyond the operand
+            const int r1 = (r0 + 128 < Rtot) ? r0 + 128 : r0;
+            x3p_offsets<FORM_RC, 128>(lo, ld, r0, Rtot, st);
+            x3p_offsets<FORM_RC, 128>(hi, ld, r1, Rtot, st);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                off[j] = lo[j];
+                off[4 + j] = hi[j] + (unsigned)(r1 - r0) * 4u;  // hi[] is relative to r1 (x3p_base adds r0 only)
+            }
+        } else {
+            x3p_offsets<FORM, R>(off, ld, r0, Rtot, st);
+        }
+    }
+    template <int SET>
+    __device__ __forceinline__ void load(const char* __restrict__ base) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + off[u]);
+            if (SET == 0)
+                raw0[u] = v;
+            else
+                raw1[u] = v;
+        }
+    }
+    // split unit u of raw set SET and write its three planes into the image at S (plane stride R * 64 B)
+    template <int SET>
+    __device__ __forceinline__ void stage_unit(int u, char* S, int st) {
+        const f32x4 (&raw)[NU] = SET == 0 ? raw0 : raw1;
+        uint2 pk[3];
+        int row, k4;
+        if constexpr (FORM == FORM_KC) {
+            x3p_split<FORM_KC, R, false>(raw, u, pk, st, 0, 0);
+            const int f = st + NT * u;
+            row = f >> 3;
+            k4 = f & 7;
+        } else if constexpr (SPLIT256) {
+            f32x4 half[4];
+            const int h = u >> 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) half[j] = raw[4 * h + j];
+            x3p_split<FORM_RC, 128, false>(half, u & 3, pk, st, 0, 0);
+            row = 128 * h + (st >> 3) * 4 + (u & 3);
+            k4 = st & 7;
+        } else {
+            x3p_split<FORM_RC, R, false>(raw, u, pk, st, 0, 0);
+            if (u < 4) {
+                row = (st >> 3) * 4 + u;
+                k4 = st & 7;
+            } else {  // rows 128..159 of a 160-row tile (DPP-transposed unit)
+                row = 128 + 4 * ((st >> 2) & 7) + (st & 3);
+                k4 = st >> 5;
+            }
+        }
+        const int o = xw_off(row, k4 >> 1) + (k4 & 1) * 8;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(S + p * (R * XW_ROWB) + o) = pk[p];
+    }
+};
+
+// position in the workgroup's stream of k-tiles (items = output tile x split-K slice, looped over persistently)
+struct XwCursor {
+    int w, kt, kt_end, bm, bn, z;
+    __device__ __forceinline__ bool valid(const GemmArgs& g) const { return w < g.nwork; }
+    __device__ __forceinline__ void open(const GemmArgs& g) {  // item w -> tile, slice, k-tile range
+        if (w >= g.nwork) return;
+        const int tiles = g.mt * g.nt;
+        z = w / tiles;
+        const int t = w - z * tiles;
+        bm = t % g.mt;
+        bn = t / g.mt;
+        kt = z * g.ktiles_per_split;
+        kt_end = min(kt + g.ktiles_per_split, g.ktiles);
+    }
+    __device__ __forceinline__ bool advance(const GemmArgs& g, int nwg) {  // next k-tile; true when a new item began
+        if (++kt < kt_end) return false;
+        w += nwg;
+        open(g);
+        return true;
+    }
+};
+
+template <int AFORM, int BFORM, int BM, int BN, int WGM, int WGN, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
+    static_assert(WGM * WGN == 4, "4 multiplier wavefronts");
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr bool KEEP_A = TM <= TN;  // fragments of the short side stay in registers over a k-step, the long side streams
+    constexpr int TK = KEEP_A ? TM : TN, TL = KEEP_A ? TN : TM;
+    constexpr int PA = BM * XW_ROWB, PB = BN * XW_ROWB;       // plane strides
+    constexpr int IMG = 3 * (PA + PB);                        // one image (A planes, then B planes)
+    static_assert(2 * IMG + XW_SCRATCH <= 160 * 1024, "two images + scratch must fit the CU's LDS");
+    __shared__ __attribute__((aligned(16))) char lds[2 * IMG + XW_SCRATCH];
+
+    const int tid = threadIdx.x;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    float* scratch = reinterpret_cast<float*>(lds + 2 * IMG);
+    // workgroup barriers an item's epilogue contains (the stagers take part in them)
+    const int epi_barriers = (EPI == EPI_RECON) ? 2 : (g.sq_part ? 2 : 0);
+
+    if (tid >= NT) {
+        // ------------------------------------------------------------------------------------------------ stagers
+        const int st = tid - NT;
+        XwOperand<AFORM, BM> oa;
+        XwOperand<BFORM, BN> ob;
+        XwCursor ld_c;  // the k-tile the next load fetches
+        XwCursor br_c;  // the k-tile whose barrier comes next (= the one the multipliers work on)
+        ld_c.w = br_c.w = L;
+        ld_c.open(g);
+        br_c.open(g);
+        if (!br_c.valid(g)) return;
+        // Branch-free on purpose: offsets are recomputed with every load (a dozen VALU instructions; the stagers have
+        // issue slots to spare) and a load past the end of the stream re-reads the last k-tile -- a wave-uniform branch
+        // around a load makes the compiler drain the memory pipeline (vmcnt(0)) at the join.
+        auto issue_load = [&](auto SET) {
+            oa.offsets(g.lda, ld_c.bm * BM, g.M, st);
+            ob.offsets(g.ldb, ld_c.bn * BN, g.N, st);
+            oa.template load<decltype(SET)::value>(x3p_base<AFORM>(g.A, g.lda, ld_c.bm * BM, ld_c.kt));
+            ob.template load<decltype(SET)::value>(x3p_base<BFORM>(g.B, g.ldb, ld_c.bn * BN, ld_c.kt));
+            XwCursor nx = ld_c;
+            nx.advance(g, nwg);
+            if (nx.valid(g)) ld_c = nx;  // (a select per field, not a branch around the loads)
+        };
+        auto stage = [&](auto SET, int img) {
+            constexpr int S_ = decltype(SET)::value;
+            char* As = lds + img * IMG;
+            char* Bs = As + 3 * PA;
+#pragma unroll
+            for (int u = 0; u < XwOperand<AFORM, BM>::NU; ++u) oa.template stage_unit<S_>(u, As, st);
+#pragma unroll
+            for (int u = 0; u < XwOperand<BFORM, BN>::NU; ++u) ob.template stage_unit<S_>(u, Bs, st);
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        issue_load(S0{});  // element 0 -> set 0
+        issue_load(S1{});  // element 1 -> set 1
+        stage(S0{}, 0);
+        issue_load(S0{});  // element 2 -> set 0
+        __syncthreads();   // image 0 holds element 0
+        // per element s of the stream (the one the multipliers work on): stage element s + 1 (it arrived in raw set
+        // (s + 1) & 1) into image (s + 1) & 1, re-issue that set as the load of element s + 3, then barrier #s.  Past the
+        // end of the stream the same code stages and loads data nobody reads.
+        while (true) {
+            stage(S1{}, 1);
+            issue_load(S1{});
+            __syncthreads();
+            if (br_c.advance(g, nwg))
+                for (int e = 0; e < epi_barriers; ++e) __syncthreads();
+            if (!br_c.valid(g)) break;
+            stage(S0{}, 0);
+            issue_load(S0{});
+            __syncthreads();
+            if (br_c.advance(g, nwg))
+                for (int e = 0; e < epi_barriers; ++e) __syncthreads();
+            if (!br_c.valid(g)) break;
+        }
+        return;
+    }
+
+    // -------------------------------------------------------------------------------------------------- multipliers
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int swz = (l31 >> 2) & 3;
+    // byte offset of this lane's fragment inside a plane for k-step ks: row l31 of a 32-row block, chunk 2 ks + half
+    const int coff[2] = {l31 * XW_ROWB + (((0 + half) ^ swz) << 4), l31 * XW_ROWB + (((2 + half) ^ swz) << 4)};
+    const int a_row0 = wm * WTM * XW_ROWB, b_row0 = wn * WTN * XW_ROWB;
+    auto frag = [&](const char* plane_base, int block, int ks) {
+        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(plane_base + block * (32 * XW_ROWB) + coff[ks]));
+    };
+    // kept side: all TK blocks x 3 planes of a k-step; streamed side: one block x 3 planes, double buffered
+    bf16x8 fk[2][3][TK], fs[2][3];
+    auto load_kept = [&](int set, const char* img, int ks) {
+        const char* base = KEEP_A ? img + a_row0 : img + 3 * PA + b_row0;
+        constexpr int P = KEEP_A ? PA : PB;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int k = 0; k < TK; ++k) fk[set][p][k] = frag(base + p * P, k, ks);
+    };
+    auto load_stream = [&](int set, const char* img, int l, int ks) {
+        const char* base = KEEP_A ? img + 3 * PA + b_row0 : img + a_row0;
+        constexpr int P = KEEP_A ? PB : PA;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fs[set][p] = frag(base + p * P, l, ks);
+    };
+
+    XwCursor c;
+    c.w = L;
+    c.open(g);
+    if (!c.valid(g)) return;
+    int s = 0;
+    __syncthreads();  // image 0 holds element 0
+    load_kept(0, lds, 0);
+    load_stream(0, lds, 0, 0);
+    while (c.valid(g)) {
+        const int bm = c.bm, bn = c.bn, z = c.z;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
+        bool more = true;
+        while (more) {
+            const char* img = lds + (s & 1) * IMG;
+            const char* nxt = lds + ((s + 1) & 1) * IMG;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int l = 0; l < TL; ++l) {
+                    const int cur = (ks * TL + l) & 1;  // fs set of this block
+                    const bool last = ks == 1 && l == TL - 1;
+                    if (last) {
+                        // every fragment of this k-tile has been requested: wait for them, then the k-tile's barrier;
+                        // behind it the other image holds the next k-tile, whose first fragments are read under the
+                        // MFMAs of this last block
+                        __syncthreads();
+                        load_kept(0, nxt, 0);
+                        load_stream(cur ^ 1, nxt, 0, 0);
+                    } else if (l + 1 < TL) {
+                        load_stream(cur ^ 1, img, l + 1, ks);
+                    } else {  // last block of k-step 0: first streamed block of k-step 1
+                        load_stream(cur ^ 1, img, 0, 1);
+                    }
+                    if (ks == 0 && l == 0) load_kept(1, img, 1);  // kept fragments of k-step 1, a whole k-step ahead
+#pragma unroll
+                    for (int k = 0; k < TK; ++k) {
+                        f32x16 cc = KEEP_A ? acc[k][l] : acc[l][k];
+                        const bf16x8 a0 = KEEP_A ? fk[ks][0][k] : fs[cur][0], a1 = KEEP_A ? fk[ks][1][k] : fs[cur][1],
+                                     a2 = KEEP_A ? fk[ks][2][k] : fs[cur][2];
+                        const bf16x8 b0 = KEEP_A ? fs[cur][0] : fk[ks][0][k], b1 = KEEP_A ? fs[cur][1] : fk[ks][1][k],
+                                     b2 = KEEP_A ? fs[cur][2] : fk[ks][2][k];
+                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, cc, 0, 0, 0);  // smallest terms first
+                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, cc, 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, cc, 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, cc, 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, cc, 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, cc, 0, 0, 0);
+                        if (KEEP_A)
+                            acc[k][l] = cc;
+                        else
+                            acc[l][k] = cc;
+                    }
+                }
+            }
+            ++s;
+            more = !c.advance(g, nwg);
+        }
+        gemm_epilogue<BM, BN, WGM, WGN, EPI>(acc, g, bm, bn, z, scratch);
+        if (EPI == EPI_RECON) __syncthreads();
+    }
+}
+
 // Fixed-order reduction of split-K slabs + the standard epilogue.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int S, int64_t slab_stride,
                                                             int M, int N, float alpha, const float* __restrict__ bias,
@@ -1367,6 +1663,9 @@ TileShape tile_shape(int layout, int id) {
     if (id == 0 || id == 3) return {128, 128, 2};
     if (id == 1 || id == 4) return {128, 160, 2};
     if (id == 5) return {160, 128, 2};
+    if (id == 6) return {256, 160, 1};  // 6, 7, 8: the wave-specialised bf16x3 kernel, one 512-thread workgroup per CU
+    if (id == 7) return {160, 256, 1};
+    if (id == 8) return {256, 128, 1};
     return {64, 64, 4};
 }
 
@@ -1416,9 +1715,42 @@ int launch_gemm_x3(int tile_id, const GemmArgs& g0, int nwork, hipStream_t s) {
     return MMVAE_OK;
 }
 
-// tile_id 3, 4, 5 = the bf16x3 kernel (128x128, 128x160, 160x128 tiles; the last two need 16-byte-regular operands)
+// MMVAE_X3W=0 switches the wave-specialised kernel off (A/B runs against the 2 x 4-wave kernel; read once)
+bool x3w_enabled() {
+    static const int on = [] {
+        const char* e = getenv("MMVAE_X3W");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    return on != 0;
+}
+
+constexpr int X3W_SLOTS = 256;  // one resident workgroup per CU
+
+template <int AFORM, int BFORM, int EPI>
+int launch_gemm_x3w(int tile_id, const GemmArgs& g0, int nwork, hipStream_t s) {
+    GemmArgs g = g0;
+    g.nwork = nwork;
+    const int nblocks = nwork < X3W_SLOTS ? nwork : X3W_SLOTS;  // persistent over the work items
+    if (tile_id == 6)
+        MMVAE_LAUNCH((gemm_x3w_kernel<AFORM, BFORM, 256, 160, 4, 1, EPI>), dim3(nblocks), dim3(512), 0, s, g);
+    else if (tile_id == 7 && EPI == EPI_STD)
+        MMVAE_LAUNCH((gemm_x3w_kernel<AFORM, BFORM, 160, 256, 1, 4, EPI_STD>), dim3(nblocks), dim3(512), 0, s, g);
+    else if (tile_id == 8)
+        MMVAE_LAUNCH((gemm_x3w_kernel<AFORM, BFORM, 256, 128, 2, 2, EPI>), dim3(nblocks), dim3(512), 0, s, g);
+    else
+        return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+// tile_id 3, 4, 5 = the bf16x3 kernel (128x128, 128x160, 160x128 tiles; the last two need 16-byte-regular operands);
+// 6, 7, 8 = its wave-specialised form (256x160, 160x256, 256x128; 16-byte-regular operands and whole k-tiles)
 template <int AFORM, int BFORM, int EPI>
 int launch_gemm_forms(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) {
+    if (tile_id >= 6) {
+        if (!(g.x3_vec && g.K % X3_BK == 0)) return MMVAE_ERR_ARG;
+        return launch_gemm_x3w<AFORM, BFORM, EPI>(tile_id, g, nblocks, s);
+    }
     if (tile_id >= 3)  // the pipelined bf16x3 loop needs 16-byte-regular operands and whole k-tiles
         return (g.x3_vec && g.K % X3_BK == 0) ? launch_gemm_x3<AFORM, BFORM, true, EPI>(tile_id, g, nblocks, s)
                                                     : launch_gemm_x3<AFORM, BFORM, false, EPI>(tile_id, g, nblocks, s);
@@ -1529,6 +1861,34 @@ int x3_tile_for(int M, int N, bool allow_tall) {
     return best;
 }
 
+// Tile of the wave-specialised kernel for `slabs` split-K slices of an M x N output over 16-byte-regular operands with
+// whole k-tiles, or 0 when that kernel would leave too many CUs without a workgroup (it runs ONE workgroup per CU).
+// Cost of a shape = rounds of the chip's 256 slots x tile area.
+int x3w_tile_for(int M, int N, int slabs, bool allow_tall) {
+    if (!x3w_enabled()) return 0;
+    int best = 0;
+    long best_cost = -1;
+    for (int id = 6; id <= 8; ++id) {
+        if (id == 7 && !allow_tall) continue;
+        const TileShape ts = tile_shape(0, id);
+        const long work = (long)ceil_div_i(M, ts.bm) * ceil_div_i(N, ts.bn) * slabs;
+        if (work < 160) continue;
+        const long cost = ((work + X3W_SLOTS - 1) / X3W_SLOTS) * ts.bm * ts.bn;
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = id;
+        }
+    }
+    return best;
+}
+
+// the bf16x3 tile an unsplit (or `slabs`-way split) launch over regular operands takes
+int x3_tile_regular(int M, int N, int slabs, bool allow_tall) {
+    const int w = x3w_tile_for(M, N, slabs, allow_tall);
+    if (w) return w;
+    return slabs == 1 ? x3_tile_for(M, N, allow_tall) : 3;
+}
+
 }  // namespace
 
 extern "C" int mmvae_gemm_plan(int layout, int M, int N, int K, int* tile_out, int* splitk_out) {
@@ -1566,7 +1926,7 @@ static int sq_tiles(int layout, int M, int N, int K, bool aligned2) {
     plan(layout, M, N, K, &tile_id, &sk);
     if (sk != 1) return 0;
     if (g_precision == MMVAE_GEMM_PRECISION_BF16X3 && tile_id != 2)
-        tile_id = (aligned2 && K % X3_BK == 0) ? x3_tile_for(M, N, true) : 3;
+        tile_id = (aligned2 && K % X3_BK == 0) ? x3_tile_regular(M, N, 1, true) : 3;
     const TileShape ts = tile_shape(layout, tile_id);
     return ceil_div_i(M, ts.bm) * ceil_div_i(N, ts.bn);
 }
@@ -1611,7 +1971,11 @@ static int gemm_f32_impl(int layout, int M, int N, int K, float alpha, const flo
     const bool x3v = x3_vec_ok(layout, M, N, (flags & MMVAE_GEMM_OPERAND_SLACK) != 0);
     flags &= ~MMVAE_GEMM_OPERAND_SLACK;
     if (g_precision == MMVAE_GEMM_PRECISION_BF16X3 && tile_id != 2)  // chip-filling GEMMs: bf16x3 cores
-        tile_id = (x3v && K % X3_BK == 0 && splitk == 1) ? x3_tile_for(M, N, true) : 3;
+        tile_id = (x3v && K % X3_BK == 0) ? x3_tile_regular(M, N, splitk, true) : 3;
+    if (tile_id >= 6) {  // the persistent kernel's k-tile stream has no empty items: every slice must own a k-tile
+        const int kt32 = K / X3_BK, kps = ceil_div_i(kt32, splitk);
+        if ((int64_t)(splitk - 1) * kps >= kt32) tile_id = 3;
+    }
     const TileShape ts = tile_shape(layout, tile_id);
     const int ktiles = ceil_div_i(K, bk_of(layout, tile_id));
     const bool raw = (flags & MMVAE_GEMM_RAW_SLABS) != 0;
@@ -1680,14 +2044,12 @@ static int gemm_f32_impl(int layout, int M, int N, int K, float alpha, const flo
         gm.ktiles_per_split = ceil_div_i(gm.ktiles, splitk - 1);
         int sk_main = splitk - 1;
         if (!raw) sk_main = ceil_div_i(gm.ktiles, gm.ktiles_per_split);
-        if (sk_main == 1) {  // one slab over the whole k-tiles: free to take the tile shape that fills the chip best
-            const int t_main = x3_tile_for(M, N, true);
+        {  // the slabs over the whole k-tiles are free to take the tile shape that fills the chip best
+            const int t_main = x3_tile_regular(M, N, sk_main, true);
             const TileShape tm = tile_shape(layout, t_main);
             gm.mt = ceil_div_i(M, tm.bm);
             gm.nt = ceil_div_i(N, tm.bn);
-            rc = launch_tile(t_main, gm, 1);
-        } else {
-            rc = launch(gm, sk_main);
+            rc = launch_tile(t_main, gm, sk_main);
         }
         if (rc != MMVAE_OK) return rc;
         GemmArgs gt = g;
@@ -1802,8 +2164,8 @@ extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, 
     g.aligned = aligned16(h) && aligned16(W) && (ldh % 4 == 0) && (ldw % 4 == 0);
     if (g.aligned && rows % 4 == 0 && G % 4 == 0 && H % 4 == 0) g.aligned = 2;
     g.x3_vec = 1;  // both operands K-contiguous: rows are clamped one by one, no edge groups
-    const int tile_id = !x3 ? 1 : ((H % X3_BK == 0) ? x3_tile_for(rows, G, false) : 3);
-    g.mt = ceil_div_i(rows, 128);
+    const int tile_id = !x3 ? 1 : ((H % X3_BK == 0) ? x3_tile_regular(rows, G, 1, false) : 3);
+    g.mt = ceil_div_i(rows, tile_shape(0, tile_id).bm);
     g.nt = ceil_div_i(G, tile_shape(0, tile_id).bn);
     g.se_tiles = mmvae_recon_tiles(G);  // rows nt .. se_tiles-1 of se_part are zeroed by the last column tile
     g.ktiles = ceil_div_i(H, x3 ? X3_BK : 16);

@@ -92,6 +92,43 @@ def test_gemm_wide_and_tall_tiles(ops, layout, M, N, K):
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(1024, 20000, 512), (20000, 1024, 512), (512, 20000, 1024), (1000, 19996, 96),
+                                   (2048, 5000, 64), (5120, 8000, 32), (300, 30000, 128)])
+def test_gemm_wave_specialised_kernel(ops, layout, M, N, K):
+    """The wave-specialised bf16x3 kernel (one 512-thread workgroup per CU: 4 multiplier + 4 stager wavefronts, double
+    buffered LDS, persistent over its work items): shapes that select its 256x160 / 160x256 / 256x128 tiles, with
+    whole and ragged edge tiles, one and several items per workgroup, against fp64 -- and bit for bit against the
+    2 x 4-wave kernel's sum order is NOT required (different accumulation split), only fp32-GEMM accuracy."""
+    import ctypes
+
+    from mmvae_amd import _lib
+
+    a, b = rnd(M, K, seed=M + 7 * layout), rnd(K, N, seed=N + 3)
+    ref = a.double() @ b.double()
+    A = a if layout != 2 else a.t().contiguous()
+    Bm = b.t().contiguous() if layout == 0 else b
+    out = ops.gemm(layout, dev(A), dev(Bm), splitk=1)
+    assert rel_l2(out, ref) < 2e-6
+    # exact on integer-valued operands (every bf16 piece and every partial sum is exact)
+    ai, bi = _asym(M, K), _asym(K, N) + 1.0
+    Ai = ai if layout != 2 else ai.t().contiguous()
+    Bi = bi.t().contiguous() if layout == 0 else bi
+    assert torch.equal(ops.gemm(layout, dev(Ai), dev(Bi), splitk=1).cpu().double(), ai.double() @ bi.double())
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_gemm_wave_specialised_split_slabs(ops, layout):
+    """Split-K slabs of the K = G reductions (enc-L1 forward NT, dec-L2 input gradient NN): 16 slices x 16 tiles of
+    256x128 = one workgroup per CU; the slabs must add up to the product."""
+    M, N, K = 512, 1024, 20000
+    a, b = rnd(M, K, seed=1), rnd(K, N, seed=2, scale=0.05)
+    Bm = b.t().contiguous() if layout == 0 else b
+    slabs = ops.gemm_slabs(layout, dev(a), dev(Bm))
+    assert slabs.shape[0] >= 8
+    assert rel_l2(slabs.double().sum(0), a.double() @ b.double()) < 2e-6
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
 def test_gemm_unaligned_strides(ops, layout):
     """Leading dimensions that are not multiples of 4 floats (e.g. 60530 / 52437-gene matrices)."""
     M, N, K = 70, 45, 131
