@@ -1434,6 +1434,37 @@ struct XwOperand {
 #pragma unroll
         for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(S + p * (R * XW_ROWB) + o) = pk[p];
     }
+    template <int SET>
+    __device__ __forceinline__ void load_one(int u, const char* __restrict__ base) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + off[u]);
+        if (SET == 0)
+            raw0[u] = v;
+        else
+            raw1[u] = v;
+    }
+    // Stage every unit of raw set SET into the image at S and re-issue each raw register as the load of the k-tile
+    // two ahead (base `next`) as soon as its last unit is split: the 13 loads of a k-tile then enter the memory
+    // pipeline one at a time between ~100-cycle runs of VALU work instead of as one burst that the wave sits behind
+    // (16 B x 64 lanes = 16 cycles of address processing each, shared by the CU's four stagers).
+    template <int SET>
+    __device__ __forceinline__ void stage_and_reload(char* S, int st, const char* __restrict__ next) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            stage_unit<SET>(u, S, st);
+            if constexpr (FORM == FORM_KC) {
+                load_one<SET>(u, next);
+            } else {
+                if (u < (NU / 4) * 4) {
+                    if ((u & 3) == 3) {
+#pragma unroll
+                        for (int j = u - 3; j <= u; ++j) load_one<SET>(j, next);
+                    }
+                } else {
+                    load_one<SET>(u, next);  // the 32 extra rows of a 160-row tile: one register, one unit
+                }
+            }
+        }
+    }
 };
 
 // position in the workgroup's stream of k-tiles (items = output tile x split-K slice, looped over persistently)
@@ -1489,19 +1520,42 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
         ld_c.open(g);
         br_c.open(g);
         if (!br_c.valid(g)) return;
-        // Branch-free on purpose: offsets are recomputed with every load (a dozen VALU instructions; the stagers have
-        // issue slots to spare) and a load past the end of the stream re-reads the last k-tile -- a wave-uniform branch
-        // around a load makes the compiler drain the memory pipeline (vmcnt(0)) at the join.
-        auto issue_load = [&](auto SET) {
-            oa.offsets(g.lda, ld_c.bm * BM, g.M, st);
-            ob.offsets(g.ldb, ld_c.bn * BN, g.N, st);
-            oa.template load<decltype(SET)::value>(x3p_base<AFORM>(g.A, g.lda, ld_c.bm * BM, ld_c.kt));
-            ob.template load<decltype(SET)::value>(x3p_base<BFORM>(g.B, g.ldb, ld_c.bn * BN, ld_c.kt));
+        // The loads themselves sit in straight-line code (a wave-uniform branch AROUND a load makes the compiler drain
+        // the memory pipeline at the join); a load past the end of the stream re-reads the last k-tile.  The per-thread
+        // offsets (64-bit multiplies: ~1 000 cycles for both operands) are recomputed only when the stream enters a new
+        // item, in a branch that holds VALU work only.
+#if MMVAE_X3_STAMPS
+        long long sst[4] = {0, 0, 0, 0};
+        long long tp = clock64();
+#define XW_SSTAMP(i)                     \
+    {                                    \
+        const long long tn_ = clock64(); \
+        sst[i] += tn_ - tp;              \
+        tp = tn_;                        \
+    }
+#else
+#define XW_SSTAMP(i)
+#endif
+        int off_w = -1;  // item the offsets were computed for
+        auto refresh_offsets = [&]() {
+            if (ld_c.w != off_w) {
+                oa.offsets(g.lda, ld_c.bm * BM, g.M, st);
+                ob.offsets(g.ldb, ld_c.bn * BN, g.N, st);
+                off_w = ld_c.w;
+            }
+        };
+        auto bump = [&]() {
             XwCursor nx = ld_c;
             nx.advance(g, nwg);
             if (nx.valid(g)) ld_c = nx;  // (a select per field, not a branch around the loads)
         };
-        auto stage = [&](auto SET, int img) {
+        auto issue_load = [&](auto SET) {  // prologue only
+            refresh_offsets();
+            oa.template load<decltype(SET)::value>(x3p_base<AFORM>(g.A, g.lda, ld_c.bm * BM, ld_c.kt));
+            ob.template load<decltype(SET)::value>(x3p_base<BFORM>(g.B, g.ldb, ld_c.bn * BN, ld_c.kt));
+            bump();
+        };
+        auto stage = [&](auto SET, int img) {  // prologue only
             constexpr int S_ = decltype(SET)::value;
             char* As = lds + img * IMG;
             char* Bs = As + 3 * PA;
@@ -1509,6 +1563,29 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
             for (int u = 0; u < XwOperand<AFORM, BM>::NU; ++u) oa.template stage_unit<S_>(u, As, st);
 #pragma unroll
             for (int u = 0; u < XwOperand<BFORM, BN>::NU; ++u) ob.template stage_unit<S_>(u, Bs, st);
+        };
+        // steady state: stage raw set SET into image `img`, re-issuing its registers as the loads of the k-tile at ld_c
+        auto stage_reload = [&](auto SET, int img) {
+            constexpr int S_ = decltype(SET)::value;
+            char* As = lds + img * IMG;
+            char* Bs = As + 3 * PA;
+#if MMVAE_X3_STAMPS
+            {  // diagnostic: how long does the oldest raw set still take to arrive?  (its NU_A + NU_B loads are the oldest
+               // outstanding ones; the other set's are younger)
+                constexpr int YOUNGER = XwOperand<AFORM, BM>::NU + XwOperand<BFORM, BN>::NU;
+                const long long t0_ = clock64();
+                if (YOUNGER == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+                if (YOUNGER == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                sst[1] += clock64() - t0_;
+                tp = clock64();
+            }
+#endif
+            // NOTE: the offsets in registers belong to the item of ld_c; the raw data being split was loaded with the
+            // offsets valid at ITS load time -- only the new loads use the refreshed ones
+            refresh_offsets();
+            oa.template stage_and_reload<S_>(As, st, x3p_base<AFORM>(g.A, g.lda, ld_c.bm * BM, ld_c.kt));
+            ob.template stage_and_reload<S_>(Bs, st, x3p_base<BFORM>(g.B, g.ldb, ld_c.bn * BN, ld_c.kt));
+            bump();
         };
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, 1>;
@@ -1521,19 +1598,31 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
         // (s + 1) & 1) into image (s + 1) & 1, re-issue that set as the load of element s + 3, then barrier #s.  Past the
         // end of the stream the same code stages and loads data nobody reads.
         while (true) {
-            stage(S1{}, 1);
-            issue_load(S1{});
+            stage_reload(S1{}, 1);
+            XW_SSTAMP(0)
             __syncthreads();
+            XW_SSTAMP(2)
+#if MMVAE_X3_STAMPS
+            sst[3] += 1;
+#endif
             if (br_c.advance(g, nwg))
                 for (int e = 0; e < epi_barriers; ++e) __syncthreads();
             if (!br_c.valid(g)) break;
-            stage(S0{}, 0);
-            issue_load(S0{});
+            stage_reload(S0{}, 0);
+            XW_SSTAMP(0)
             __syncthreads();
+            XW_SSTAMP(2)
+#if MMVAE_X3_STAMPS
+            sst[3] += 1;
+#endif
             if (br_c.advance(g, nwg))
                 for (int e = 0; e < epi_barriers; ++e) __syncthreads();
             if (!br_c.valid(g)) break;
         }
+#if MMVAE_X3_STAMPS
+        if (bid == 0 && (tid & 63) == 0)
+            for (int i = 0; i < 4; ++i) g_x3_stamps[16 + (tid >> 6) - 4 + 4 * i - 0] = sst[i];  // slots 16..31: [i][stager wave]
+#endif
         return;
     }
 
@@ -1570,9 +1659,20 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
     c.open(g);
     if (!c.valid(g)) return;
     int s = 0;
+    // the multipliers' MFMAs and fragment reads win every issue arbitration against the stager wave of their SIMD: the
+    // matrix pipe sets the pace, the stagers fill the slots it leaves
+#ifndef MMVAE_XW_PRIO
+#define MMVAE_XW_PRIO 0
+#endif
+    if (MMVAE_XW_PRIO) __builtin_amdgcn_s_setprio(MMVAE_XW_PRIO);
     __syncthreads();  // image 0 holds element 0
     load_kept(0, lds, 0);
     load_stream(0, lds, 0, 0);
+#if MMVAE_X3_STAMPS
+    long long mst[4] = {0, 0, 0, 0};  // before the barrier, in the barrier, behind it, k-tiles
+    long long tq = clock64();
+    if (tid == 0 && bid < 4096) g_x3_trace[bid * 4 + 0] = wall_clock64();
+#endif
     while (c.valid(g)) {
         const int bm = c.bm, bn = c.bn, z = c.z;
         f32x16 acc[TM][TN];
@@ -1596,7 +1696,22 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
                         // every fragment of this k-tile has been requested: wait for them, then the k-tile's barrier;
                         // behind it the other image holds the next k-tile, whose first fragments are read under the
                         // MFMAs of this last block
+#if MMVAE_X3_STAMPS
+                        {
+                            const long long tn_ = clock64();
+                            mst[0] += tn_ - tq;
+                            tq = tn_;
+                        }
+#endif
                         __syncthreads();
+#if MMVAE_X3_STAMPS
+                        {
+                            const long long tn_ = clock64();
+                            mst[1] += tn_ - tq;
+                            tq = tn_;
+                            mst[3] += 1;
+                        }
+#endif
                         load_kept(0, nxt, 0);
                         load_stream(cur ^ 1, nxt, 0, 0);
                     } else if (l + 1 < TL) {
@@ -1627,10 +1742,31 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
             }
             ++s;
             more = !c.advance(g, nwg);
+#if MMVAE_X3_STAMPS
+            {
+                const long long tn_ = clock64();
+                mst[2] += tn_ - tq;
+                tq = tn_;
+            }
+#endif
         }
+#if MMVAE_X3_STAMPS
+        if (tid == 0 && bid < 4096) g_x3_trace[bid * 4 + 2] = wall_clock64();
+#endif
         gemm_epilogue<BM, BN, WGM, WGN, EPI>(acc, g, bm, bn, z, scratch);
         if (EPI == EPI_RECON) __syncthreads();
+#if MMVAE_X3_STAMPS
+        tq = clock64();
+#endif
     }
+#if MMVAE_X3_STAMPS
+    if (bid == 0 && lane == 0)
+        for (int i = 0; i < 4; ++i) g_x3_stamps[wave + 4 * i] = mst[i];  // slots 0..15: [i][multiplier wave]
+    if (tid == 0 && bid < 4096) {
+        __builtin_amdgcn_s_waitcnt(0);
+        g_x3_trace[bid * 4 + 3] = wall_clock64();
+    }
+#endif
 }
 
 // Fixed-order reduction of split-K slabs + the standard epilogue.
@@ -1715,13 +1851,11 @@ int launch_gemm_x3(int tile_id, const GemmArgs& g0, int nwork, hipStream_t s) {
     return MMVAE_OK;
 }
 
-// MMVAE_X3W=0 switches the wave-specialised kernel off (A/B runs against the 2 x 4-wave kernel; read once)
+// MMVAE_X3W=1 selects the wave-specialised kernel where its tiles fill the chip (read at every launch: tests and A/B
+// runs toggle it).  Off by default: measured level with the 2 x 4-wave kernel inside the C2 step.
 bool x3w_enabled() {
-    static const int on = [] {
-        const char* e = getenv("MMVAE_X3W");
-        return (e && e[0] == '0') ? 0 : 1;
-    }();
-    return on != 0;
+    const char* e = getenv("MMVAE_X3W");
+    return e && e[0] == '1';
 }
 
 constexpr int X3W_SLOTS = 256;  // one resident workgroup per CU
@@ -2164,7 +2298,11 @@ extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, 
     g.aligned = aligned16(h) && aligned16(W) && (ldh % 4 == 0) && (ldw % 4 == 0);
     if (g.aligned && rows % 4 == 0 && G % 4 == 0 && H % 4 == 0) g.aligned = 2;
     g.x3_vec = 1;  // both operands K-contiguous: rows are clamped one by one, no edge groups
-    const int tile_id = !x3 ? 1 : ((H % X3_BK == 0) ? x3_tile_regular(rows, G, 1, false) : 3);
+    // (the wave-specialised kernel's fused-recon instantiation runs out of registers in the epilogue -- 63 spills -- and
+    // measured 134 us against 119 us in the C2 step: the 2 x 4-wave kernel keeps this launch; MMVAE_X3W_RECON=1 to compare)
+    const char* e_recon = getenv("MMVAE_X3W_RECON");
+    const bool w_recon = e_recon && e_recon[0] == '1';
+    const int tile_id = !x3 ? 1 : ((H % X3_BK == 0) ? (w_recon ? x3_tile_regular(rows, G, 1, false) : x3_tile_for(rows, G, false)) : 3);
     g.mt = ceil_div_i(rows, tile_shape(0, tile_id).bm);
     g.nt = ceil_div_i(G, tile_shape(0, tile_id).bn);
     g.se_tiles = mmvae_recon_tiles(G);  // rows nt .. se_tiles-1 of se_part are zeroed by the last column tile

@@ -94,7 +94,7 @@ def test_gemm_wide_and_tall_tiles(ops, layout, M, N, K):
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(1024, 20000, 512), (20000, 1024, 512), (512, 20000, 1024), (1000, 19996, 96),
                                    (2048, 5000, 64), (5120, 8000, 32), (300, 30000, 128)])
-def test_gemm_wave_specialised_kernel(ops, layout, M, N, K):
+def test_gemm_wave_specialised_kernel(ops, layout, M, N, K, monkeypatch):
     """The wave-specialised bf16x3 kernel (one 512-thread workgroup per CU: 4 multiplier + 4 stager wavefronts, double
     buffered LDS, persistent over its work items): shapes that select its 256x160 / 160x256 / 256x128 tiles, with
     whole and ragged edge tiles, one and several items per workgroup, against fp64 -- and bit for bit against the
@@ -103,6 +103,8 @@ def test_gemm_wave_specialised_kernel(ops, layout, M, N, K):
 
     from mmvae_amd import _lib
 
+    monkeypatch.setenv("MMVAE_X3W", "1")  # (off by default: level with the 2 x 4-wave kernel inside the step)
+    t, sk = ctypes.c_int(), ctypes.c_int()
     a, b = rnd(M, K, seed=M + 7 * layout), rnd(K, N, seed=N + 3)
     ref = a.double() @ b.double()
     A = a if layout != 2 else a.t().contiguous()
@@ -117,9 +119,10 @@ def test_gemm_wave_specialised_kernel(ops, layout, M, N, K):
 
 
 @pytest.mark.parametrize("layout", [0, 1])
-def test_gemm_wave_specialised_split_slabs(ops, layout):
+def test_gemm_wave_specialised_split_slabs(ops, layout, monkeypatch):
     """Split-K slabs of the K = G reductions (enc-L1 forward NT, dec-L2 input gradient NN): 16 slices x 16 tiles of
     256x128 = one workgroup per CU; the slabs must add up to the product."""
+    monkeypatch.setenv("MMVAE_X3W", "1")
     M, N, K = 512, 1024, 20000
     a, b = rnd(M, K, seed=1), rnd(K, N, seed=2, scale=0.05)
     Bm = b.t().contiguous() if layout == 0 else b
