@@ -407,6 +407,16 @@ int mmvae_csr_to_dense_f32(int B, int G, int64_t nnz, const int64_t* crow_indice
 int mmvae_csr_to_dense_i32_f32(int B, int G, int64_t nnz, const int32_t* crow_indices, const int32_t* col_indices,
                                const float* values, float* out, int64_t ldo, mmvae_stream_t stream);
 
+/* f1 measurement (NOT on the product path): the first layer's product straight from the CSR batch,
+ *   y[B, N] = x_csr[B, G] . W^T (+ bias)      with Wt = W transposed, [G, ldwt >= N], N % 4 == 0, int32 indices.
+ * replaces (would replace): `x.to_dense()` + nn.Linear of the expert encoder's first layer (vae.py:140-141,
+ * components.py:276).  A gather of nnz rows of Wt (4 N bytes each); accumulation in stored order.  Measured against
+ * the dense bf16x3 GEMM at the reference's widths and 5 / 10 % density in profiles/r2_sparse_input.txt: dense wins, so
+ * the engine keeps densifying (mmvae_csr_to_dense_*); this entry point stays as the evidence and for wider matrices. */
+int mmvae_csr_spmm_wt_i32_f32(int B, int N, int G, int64_t nnz, const int32_t* crow_indices, const int32_t* col_indices,
+                              const float* values, const float* Wt, int64_t ldwt, const float* bias, float* y,
+                              int64_t ldy, mmvae_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Conditional layers: y[b] = W[c_b] x[b] + bias[c_b], the Linear of each cell's OWN condition.
  * replaces: ConditionalLayer.forward (components.py:365-413: per present condition index_select -> Linear ->

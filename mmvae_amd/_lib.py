@@ -100,6 +100,7 @@ PROTOTYPES = {
     "mmvae_gemm_f32_sq": (_i, [_i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _u, _p, _l, _p]),
     "mmvae_csr_to_dense_f32": (_i, [_i, _i, _l, _p, _p, _p, _p, _l, _p]),
     "mmvae_csr_to_dense_i32_f32": (_i, [_i, _i, _l, _p, _p, _p, _p, _l, _p]),
+    "mmvae_csr_spmm_wt_i32_f32": (_i, [_i, _i, _i, _l, _p, _p, _p, _p, _l, _p, _p, _l, _p]),
     "mmvae_cond_linear_fwd": (_i, [_i, _i, _i, _p, _l, _p, _p, _p, _p, _p, _p, _l, _p]),
     "mmvae_cond_linear_bwd_dx": (_i, [_i, _i, _i, _p, _l, _p, _p, _p, _p, _p, _l, _i, _p]),
     "mmvae_cond_linear_bwd_dw": (_i, [_i, _p, _p, _p, _p, _i, _i, _p, _l, _p, _l, _p, _p, _p, _i, _p, _p, _p, _p, _p]),

@@ -1140,6 +1140,68 @@ extern "C" int mmvae_csr_to_dense_i32_f32(int B, int G, int64_t nnz, const int32
     return MMVAE_OK;
 }
 
+// ---- f1 experiment: CSR x dense^T product of the first layer WITHOUT densifying.
+// y[b, :] = sum over the stored elements (g, v) of row b of v * Wt[g, :]  (+ bias), Wt = the layer's weight TRANSPOSED
+// ([G, N], N contiguous: a stored element then touches one contiguous 4 N-byte row of Wt).  One workgroup per cell row
+// and 1024-column chunk; thread t owns columns 4 t .. 4 t + 3 of the chunk; the row's (column, value) pairs are staged
+// through LDS 256 at a time and every pair costs each wave one 1-KB coalesced load of Wt: the kernel is a gather from
+// L2 / Infinity Cache / HBM of nnz x 4 N bytes -- at 10 % density ~10x the bytes the dense GEMM streams, which is why
+// the dense bf16x3 GEMM over the densified batch stays the product path (measured: profiles/r2_sparse_input.txt).
+// Accumulation in stored order: bitwise reproducible.
+template <typename I>
+__global__ __launch_bounds__(256) void csr_spmm_rows_kernel(int N, int G, int64_t nnz, const I* __restrict__ crow,
+                                                            const I* __restrict__ col, const float* __restrict__ val,
+                                                            const float* __restrict__ Wt, int64_t ldwt,
+                                                            const float* __restrict__ bias, float* __restrict__ y,
+                                                            int64_t ldy) {
+    __shared__ int s_col[256];
+    __shared__ float s_val[256];
+    const int row = blockIdx.y;
+    const int c = blockIdx.x * 1024 + 4 * threadIdx.x;
+    const bool live = c + 3 < N;  // N % 4 == 0 is required: a 16-byte group is inside the row or outside it
+    int64_t beg = (int64_t)crow[row], end = (int64_t)crow[row + 1];
+    beg = beg < 0 ? 0 : beg;
+    end = end > nnz ? nnz : end;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t base = beg; base < end; base += 256) {
+        const int n = (int)((end - base) < 256 ? (end - base) : 256);
+        __syncthreads();
+        if ((int)threadIdx.x < n) {
+            const int64_t g = (int64_t)col[base + threadIdx.x];
+            const bool ok = g >= 0 && g < G;  // a malformed index contributes nothing
+            s_col[threadIdx.x] = ok ? (int)g : 0;
+            s_val[threadIdx.x] = ok ? val[base + threadIdx.x] : 0.f;
+        }
+        __syncthreads();
+        if (live) {
+            int i = 0;
+            for (; i + 8 <= n; i += 8) {  // 8 gathered rows in flight per thread
+                f32x4 w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const f32x4*>(Wt + (int64_t)s_col[i + u] * ldwt + c);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += w[u] * s_val[i + u];
+            }
+            for (; i < n; ++i) acc += *reinterpret_cast<const f32x4*>(Wt + (int64_t)s_col[i] * ldwt + c) * s_val[i];
+        }
+    }
+    if (live) {
+        if (bias) acc += *reinterpret_cast<const f32x4*>(bias + c);
+        *reinterpret_cast<f32x4*>(y + (int64_t)row * ldy + c) = acc;
+    }
+}
+
+extern "C" int mmvae_csr_spmm_wt_i32_f32(int B, int N, int G, int64_t nnz, const int32_t* crow_indices,
+                                         const int32_t* col_indices, const float* values, const float* Wt, int64_t ldwt,
+                                         const float* bias, float* y, int64_t ldy, mmvae_stream_t stream) {
+    if (B <= 0 || B > 65535 || N <= 0 || N % 4 != 0 || G <= 0 || nnz < 0 || !crow_indices || !Wt || !y) return MMVAE_ERR_ARG;
+    if (ldwt < N || ldy < N || (nnz > 0 && (!col_indices || !values))) return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(csr_spmm_rows_kernel<int32_t>, dim3(ceil_div_i(N, 1024), B), dim3(256), 0, (hipStream_t)stream, N, G, nnz,
+                 crow_indices, col_indices, values, Wt, ldwt, bias, y, ldy);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
 extern "C" int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, float* y, mmvae_stream_t stream) {
     if (n <= 0 || !x || !y) return MMVAE_ERR_ARG;
     if (n % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)

@@ -551,6 +551,26 @@ def csr_to_dense(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
     return out
 
 
+def csr_spmm_wt(x: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """f1 measurement: y[B, N] = x_csr[B, G] . wt[G, N] (+ bias) straight from a `torch.sparse_csr` batch with int32
+    indices; wt is the layer's weight TRANSPOSED.  Not on the product path (the engine densifies)."""
+    lib = _lib.load()
+    if x.layout != torch.sparse_csr or x.dim() != 2:
+        raise ValueError("csr_spmm_wt: expected a 2-D torch.sparse_csr tensor")
+    crow, col, val = x.crow_indices().int().contiguous(), x.col_indices().int().contiguous(), x.values().float().contiguous()
+    _chk(wt, "wt"), _chk(bias, "bias")
+    B, G = x.shape
+    if wt.shape[0] != G or wt.stride(1) != 1 or wt.shape[1] % 4:
+        raise ValueError("wt must be [G, N] with N contiguous and N % 4 == 0")
+    N = wt.shape[1]
+    y = torch.empty((B, N), dtype=torch.float32, device=val.device)
+    nnz = int(val.numel())
+    _lib.check(lib.mmvae_csr_spmm_wt_i32_f32(B, N, G, nnz, crow.data_ptr(), col.data_ptr() if nnz else None,
+                                             val.data_ptr() if nnz else None, _ptr(wt), wt.stride(0), _ptr(bias), _ptr(y), N,
+                                             _stream()), "mmvae_csr_spmm_wt_i32_f32")
+    return y
+
+
 def cond_linear_fwd(x: torch.Tensor, params: torch.Tensor, w_off: torch.Tensor, b_off: torch.Tensor,
                     cond: torch.Tensor, n_out: int, rows: torch.Tensor = None) -> torch.Tensor:
     """y[b] = W[cond[b]] x[b] + bias[cond[b]]; blocks addressed by element offsets into the flat `params` arena.

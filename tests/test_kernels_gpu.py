@@ -584,6 +584,25 @@ def test_csr_to_dense(ops, B, G, density):
     assert torch.equal(base[:, :G].cpu(), d) and bool((base[:, G:] == 7.0).all())
 
 
+@pytest.mark.parametrize("B,G,N,density", [(33, 257, 72, 0.1), (64, 20000, 1024, 0.08), (7, 1000, 2048, 0.0), (16, 5000, 1028, 0.3)])
+def test_csr_spmm_against_dense(ops, B, G, N, density):
+    """SURVEY 8 f1 measurement kernel: the first layer's product straight from the CSR batch (gather of transposed
+    weight rows) equals the dense product of the densified batch (fp64 reference, rel-L2 <= 2e-6); empty rows give the bias."""
+    g = torch.Generator().manual_seed(B + G)
+    d = torch.rand(B, G, generator=g)
+    d = torch.where(d < density, torch.rand(B, G, generator=g) * 9.0, torch.zeros(()))
+    if B > 2:
+        d[1] = 0.0  # an empty row
+    w, bias = rnd(N, G, seed=3, scale=0.05), rnd(N, seed=4, scale=0.1)
+    x = d.to_sparse_csr()
+    x = torch.sparse_csr_tensor(x.crow_indices().int(), x.col_indices().int(), x.values(), size=(B, G)).cuda()
+    y = ops.csr_spmm_wt(x, dev(w.t().contiguous()), dev(bias))
+    ref = d.double() @ w.double().t() + bias.double()
+    assert rel_l2(y, ref) < 2e-6
+    if B > 2:
+        assert torch.equal(y[1].cpu(), bias)
+
+
 @pytest.mark.parametrize("layout,M,N,K", [(2, 1024, 20000, 64), (2, 20000, 1024, 32), (0, 512, 20000, 96),
                                            (2, 2048, 2004, 40), (1, 640, 20000, 64)])
 def test_gemm_with_fused_sum_of_squares(ops, layout, M, N, K):
