@@ -1512,6 +1512,11 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
     if (tid >= NT) {
         // ------------------------------------------------------------------------------------------------ stagers
         const int st = tid - NT;
+#ifndef MMVAE_XW_STAGER_PRIO
+#define MMVAE_XW_STAGER_PRIO 0
+#endif
+        // (the stagers are the longer role -- ~4 400 against ~3 900 cycles per k-tile, profiles/r2_x3w_stamps.txt)
+        if (MMVAE_XW_STAGER_PRIO) __builtin_amdgcn_s_setprio(MMVAE_XW_STAGER_PRIO);
         XwOperand<AFORM, BM> oa;
         XwOperand<BFORM, BN> ob;
         XwCursor ld_c;  // the k-tile the next load fetches

@@ -201,6 +201,12 @@ class StepEngine:
             ov = os.environ.get("MMVAE_DP_OVERLAP", os.environ.get("MMVAE_DEFER_EXPERT_ADAM", ""))
             defer = (ov != "0") if ov != "" else mdist.collectives_active()
         self.overlap = bool(defer)
+        # The wave-specialised GEMM kernel runs ONE persistent workgroup per CU with statically dealt work items: a
+        # collective's workgroups holding CUs beside it (the previous step's all-reduce under data parallelism) would
+        # delay whole workgroups by a round.  Under a gradient exchange the 2 x 4-wave kernel (measured sensitivity:
+        # DESIGN.md section 7) is kept unless the caller chose explicitly.
+        if mdist.collectives_active() and "MMVAE_X3W" not in os.environ:
+            os.environ["MMVAE_X3W"] = "0"
         if self.overlap and self.comm_stream is None:
             self.comm_stream = torch.cuda.Stream(device=self.device)
             self.small_stream = torch.cuda.Stream(device=self.device)
