@@ -82,6 +82,11 @@ const char* mmvae_build_arch(void);
 #define MMVAE_GEMM_PRECISION_F32 0
 #define MMVAE_GEMM_PRECISION_BF16X3 1
 int mmvae_gemm_set_precision(int mode);
+/* Host-side launch state (like the precision switch): max_workgroups > 0 caps the grid of the persistent
+ * (wave-specialised) GEMM kernel for the launches that follow, 0 removes the cap.  A capped launch leaves the other
+ * CUs to kernels of another stream: the engine runs a weight-gradient GEMM that way beside the latency-bound backward
+ * chain of the core layers.  Results do not depend on the cap. */
+int mmvae_gemm_set_workgroup_cap(int max_workgroups);
 int mmvae_gemm_get_precision(void);
 
 /* Library heuristic: picks the block tile (128 or 64; the bf16x3 path may widen a 128 tile to 128x160 / 160x128 at

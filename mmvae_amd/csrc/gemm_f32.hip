@@ -1864,12 +1864,14 @@ bool x3w_enabled() {
 }
 
 constexpr int X3W_SLOTS = 256;  // one resident workgroup per CU
+int g_wg_cap = 0;               // mmvae_gemm_set_workgroup_cap: > 0 caps the persistent kernel's grid
+int x3w_slots() { return (g_wg_cap > 0 && g_wg_cap < X3W_SLOTS) ? g_wg_cap : X3W_SLOTS; }
 
 template <int AFORM, int BFORM, int EPI>
 int launch_gemm_x3w(int tile_id, const GemmArgs& g0, int nwork, hipStream_t s) {
     GemmArgs g = g0;
     g.nwork = nwork;
-    const int nblocks = nwork < X3W_SLOTS ? nwork : X3W_SLOTS;  // persistent over the work items
+    const int nblocks = nwork < x3w_slots() ? nwork : x3w_slots();  // persistent over the work items
     if (tile_id == 6)
         MMVAE_LAUNCH((gemm_x3w_kernel<AFORM, BFORM, 256, 160, 4, 1, EPI>), dim3(nblocks), dim3(512), 0, s, g);
     else if (tile_id == 7 && EPI == EPI_STD)
@@ -2012,7 +2014,7 @@ int x3w_tile_for(int M, int N, int slabs, bool allow_tall) {
         const TileShape ts = tile_shape(0, id);
         const long work = (long)ceil_div_i(M, ts.bm) * ceil_div_i(N, ts.bn) * slabs;
         if (work < 160) continue;
-        const long cost = ((work + X3W_SLOTS - 1) / X3W_SLOTS) * ts.bm * ts.bn;
+        const long cost = ((work + x3w_slots() - 1) / x3w_slots()) * ts.bm * ts.bn;
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
             best = id;
@@ -2280,6 +2282,12 @@ extern "C" int mmvae_gemm_set_precision(int mode) {
 }
 
 extern "C" int mmvae_gemm_get_precision(void) { return g_precision; }
+
+extern "C" int mmvae_gemm_set_workgroup_cap(int max_workgroups) {
+    if (max_workgroups < 0) return MMVAE_ERR_ARG;
+    g_wg_cap = max_workgroups;
+    return MMVAE_OK;
+}
 
 extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, const float* h, int64_t ldh,
                                             const float* W, int64_t ldw, const float* bias, const float* x, int64_t ldx,

@@ -169,6 +169,13 @@ class StepEngine:
         self.fuse_sqnorm = os.environ.get("MMVAE_FUSE_SQNORM", "1") != "0"
         if os.environ.get("MMVAE_SIDE_STREAM", "0") != "0":
             side_stream = True
+        # The decoder's G-wide weight gradient (dW = dP^T h, ~105 us at C2, needed by the optimiser only) on a second
+        # stream beside the backward chain of the core layers (~150 us of latency-bound launches that leave most CUs
+        # idle): the persistent GEMM kernel is launched with its grid capped to `side_dw` workgroups = CUs, the chain
+        # gets the rest.  Inside the captured graph (a forked branch joined ahead of the optimisers).  0 = off.
+        self.side_dw = int(os.environ.get("MMVAE_SIDE_DW", "0"))
+        if self.side_dw:
+            side_stream = True
         self.side_stream = torch.cuda.Stream(device=self.device) if side_stream else None
         # only the small (latency-bound) weight-gradient GEMMs go aside; chip-filling ones stay in order on the main stream
         self.side_max_elems = int(os.environ.get("MMVAE_SIDE_MAX_ELEMS", 2 * 1024 * 1024))
@@ -512,7 +519,7 @@ class _Plan:
         self.lib.mmvae_gemm_plan(layout, M, N, K, C.byref(tile), C.byref(sk))
         return sk.value
 
-    def _fuse_sqnorm(self, layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags) -> bool:
+    def _fuse_sqnorm(self, layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, side_cap: int = 0) -> bool:
         """Unsplit weight-gradient GEMM straight into a gradient arena: let its epilogue also leave the partial sums of
         squares of what it stores (mmvae_gemm_f32_sq), so that the clip's norm pass does not read the 82 MB back.  Only
         without a gradient exchange: under data parallelism the norm is that of the REDUCED gradients."""
@@ -520,7 +527,9 @@ class _Plan:
         if not eng.fuse_sqnorm or eng.overlap or eng.world > 1 or ldc != N or (flags & ~ACC):
             return False
         regular = int(_p(A) % 16 == 0 and _p(Bm) % 16 == 0 and lda % 4 == 0 and ldb % 4 == 0)
+        self.lib.mmvae_gemm_set_workgroup_cap(side_cap)  # the tile (and so the partial count) is planned under the cap
         n_part = self.lib.mmvae_gemm_sq_partials(layout, M, N, K, regular)
+        self.lib.mmvae_gemm_set_workgroup_cap(0)
         if n_part <= 0:
             return False
         hit = eng.locate_grad(Cm)
@@ -537,12 +546,25 @@ class _Plan:
         self._sq_cover.setdefault(id(opt), []).append((off, M * N))
         plan = self
 
-        def call():
+        def launch():
             rc = plan.lib.mmvae_gemm_f32_sq(layout, M, N, K, alpha, _p(A), lda, _p(Bm), ldb, _p(Cm), ldc, _p(bias), flags | SLACK,
                                             buf.data_ptr() + 4 * base, n_part, _s())
             if rc != 0:
                 raise _lib.HipLibraryError(f"mmvae_gemm_f32_sq failed with code {rc} (layout {layout}, {M}x{N}x{K})")
 
+        if side_cap:
+            side = eng.side_stream
+            self._fork()
+
+            def call():
+                plan.lib.mmvae_gemm_set_workgroup_cap(side_cap)
+                try:
+                    with torch.cuda.stream(side):
+                        launch()
+                finally:
+                    plan.lib.mmvae_gemm_set_workgroup_cap(0)
+        else:
+            call = launch
         self._cur.append(call)
         return True
 
@@ -922,8 +944,15 @@ class _Plan:
             self._emit_fc_bwd(R, G, self.dP, None, self.w, self.dP, last.gb)
         else:
             self._emit_fc_bwd(R, G, self.dP, None, None, None, last.gb)
-        self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True)
-        S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
+        side_dw = eng.side_dw if (eng.side_stream is not None and not eng.overlap and eng.world == 1) else 0
+        if side_dw:  # input gradient first (the chain waits for it), then the weight gradient on the side branch
+            S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
+            if not self._fuse_sqnorm(TN, G, last.n_in, self.kpad(R), 1.0, self.dP, G, last.inp, last.ld_inp, last.gW,
+                                     last.n_in, None, 0, side_cap=side_dw):
+                self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True)
+        else:
+            self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True)
+            S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
         rest = self.dec_layers[:-1]
         for j in range(len(rest) - 1, -1, -1):
             l = rest[j]

@@ -286,11 +286,15 @@ def compare_with_oracle_at_given_slopes(model, case, eid, sd_in, count, moments,
         e = H.rel_l2(g, ref["grads"][n])
         assert e < tol, f"gradient {n}: rel-L2 {e:.3g} against the oracle at the same ReLU slopes"
         wg = max(wg, e)
+    # A cold first Adam step is sign-like (+-lr whatever the gradient's magnitude): an entry whose gradient is at rounding
+    # level takes either sign, and a handful of such entries (4 of 131 072 in the VAE encoder at K = 5) already cost
+    # 6e-4 in rel-L2 although the gradients themselves agree to 4e-6.  Cold steps: 1e-3; warm steps (moments set): tol.
+    tol_p = 1e-3 if count == 0 else tol
     for n, v in got_sd.items():
         if n in skip or not v.is_floating_point() or n not in sd_new:
             continue
         e = H.rel_l2(v, sd_new[n])
-        assert e < tol, f"parameter {n}: rel-L2 {e:.3g} against the oracle at the same ReLU slopes"
+        assert e < tol_p, f"parameter {n}: rel-L2 {e:.3g} against the oracle at the same ReLU slopes"
         wp = max(wp, e)
     return n_diff, wg, wp, ref
 
