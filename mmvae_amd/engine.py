@@ -172,8 +172,15 @@ class StepEngine:
         # The decoder's G-wide weight gradient (dW = dP^T h, ~105 us at C2, needed by the optimiser only) on a second
         # stream beside the backward chain of the core layers (~150 us of latency-bound launches that leave most CUs
         # idle): the persistent GEMM kernel is launched with its grid capped to `side_dw` workgroups = CUs, the chain
-        # gets the rest.  Inside the captured graph (a forked branch joined ahead of the optimisers).  0 = off.
-        self.side_dw = int(os.environ.get("MMVAE_SIDE_DW", "0"))
+        # gets the rest.  Inside the captured graph (a forked branch joined ahead of the expert's optimiser).  Used by
+        # the in-order single-rank program only.  Measured at C2 (profiles/r2_side_dw_sweep.txt): cap 125 -> -2.4 %,
+        # 140/167 -> -0.8 %, 200 -> +2.6 %; bit-identical results.  0 = off.
+        self.side_dw = int(os.environ.get("MMVAE_SIDE_DW", "125"))
+        # cap of the expert encoder's weight gradient while the shared VAE's optimiser runs beside it (553 items at C2:
+        # 3 rounds on 185 workgroups as on 256), and the switch for the small branches (loss words, bias column sums,
+        # VAE optimiser) on a second branch stream
+        self.side_dw2 = int(os.environ.get("MMVAE_SIDE_DW2", "185"))
+        self.side_branches = os.environ.get("MMVAE_SIDE_BRANCHES", "1") != "0"
         if self.side_dw:
             side_stream = True
         self.side_stream = torch.cuda.Stream(device=self.device) if side_stream else None
@@ -460,6 +467,8 @@ class _Plan:
         self.metric_slots: Dict[str, int] = {}
         self.segments: List = []  # list of closure lists, separated by ("allreduce", opt) markers
         self._cur: List = []
+        self._dirty: List = []          # branch streams with work the main stream has not joined yet
+        self._side_foreign = False      # a gradient that is not the active expert's was computed on the side stream
         self._sq_used: Dict[int, int] = {}    # per optimiser: norm-partial slots taken by fused GEMM epilogues
         self._sq_cover: Dict[int, list] = {}  # per optimiser: (offset, length) of the arena ranges they cover
         self._mask_layers: List = []   # (layer, Philox stream id) of every dropout keep mask of the program
@@ -494,6 +503,7 @@ class _Plan:
         self._cur.append(call)
 
     def _cut(self, marker):
+        self._join()  # a captured segment may not end with work outstanding on the side branch
         self.segments.append(self._cur)
         self.segments.append(marker)
         self._cur = []
@@ -519,7 +529,8 @@ class _Plan:
         self.lib.mmvae_gemm_plan(layout, M, N, K, C.byref(tile), C.byref(sk))
         return sk.value
 
-    def _fuse_sqnorm(self, layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, side_cap: int = 0) -> bool:
+    def _fuse_sqnorm(self, layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, side_cap: int = 0,
+                     on_side: bool = True) -> bool:
         """Unsplit weight-gradient GEMM straight into a gradient arena: let its epilogue also leave the partial sums of
         squares of what it stores (mmvae_gemm_f32_sq), so that the clip's norm pass does not read the 82 MB back.  Only
         without a gradient exchange: under data parallelism the norm is that of the REDUCED gradients."""
@@ -552,14 +563,18 @@ class _Plan:
             if rc != 0:
                 raise _lib.HipLibraryError(f"mmvae_gemm_f32_sq failed with code {rc} (layout {layout}, {M}x{N}x{K})")
 
-        if side_cap:
-            side = eng.side_stream
-            self._fork()
+        if side_cap:  # persistent grid capped to `side_cap` workgroups: the CUs left over serve another branch
+            side = eng.side_stream if on_side else None
+            if on_side:
+                self._fork()
 
             def call():
                 plan.lib.mmvae_gemm_set_workgroup_cap(side_cap)
                 try:
-                    with torch.cuda.stream(side):
+                    if side is not None:
+                        with torch.cuda.stream(side):
+                            launch()
+                    else:
                         launch()
                 finally:
                     plan.lib.mmvae_gemm_set_workgroup_cap(0)
@@ -613,33 +628,65 @@ class _Plan:
         nbytes = self.lib.mmvae_gemm_workspace_bytes(layout, M, N, K, sk)
         if side and self.eng.side_stream is not None and M * N <= self.eng.side_max_elems:
             self._ws_side_bytes = max(getattr(self, "_ws_side_bytes", 0), nbytes)
+            hit = self.eng.locate_grad(Cm)
+            if hit is None or hit[0] is not self.opt_exp:
+                self._side_foreign = True
             self._fork()
             self._emit_gemm(layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, sk, "side")
             return
         self._ws_bytes = max(self._ws_bytes, nbytes)
         self._emit_gemm(layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, sk, True)
 
-    def _fork(self):
-        """Side stream waits for everything enqueued so far on the main stream (graph edge under capture)."""
-        side = self.eng.side_stream
+    def _fork(self, stream=None):
+        """A branch stream (default: the side stream) waits for everything enqueued so far on the main stream (a graph
+        edge under capture)."""
+        side = stream if stream is not None else self.eng.side_stream
 
         def call():
             side.wait_stream(torch.cuda.current_stream())
 
         self._cur.append(call)
-        self._side_dirty = True
+        if side not in self._dirty:
+            self._dirty.append(side)
 
     def _join(self):
-        """Main stream waits for the side stream (before the optimiser reads the gradient arenas)."""
-        if not getattr(self, "_side_dirty", False):
+        """Main stream waits for every branch with outstanding work (before the optimiser reads the gradient arenas)."""
+        for side in self._dirty:
+            def call(side=side):
+                torch.cuda.current_stream().wait_stream(side)
+
+            self._cur.append(call)
+        self._dirty = []
+
+    def _mark(self):
+        """An event recorded at this point of the main stream: a branch emitted LATER can fork from here."""
+        ev = torch.cuda.Event()
+        self._cur.append(lambda: ev.record(torch.cuda.current_stream()))
+        return ev
+
+    def _take(self, start: int) -> list:
+        """Remove and return the calls emitted since position `start`."""
+        calls = self._cur[start:]
+        del self._cur[start:]
+        return calls
+
+    def _branch(self, stream, ev, calls):
+        """Run `calls` on `stream` as a branch of the captured graph that forks at the mark `ev` and is joined by the
+        next _join().  Emit it AFTER the main-stream work it should run beside: the graph executor enqueues in
+        emission order, and a main-stream kernel enqueued behind a branch waited for the branch's node(s) ahead of it
+        (profiles/r2_branch_order.txt).  The calls must not fork or join themselves."""
+        if not calls:
             return
-        side = self.eng.side_stream
 
         def call():
-            torch.cuda.current_stream().wait_stream(side)
+            stream.wait_event(ev)
+            with torch.cuda.stream(stream):
+                for c in calls:
+                    c()
 
         self._cur.append(call)
-        self._side_dirty = False
+        if stream not in self._dirty:
+            self._dirty.append(stream)
 
     def _next_defer_id(self) -> int:
         # position in this plan's program: the same geometry built again (another input pointer) shares the buffers
@@ -764,7 +811,13 @@ class _Plan:
         # dW[n_out, n_in] = dz^T[n_out, rows] . inp[rows, n_in]  -> straight into the gradient arena
         # (an adversary reading the first of K > 1 samples: the rows behind its B input rows are the next sample, not slack)
         k_rows = rows if (self.K > 1 and l.inp is self.z and rows != self.R) else self.kpad(rows)
-        self.gemm(TN, l.n_out, l.n_in, k_rows, l.dz, l.n_out, l.inp, l.ld_inp, l.gW, l.n_in, side=True)
+        if getattr(self, "_defer_next_dw", False):
+            # (side-branch mode) the first layer's chip-filling weight gradient is emitted behind the shared VAE's
+            # optimiser: by then the decoder's weight gradient on the side branch has released its CUs
+            self._deferred_dw = (TN, l.n_out, l.n_in, k_rows, l.dz, l.n_out, l.inp, l.ld_inp, l.gW, l.n_in)
+            self._defer_next_dw = False
+        else:
+            self.gemm(TN, l.n_out, l.n_in, k_rows, l.dz, l.n_out, l.inp, l.ld_inp, l.gW, l.n_in, side=True)
         if need_dx == "raw":
             return self.gemm_raw(NN, rows, l.n_in, l.n_out, l.dz, l.n_out, l.W, l.n_in)
         if need_dx == "full":
@@ -796,12 +849,14 @@ class _Plan:
 
         self._cur.append(call)
 
-    def optimizer(self, opt: HipAdam, max_norm: float, advance: bool = True, step: bool = True, exchange: str = "inline"):
+    def optimizer(self, opt: HipAdam, max_norm: float, advance: bool = True, step: bool = True, exchange: str = "inline",
+                  join: bool = True):
         """Fused clip + Adam over one optimiser's arenas.  `exchange` places the gradient all-reduce under data
         parallelism: "inline" (here, on the main stream), "wait" (it was begun earlier with _begin_exchange; the main
         stream joins it here) or "deferred" (it and everything after it run on the communication stream, overlapped
-        with the next step)."""
-        self._join()
+        with the next step).  `join=False`: none of this optimiser's gradients come from the side branch."""
+        if join:
+            self._join()
         self._flush_sums()
         a = opt.arena
         g = opt.param_groups[0]
@@ -869,6 +924,11 @@ class _Plan:
         self.eps = eng.buf("eps", (K, B, Z))
 
         train = self.mode == "train"
+        # branches beside the latency-bound sections (in-order single-rank program only; see MmvaeEngine.side_dw)
+        side_dw = eng.side_dw if (train and eng.side_stream is not None and not eng.overlap and eng.world == 1) else 0
+        early_branch = bool(side_dw and K == 1 and not self.iwae and eng.batch_finish and eng.merge_launches
+                            and eng.side_branches)
+        early_ev, early_calls = None, []
         # ---- forward, encoder side
         cur, ld = x, ldx
         for i, l in enumerate(self.enc_layers):
@@ -917,8 +977,15 @@ class _Plan:
             self._emit(lib.mmvae_elbo_finalize_iwae, B, K, T, _p(self.se_part), _p(self.logratio), _p(self.stat), Z,
                        _p(eng.klw_dev), 1.0, _p(self.metrics), _p(self.w), _p(self.rows3))
         else:
+            if early_branch and not self.has_adv:
+                # K = 1: the backward pass starts from dP, which the reconstruction epilogue has already written; the
+                # loss words are only logged -- their two launches leave the critical path
+                early_ev = self._mark()
+            start = len(self._cur)
             self._emit(lib.mmvae_elbo_finalize, B, K, T, _p(self.se_part), _p(self.kl_row), _p(self.stat), Z,
                        _p(eng.klw_dev), 1.0, _p(self.metrics), _p(self.w), _p(self.recon_row))
+            if early_ev is not None:
+                early_calls = self._take(start)
         if not train:  # validation: the program ends with the ELBO terms in the metrics buffer
             return self._finish_forward_only()
         # total loss slot starts as the ELBO loss (without adversaries it IS the ELBO loss word: no launch)
@@ -943,13 +1010,19 @@ class _Plan:
             # dP <- diag(w) dP in place (w = softmax weights of the K-sample bound), dbias = column sums
             self._emit_fc_bwd(R, G, self.dP, None, self.w, self.dP, last.gb)
         else:
+            if early_branch and early_ev is None:
+                early_ev = self._mark()
+            start = len(self._cur)
             self._emit_fc_bwd(R, G, self.dP, None, None, None, last.gb)
-        side_dw = eng.side_dw if (eng.side_stream is not None and not eng.overlap and eng.world == 1) else 0
+            if early_branch:  # the bias gradient (a pass over dP) is needed by the optimiser only
+                early_calls += self._take(start)
         if side_dw:  # input gradient first (the chain waits for it), then the weight gradient on the side branch
             S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
             if not self._fuse_sqnorm(TN, G, last.n_in, self.kpad(R), 1.0, self.dP, G, last.inp, last.ld_inp, last.gW,
                                      last.n_in, None, 0, side_cap=side_dw):
                 self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True)
+            if early_branch:  # behind the weight gradient on its stream: one branch, in order (probe: DESIGN.md 5)
+                self._branch(eng.side_stream, early_ev, early_calls)
         else:
             self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True)
             S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
@@ -998,6 +1071,8 @@ class _Plan:
             l = self.enc_layers[j]
             hid = l.a if l.a is not None else l.d
             addend = self.adv_grad_into.get(id(hid)) if l.return_hidden else None
+            if j == 0 and side_dw:
+                self._defer_next_dw = True
             S_next = self.bwd_layer(l, din, S, addend=addend, need_dx="raw" if j > 0 else "none")
             din, S = None, S_next
             if early and j == self.n_expert_enc:  # the last VAE layer is done: what remains is the expert's encoder
@@ -1011,8 +1086,30 @@ class _Plan:
         def emit_log_copy():
             self._emit(lib.mmvae_axpby, 256, 1.0, _p(self.metrics), 0.0, _p(self.log_buf))
 
-        self.optimizer(self.opt_vae, self.clip_vae, exchange="wait" if early else "inline")
+        dw = getattr(self, "_deferred_dw", None)
+        self._deferred_dw = None
+        late_branch = bool(side_dw and eng.side_branches and dw is not None and not self._side_foreign
+                           and self.cond is None)
+        start = len(self._cur)
+        self.optimizer(self.opt_vae, self.clip_vae, exchange="wait" if early else "inline",
+                       join=not late_branch)
         self.log_norm(self.opt_vae, "grad_norms/vae")
+        if late_branch:
+            # the shared VAE's clip + Adam (a chain of small launches) beside the expert encoder's G-wide weight
+            # gradient, whose persistent grid is capped to the workgroup count that keeps its number of rounds
+            # Emission order matters to the graph executor: the weight gradient is enqueued first and the branch
+            # forks from an event recorded ahead of it (a branch enqueued first made the GEMM wait for the branch's
+            # last node; uncapped, the branch starves behind the GEMM's one-workgroup-per-CU grid -- timelines in
+            # profiles/r2_branch_order.txt).
+            calls = self._take(start)
+            ev = self._mark()
+            layout, M, N, Kk, A, lda, Bm, ldb, Cm, ldc = dw
+            if not self._fuse_sqnorm(layout, M, N, Kk, 1.0, A, lda, Bm, ldb, Cm, ldc, None, 0, side_cap=eng.side_dw2,
+                                     on_side=False):
+                self.gemm(*dw, side=True)
+            self._branch(eng.side_stream, ev, calls)
+        elif dw is not None:
+            self.gemm(*dw, side=True)
         if early:  # the expert's exchange + update leave the main stream: its norm is logged from the comm stream
             emit_log_copy()
         self.optimizer(self.opt_exp, self.clip_exp, exchange="deferred" if early else "inline")
