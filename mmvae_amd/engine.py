@@ -241,7 +241,10 @@ class StepEngine:
         sig = self._signature()
         if sig != self._sig:
             self.flush()
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.synchronize(self.device)
+            for k, p in self._plans.items():
+                if str(k[0]).startswith("train"):
+                    p.release()
             self._plans = {k: p for k, p in self._plans.items() if not str(k[0]).startswith("train")}
             self._ptr_seen.clear()
             self._configure_parallel()
@@ -283,6 +286,15 @@ class StepEngine:
         pass's chunk partials of the uncovered ranges)."""
         n = int(self.lib.mmvae_sqnorm_partials(opt.arena.numel)) + 4096 + 64
         return self.buf(f"sqparts.{id(opt)}", (n,))
+
+    def close(self) -> None:
+        """Release every captured program now (see _Plan.release) instead of when the collector finds the cycles."""
+        self.flush()
+        torch.cuda.synchronize(self.device)
+        for p in self._plans.values():
+            p.release()
+        self._plans = {}
+        self._ptr_seen.clear()
 
     def flush(self) -> None:
         """Make the current stream wait for every deferred expert update (before parameters are read elsewhere)."""
@@ -479,6 +491,8 @@ class _Plan:
         self._ws_bytes = 0
         self._slab_floats = 0
         self._graphs: Optional[list] = None
+        self._forked = False            # the program has branches on other streams
+        self._events: List = []         # the fork / join events of the program (kept alive: see _edge)
         self._runs = 0
         self.exp_norm_log = None  # overlapped mode: the expert's pre-clip gradient norm, copied on the comm stream
         self.metrics = eng.buf("metrics", (256,))
@@ -597,6 +611,29 @@ class _Plan:
         self._sum_keep.append((A, Bm, Cm, bias))
         return True
 
+    def _gemm_group(self, jobs) -> bool:
+        """Independent GEMMs of the planner's 64x64-tile class in ONE launch, in place (not deferred): the two heads of
+        the encoder forward and backward.  jobs: (layout, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, alpha).  False
+        (nothing emitted) when a job is not of that class."""
+        if not self.eng.batch_gemms:
+            return False
+        arr = []
+        for layout, M, N, K, A, lda, Bm, ldb, Cm, ldc, bias, flags, alpha in jobs:
+            tile, sk = C.c_int(0), C.c_int(0)
+            self.lib.mmvae_gemm_plan(layout, M, N, K, C.byref(tile), C.byref(sk))
+            job = _lib.GemmJob(_p(A), _p(Bm), _p(Cm), _p(bias), lda, ldb, ldc, layout, M, N, K, float(alpha), int(flags), 0, 0)
+            if tile.value != 2 or not self.lib.mmvae_gemm_batch_job_ok(C.addressof(job)):
+                return False
+            arr.append(job)
+            self._sum_keep.append((A, Bm, Cm, bias))
+        table = (_lib.GemmJob * len(arr))(*arr)
+        total = C.c_int(0)
+        _lib.check(self.lib.mmvae_gemm_batch_prepare(len(arr), C.addressof(table), C.byref(total)), "mmvae_gemm_batch_prepare")
+        jobs_dev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(self.eng.device)
+        self._job_tables.append(jobs_dev)
+        self._emit(self.lib.mmvae_gemm_batch_f32, len(arr), jobs_dev.data_ptr(), total.value)
+        return True
+
     def _flush_gemms(self):
         if not self._gemm_jobs:
             return
@@ -637,32 +674,35 @@ class _Plan:
         self._ws_bytes = max(self._ws_bytes, nbytes)
         self._emit_gemm(layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, sk, True)
 
-    def _fork(self, stream=None):
-        """A branch stream (default: the side stream) waits for everything enqueued so far on the main stream (a graph
-        edge under capture)."""
-        side = stream if stream is not None else self.eng.side_stream
+    def _edge(self, src, dst):
+        """dst waits for everything enqueued so far on src (None = the current stream at run time): a graph edge under
+        capture.  The event lives as long as the plan: torch's Stream.wait_stream creates an event and drops it at once,
+        and destroying an event in the middle of a stream capture left the runtime with a dangling reference --
+        box-dependent segmentation faults inside later hipGraphLaunch calls (tools/debug/seg_hunt.sh)."""
+        ev = torch.cuda.Event()
+        self._events.append(ev)
 
         def call():
-            side.wait_stream(torch.cuda.current_stream())
+            s = src if src is not None else torch.cuda.current_stream()
+            d = dst if dst is not None else torch.cuda.current_stream()
+            ev.record(s)
+            d.wait_event(ev)
 
         self._cur.append(call)
+
+    def _fork(self, stream=None):
+        """A branch stream (default: the side stream) waits for everything enqueued so far on the main stream."""
+        side = stream if stream is not None else self.eng.side_stream
+        self._edge(None, side)
+        self._forked = True
         if side not in self._dirty:
             self._dirty.append(side)
 
     def _join(self):
         """Main stream waits for every branch with outstanding work (before the optimiser reads the gradient arenas)."""
         for side in self._dirty:
-            def call(side=side):
-                torch.cuda.current_stream().wait_stream(side)
-
-            self._cur.append(call)
+            self._edge(side, None)
         self._dirty = []
-
-    def _mark(self):
-        """An event recorded at this point of the main stream: a branch emitted LATER can fork from here."""
-        ev = torch.cuda.Event()
-        self._cur.append(lambda: ev.record(torch.cuda.current_stream()))
-        return ev
 
     def _take(self, start: int) -> list:
         """Remove and return the calls emitted since position `start`."""
@@ -670,16 +710,15 @@ class _Plan:
         del self._cur[start:]
         return calls
 
-    def _branch(self, stream, ev, calls):
-        """Run `calls` on `stream` as a branch of the captured graph that forks at the mark `ev` and is joined by the
-        next _join().  Emit it AFTER the main-stream work it should run beside: the graph executor enqueues in
-        emission order, and a main-stream kernel enqueued behind a branch waited for the branch's node(s) ahead of it
-        (profiles/r2_branch_order.txt).  The calls must not fork or join themselves."""
+    def _branch(self, stream, calls):
+        """Run `calls` on `stream` as a branch of the captured graph, behind the last _fork(stream) (the point of the
+        main stream it depends on) and joined by the next _join().  Emit it AFTER the main-stream work it should run
+        beside: the graph executor enqueues in emission order, and a main-stream kernel enqueued behind a branch waited
+        for the branch's node(s) ahead of it (profiles/r2_branch_order.txt).  The calls must not fork or join."""
         if not calls:
             return
 
         def call():
-            stream.wait_event(ev)
             with torch.cuda.stream(stream):
                 for c in calls:
                     c()
@@ -833,6 +872,27 @@ class _Plan:
         self._defer_sum(ws, RC, N, 1, N, N, dbias, N)
         return ws
 
+    def _emit_colsum_pair(self, B, N, pair, dbias0, dbias1):
+        """Column sums of two stacked [B, N] matrices (pair: [2, B, N], B a multiple of the 32-row chunk) in one pass;
+        the two halves of the chunk partials are summed into dbias0 / dbias1 by the deferred reduction."""
+        plan = self
+        rows = 2 * B
+        RC = rows // 32
+        self._fcws_bytes = max(getattr(self, "_fcws_bytes", 0), self.lib.mmvae_fc_workspace_bytes(rows, N))
+        ws = self.eng.buf(f"biasparts.{self._next_defer_id()}",
+                          (max(self.lib.mmvae_fc_workspace_bytes(rows, N) // 4, RC * N),))
+        self._defer_sum(ws, RC // 2, N, 1, N, N, dbias0, N)
+        self._defer_sum(ws[(RC // 2) * N:], RC // 2, N, 1, N, N, dbias1, N)
+
+        def call():
+            rc = plan.lib.mmvae_fc_epilogue_bwd(rows, N, _p(pair), N, 1, None, None, None, None, 0.0, 0, None, None,
+                                                None, None, None, 0, None, N, None, None, None, ws.data_ptr(),
+                                                ws.numel() * 4, _s())
+            if rc != 0:
+                raise _lib.HipLibraryError(f"mmvae_fc_epilogue_bwd (stacked column sums) failed with code {rc}")
+
+        self._cur.append(call)
+
     def _emit_fc_bwd(self, rows, N, din, addend, row_scale, dz_out, dbias):
         """Plain (no BN / ReLU / mask) column pass: dz = row_scale * (din + addend) (optional), dbias = column sums."""
         plan = self
@@ -928,7 +988,7 @@ class _Plan:
         side_dw = eng.side_dw if (train and eng.side_stream is not None and not eng.overlap and eng.world == 1) else 0
         early_branch = bool(side_dw and K == 1 and not self.iwae and eng.batch_finish and eng.merge_launches
                             and eng.side_branches)
-        early_ev, early_calls = None, []
+        loss_aside, early_calls = False, []
         # ---- forward, encoder side
         cur, ld = x, ldx
         for i, l in enumerate(self.enc_layers):
@@ -943,8 +1003,11 @@ class _Plan:
         self.z = eng.buf("z", (K, B, Z))
         self.kl_row = eng.buf("kl_row", (B,))
         self.stat = eng.buf("stat", (2, B))
-        self.gemm(NT, B, Z, HV, q, HV, self.mean_enc.weight, HV, self.mu, Z, bias=self.mean_enc.bias)
-        self.gemm(NT, B, Z, HV, q, HV, self.var_enc.weight, HV, self.a_raw, Z, bias=self.var_enc.bias)
+        if not self._gemm_group([
+                (NT, B, Z, HV, q, HV, self.mean_enc.weight, HV, self.mu, Z, self.mean_enc.bias, 0, 1.0),
+                (NT, B, Z, HV, q, HV, self.var_enc.weight, HV, self.a_raw, Z, self.var_enc.bias, 0, 1.0)]):
+            self.gemm(NT, B, Z, HV, q, HV, self.mean_enc.weight, HV, self.mu, Z, bias=self.mean_enc.bias)
+            self.gemm(NT, B, Z, HV, q, HV, self.var_enc.weight, HV, self.a_raw, Z, bias=self.var_enc.bias)
         self._emit(lib.mmvae_reparam_kl_fwd, B, Z, K, _p(self.mu), _p(self.a_raw), _p(self.eps), self.var_eps,
                    _p(self.std), _p(self.z), _p(self.kl_row), _p(self.stat))
         if self.mode == "embed":  # predict path: the program ends at z
@@ -980,11 +1043,11 @@ class _Plan:
             if early_branch and not self.has_adv:
                 # K = 1: the backward pass starts from dP, which the reconstruction epilogue has already written; the
                 # loss words are only logged -- their two launches leave the critical path
-                early_ev = self._mark()
+                loss_aside = True
             start = len(self._cur)
             self._emit(lib.mmvae_elbo_finalize, B, K, T, _p(self.se_part), _p(self.kl_row), _p(self.stat), Z,
                        _p(eng.klw_dev), 1.0, _p(self.metrics), _p(self.w), _p(self.recon_row))
-            if early_ev is not None:
+            if loss_aside:
                 early_calls = self._take(start)
         if not train:  # validation: the program ends with the ELBO terms in the metrics buffer
             return self._finish_forward_only()
@@ -1010,8 +1073,6 @@ class _Plan:
             # dP <- diag(w) dP in place (w = softmax weights of the K-sample bound), dbias = column sums
             self._emit_fc_bwd(R, G, self.dP, None, self.w, self.dP, last.gb)
         else:
-            if early_branch and early_ev is None:
-                early_ev = self._mark()
             start = len(self._cur)
             self._emit_fc_bwd(R, G, self.dP, None, None, None, last.gb)
             if early_branch:  # the bias gradient (a pass over dP) is needed by the optimiser only
@@ -1022,7 +1083,8 @@ class _Plan:
                                      last.n_in, None, 0, side_cap=side_dw):
                 self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True)
             if early_branch:  # behind the weight gradient on its stream: one branch, in order (probe: DESIGN.md 5)
-                self._branch(eng.side_stream, early_ev, early_calls)
+                self._fork()  # (the weight gradient may have stayed on the main stream)
+                self._branch(eng.side_stream, early_calls)
         else:
             self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True)
             S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
@@ -1043,9 +1105,10 @@ class _Plan:
         if zi is not None:
             self._emit(lib.mmvae_axpby, B * Z, 1.0, _p(zi), 1.0, _p(self.dz_lat))
         # ---- reparameterisation + heads backward
-        self.dmu = eng.buf("dmu", (B, Z))
-        self.da = eng.buf("da", (B, Z))
-        self.dq = eng.buf("dq", (B, HV))
+        dm = eng.buf("dmu_da", (2, B, Z))  # one buffer: the two heads' bias column sums are one pass over [2B, Z]
+        self.dmu, self.da = dm[0], dm[1]
+        dq2 = eng.buf("dq", (2, B, HV))    # one slab per head: the next layer's tail sums them on the fly
+        self.dq = dq2[0]
         if self.iwae:
             # d/dz of the log-ratio joins the decoder's gradient, its direct dependence on the variance arrives as
             # dstd_extra; the analytic-KL terms of the kernel are switched off (kl_scale_host = 0)
@@ -1057,13 +1120,21 @@ class _Plan:
         else:
             self._emit(lib.mmvae_reparam_kl_bwd, B, Z, K, _p(self.mu), _p(self.std), _p(self.eps), _p(self.dz_lat), None,
                        None, None, _p(eng.klw_dev), 1.0 / B, self.var_eps, _p(self.dmu), _p(self.da))
+        if B % 32 == 0 and eng.batch_finish:
+            self._emit_colsum_pair(B, Z, dm, eng.grad_of(self.mean_enc.bias), eng.grad_of(self.var_enc.bias))
+        else:
+            for dy, lin in ((self.dmu, self.mean_enc), (self.da, self.var_enc)):
+                self._emit_fc_bwd(B, Z, dy, None, None, None, eng.grad_of(lin.bias))
         for dy, lin in ((self.dmu, self.mean_enc), (self.da, self.var_enc)):
-            self._emit_fc_bwd(B, Z, dy, None, None, None, eng.grad_of(lin.bias))
             self.gemm(TN, Z, HV, self.kpad(B), dy, Z, q, HV, eng.grad_of(lin.weight), HV, side=True)
-        self.gemm(NN, B, HV, Z, self.dmu, Z, self.mean_enc.weight, HV, self.dq, HV)
-        self.gemm(NN, B, HV, Z, self.da, Z, self.var_enc.weight, HV, self.dq, HV, flags=ACC)
         # ---- backward, encoder side
-        din, S = self.dq, 1
+        if self._gemm_group([(NN, B, HV, Z, self.dmu, Z, self.mean_enc.weight, HV, dq2[0], HV, None, 0, 1.0),
+                             (NN, B, HV, Z, self.da, Z, self.var_enc.weight, HV, dq2[1], HV, None, 0, 1.0)]):
+            din, S = dq2, 2
+        else:
+            self.gemm(NN, B, HV, Z, self.dmu, Z, self.mean_enc.weight, HV, self.dq, HV)
+            self.gemm(NN, B, HV, Z, self.da, Z, self.var_enc.weight, HV, self.dq, HV, flags=ACC)
+            din, S = self.dq, 1
         early = eng.overlap
         if early and len(self.enc_layers) == self.n_expert_enc:  # no VAE-encoder layers: VAE gradients are final
             self._begin_exchange(self.opt_vae)
@@ -1102,12 +1173,12 @@ class _Plan:
             # last node; uncapped, the branch starves behind the GEMM's one-workgroup-per-CU grid -- timelines in
             # profiles/r2_branch_order.txt).
             calls = self._take(start)
-            ev = self._mark()
+            self._fork()  # the branch depends on the chain up to here; its kernels are enqueued behind the GEMM
             layout, M, N, Kk, A, lda, Bm, ldb, Cm, ldc = dw
             if not self._fuse_sqnorm(layout, M, N, Kk, 1.0, A, lda, Bm, ldb, Cm, ldc, None, 0, side_cap=eng.side_dw2,
                                      on_side=False):
                 self.gemm(*dw, side=True)
-            self._branch(eng.side_stream, ev, calls)
+            self._branch(eng.side_stream, calls)
         elif dw is not None:
             self.gemm(*dw, side=True)
         if early:  # the expert's exchange + update leave the main stream: its norm is logged from the comm stream
@@ -1379,6 +1450,19 @@ class _Plan:
             ev = torch.cuda.Event()
             ev.record(tail)
         return ev
+
+    def release(self):
+        """Destroy the captured graphs and drop the program's closures (which reference the plan: a cycle only the
+        cyclic collector would free).  A graph with forked branches owns runtime-internal streams, and a process that
+        piled up dozens of such executables (a test session; plans rebuilt after every settings change) crashed inside
+        hipGraphLaunch on some boxes.  The caller has synchronised the device."""
+        for g in self._graphs or []:
+            if not isinstance(g, tuple):
+                g.reset()
+        self._graphs = None
+        self.segments = []
+        self._cur = []
+        self._events = []
 
     @staticmethod
     def _launch_eager(seg):

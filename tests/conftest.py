@@ -33,3 +33,20 @@ def pytest_collection_modifyitems(session, config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def release_captured_programs(request):
+    """Engines, their plans and the closures of a plan reference each other: without a collection the captured graphs of
+    every earlier test (each with the runtime-internal streams of its forked branches) stay alive until the cyclic
+    collector happens to run.  Dozens of live multi-stream graph executables made later launches crash inside the
+    runtime on some boxes (null stream, tools/debug/seg_hunt.sh); a training process holds a handful."""
+    yield
+    if request.node.get_closest_marker("gpu") is None or os.environ.get("MMVAE_TEST_NO_GC", "0") != "0":
+        return
+    import gc
+
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        gc.collect()

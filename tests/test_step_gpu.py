@@ -102,7 +102,9 @@ def test_engine_follows_settings_changed_after_capture(name):
     for a, b in zip(ra, rb):
         for k, v in a["sd"].items():
             if v.is_floating_point() and not k.endswith("lin.bias"):
-                assert H.rel_l2(v, b["sd"][k]) < 1e-5, k
+                # batch means of pre-activations sit next to zero: their relative distance is the least stable word
+                tol = 5e-5 if k.endswith("running_mean") else 1e-5
+                assert H.rel_l2(v, b["sd"][k]) < tol, k
         la, lb = a["logged"][f"loss/training/{a['eid']}"], b["logged"][f"loss/training/{b['eid']}"]
         assert abs(la - lb) <= 2e-5 * abs(lb)
 

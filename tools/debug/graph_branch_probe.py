@@ -198,3 +198,62 @@ def p_beside_adam():
 
 
 run("VAE optimiser beside the expert's Adam", p_beside_adam, 422, 632)
+
+
+# ---- the same step as SEPARATE single-stream graphs joined by ordinary stream events (no forked capture)
+def capture(body, stream):
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        body()
+        stream.synchronize()
+        with torch.cuda.graph(g, stream=stream):
+            body()
+    return g
+
+
+def run_multi(name, launch, ideal):
+    with torch.cuda.stream(main):
+        for _ in range(3):
+            launch()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            launch()
+        b.record()
+        b.synchronize()
+        print(f"{name:58s} {a.elapsed_time(b) * 100:7.1f} us   (ideal {ideal})", flush=True)
+
+
+g_a = capture(lambda: (k(50), k(100)), main)                        # recon, K4b
+g_side1 = capture(lambda: (k(150), k(10), k(10)), side)             # K4a, loss words
+g_chain = capture(lambda: [k(17)] + [k(20) for _ in range(5)], main)
+g_k2 = capture(lambda: k(100), main)
+g_v = capture(lambda: (k(30), k(10)), side)
+g_tail = capture(lambda: (k(50), k(5)), main)
+g_whole = capture(lambda: (k(50), k(100), k(17), [k(20) for _ in range(5)], k(100), k(50), k(5)), main)
+e1, e2, e3 = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+
+
+def launch_multi():
+    g_a.replay(); e1.record(main)
+    side.wait_event(e1)
+    with torch.cuda.stream(side):
+        g_side1.replay()
+    g_chain.replay(); e2.record(main)
+    g_k2.replay()
+    side.wait_event(e2)
+    with torch.cuda.stream(side):
+        g_v.replay()
+        e3.record(side)
+    main.wait_event(e3)
+    g_tail.replay()
+
+
+def launch_cut_only():  # the main-stream work as four graphs back to back, nothing on the side
+    g_a.replay(); g_chain.replay(); g_k2.replay(); g_tail.replay()
+
+
+run_multi("main-stream kernels only, ONE graph", lambda: g_whole.replay(), 422)
+run_multi("main-stream kernels only, four graphs back to back", launch_cut_only, 422)
+run_multi("six single-stream graphs + stream events", launch_multi, 422)
