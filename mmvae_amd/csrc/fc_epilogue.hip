@@ -323,172 +323,6 @@ __global__ __launch_bounds__(256) void fc_colsum_finish_kernel(const float* __re
     dbias[c] = s;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Column-owner variants for batches of at most OWN_MAX_ROWS rows: one workgroup owns OC feature columns over ALL batch
-// rows, so the column statistics are workgroup-local and the two passes (statistics, then normalise) of a BatchNorm
-// layer become ONE launch -- the values stay in registers between them.  The core layers of the step are chains of
-// 5-15 us launches whose length is set by the launch count, not by the bytes; N/16 workgroups of a
-// 256..1024-wide layer still cover 16-64 CUs.  Thread = (column cl, row group rg): rows rg, rg + OG, rg + 2 OG, ...
-constexpr int OC = 16;            // columns per workgroup: a wave covers 4 rows x 64 B
-constexpr int OG = 64;            // row groups per workgroup (1024 threads: the loads in flight hide the latency that
-                                  // 256 threads x 32 rows each could not -- 40 us against 21 for the two-pass pair)
-constexpr int OT = OC * OG;
-constexpr int OWN_MAX_ROWS = 1024;
-
-// Sum of v over the OG row groups for each of the OC columns (fixed order); result valid in every thread.
-__device__ __forceinline__ float owner_colsum(float v, float (*red)[OC], int rg, int cl) {
-    __syncthreads();
-    red[rg][cl] = v;
-    __syncthreads();
-    float s = 0.f;
-#pragma unroll 8
-    for (int g = 0; g < OG; ++g) s += red[g][cl];  // fixed order
-    return s;
-}
-
-// v[i] = init + sum over the split-K slabs of element (row rg + i*OG, column c), slab order, loads of one slab issued
-// together.  Rows >= B are clamped (callers mask).
-template <int RPT, int U>
-__device__ __forceinline__ void owner_slab_sum(float (&v)[RPT], const float* __restrict__ in, int64_t ld,
-                                               int64_t slab_stride, int n_slabs, int rg, int B, int c, float init) {
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) v[i] = init;
-    const int64_t step = (int64_t)OG * ld;
-    const float* p = in + (int64_t)rg * ld + c;
-    int s = 0;
-    for (; s + U <= n_slabs; s += U) {  // U slabs x RPT rows in flight per thread
-        float t[U][RPT];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int i = 0; i < RPT; ++i) t[u][i] = (rg + i * OG < B) ? p[(int64_t)(s + u) * slab_stride + i * step] : 0.f;
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int i = 0; i < RPT; ++i) v[i] += t[u][i];
-    }
-    for (; s < n_slabs; ++s) {
-        float t[RPT];
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) t[i] = (rg + i * OG < B) ? p[(int64_t)s * slab_stride + i * step] : 0.f;
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) v[i] += t[i];
-    }
-}
-
-// Training BatchNorm layer tail in one launch: z = bias + slabs (stored), column mean / variance over all rows (two
-// passes over registers), running statistics, normalise, ReLU, dropout.
-template <int RPT>
-__global__ __launch_bounds__(OT) void fc_fwd_owner_kernel(const FwdArgs a) {
-    __shared__ float red[OG][OC];
-    const int cl = threadIdx.x & (OC - 1), rg = threadIdx.x / OC;
-    const int c0 = blockIdx.x * OC + cl;
-    const bool cv = c0 < a.N;
-    const int c = cv ? c0 : a.N - 1;
-    float zv[RPT];
-    owner_slab_sum<RPT, (RPT <= 8 ? 4 : 2)>(zv, a.in, a.ld_in, a.slab_stride, a.n_slabs, rg, a.B, c, a.bias ? a.bias[c] : 0.f);
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < RPT; ++i)
-        if (rg + i * OG < a.B) s += zv[i];
-    const float mean = owner_colsum(s, red, rg, cl) / (float)a.B;
-    float m2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < RPT; ++i)
-        if (rg + i * OG < a.B) {
-            const float d = zv[i] - mean;
-            m2 += d * d;
-        }
-    const float var = owner_colsum(m2, red, rg, cl) / (float)a.B;
-    const float invstd = 1.0f / sqrtf(var + a.eps);
-    if (!cv) return;
-    const float gam = a.gamma ? a.gamma[c] : 1.f, bet = a.beta ? a.beta[c] : 0.f;
-    if (rg == 0) {
-        if (a.save_mean) a.save_mean[c] = mean;
-        if (a.save_invstd) a.save_invstd[c] = invstd;
-        if (a.running_mean) a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
-        if (a.running_var) {
-            const float unb = a.B > 1 ? var * ((float)a.B / (float)(a.B - 1)) : var;
-            a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unb;
-        }
-        if (blockIdx.x == 0 && cl == 0 && a.nbt) *a.nbt += 1;
-    }
-    // every keep-mask byte is loaded ahead of the first store (the stores may alias: loads behind them would each
-    // wait for a round trip)
-    uint8_t mk[RPT];
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        const int r = rg + i * OG;
-        mk[i] = (a.mask && r < a.B) ? a.mask[(int64_t)r * a.N + c] : (uint8_t)1;
-    }
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        const int r = rg + i * OG;
-        if (r < a.B) {
-            const int64_t o = (int64_t)r * a.ld_out + c;
-            a.z_out[o] = zv[i];
-            float y = (zv[i] - mean) * invstd * gam + bet;
-            if (a.relu) y = fmaxf(y, 0.f);
-            if (a.a_out) a.a_out[o] = y;
-            if (a.d_out) a.d_out[o] = a.mask ? (mk[i] ? y * a.keep_scale : 0.f) : y;
-        }
-    }
-}
-
-// BatchNorm layer backward in one launch: dy through dropout / ReLU, the three column sums over all rows, dz.
-template <int RPT>
-__global__ __launch_bounds__(OT) void fc_bwd_owner_kernel(const BwdArgs a) {
-    __shared__ float red[OG][OC];
-    const int cl = threadIdx.x & (OC - 1), rg = threadIdx.x / OC;
-    const int c0 = blockIdx.x * OC + cl;
-    const bool cv = c0 < a.N;
-    const int c = cv ? c0 : a.N - 1;
-    const float mean = a.save_mean[c], invstd = a.save_invstd[c];
-    float dy[RPT], xh[RPT];
-    owner_slab_sum<RPT, (RPT <= 4 ? 4 : (RPT <= 8 ? 2 : 1))>(dy, a.din, a.ld_in, a.slab_stride, a.n_slabs, rg, a.B, c, 0.f);
-    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        const int r = rg + i * OG;
-        if (r < a.B) {
-            dy[i] = bwd_dy(a, r, c, dy[i]);
-            xh[i] = (a.z[(int64_t)r * a.ld_out + c] - mean) * invstd;
-            s1 += dy[i];
-            s2 += dy[i] * xh[i];
-            s3 += xh[i];
-        } else {
-            dy[i] = 0.f;
-            xh[i] = 0.f;
-        }
-    }
-    const float S1 = owner_colsum(s1, red, rg, cl);
-    const float S2 = owner_colsum(s2, red, rg, cl);
-    const float S3 = owner_colsum(s3, red, rg, cl);
-    if (!cv) return;
-    const float gam = a.gamma ? a.gamma[c] : 1.f;
-    const float invB = 1.f / (float)a.B;
-    const float m1 = S1 * invB, m2 = S2 * invB;
-    if (rg == 0) {
-        if (a.dbeta) a.dbeta[c] = S1;
-        if (a.dgamma) a.dgamma[c] = S2;
-        if (a.dbias) a.dbias[c] = -gam * invstd * m2 * S3;
-    }
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        const int r = rg + i * OG;
-        if (r < a.B) a.dz_out[(int64_t)r * a.ld_out + c] = gam * invstd * (dy[i] - m1 - xh[i] * m2);
-    }
-}
-
-// MMVAE_FC_OWNER=0 keeps the two-pass kernels at every size (A/B switch, read once).
-inline bool owner_enabled() {
-    static const bool v = [] {
-        const char* e = getenv("MMVAE_FC_OWNER");
-        return !(e && e[0] == '0');
-    }();
-    return v;
-}
-
 // LayerNorm without affine: one wavefront per row.
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int B, int N, const float* __restrict__ x, int64_t ldx,
                                                             float eps, float* __restrict__ y, int64_t ldy,
@@ -584,17 +418,6 @@ extern "C" int mmvae_fc_epilogue_fwd(int B, int N, const float* in, int64_t ld_i
     a.RC = ceil_div_i(B, RPC);
     const dim3 grid(ceil_div_i(N, CW), a.RC);
     hipStream_t s = (hipStream_t)stream;
-    if (stats && B <= OWN_MAX_ROWS && owner_enabled()) {
-        const dim3 og(ceil_div_i(N, OC));
-        if (B <= 4 * OG)
-            MMVAE_LAUNCH(fc_fwd_owner_kernel<4>, og, dim3(OT), 0, s, a);
-        else if (B <= 8 * OG)
-            MMVAE_LAUNCH(fc_fwd_owner_kernel<8>, og, dim3(OT), 0, s, a);
-        else
-            MMVAE_LAUNCH(fc_fwd_owner_kernel<16>, og, dim3(OT), 0, s, a);
-        MMVAE_LAUNCH_CHECK();
-        return MMVAE_OK;
-    }
     if (stats) {
         MMVAE_LAUNCH(fc_fwd_stats_kernel, grid, dim3(CT), 0, s, a);
         MMVAE_LAUNCH_CHECK();
@@ -647,15 +470,7 @@ extern "C" int mmvae_fc_epilogue_bwd(int B, int N, const float* din, int64_t ld_
     a.RC = ceil_div_i(B, RPC);
     const dim3 grid(ceil_div_i(N, CW), a.RC);
     hipStream_t s = (hipStream_t)stream;
-    if (has_bn && B <= OWN_MAX_ROWS && owner_enabled()) {
-        const dim3 og(ceil_div_i(N, OC));
-        if (B <= 4 * OG)
-            MMVAE_LAUNCH(fc_bwd_owner_kernel<4>, og, dim3(OT), 0, s, a);
-        else if (B <= 8 * OG)
-            MMVAE_LAUNCH(fc_bwd_owner_kernel<8>, og, dim3(OT), 0, s, a);
-        else
-            MMVAE_LAUNCH(fc_bwd_owner_kernel<16>, og, dim3(OT), 0, s, a);
-    } else if (has_bn) {
+    if (has_bn) {
         MMVAE_LAUNCH(fc_bwd_stats_kernel<true>, grid, dim3(CT), 0, s, a);
         MMVAE_LAUNCH_CHECK();
         MMVAE_LAUNCH(fc_bwd_apply_kernel, grid, dim3(CT), 0, s, a);
