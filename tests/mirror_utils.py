@@ -355,8 +355,12 @@ def replay_regen(name, device, use_engine=True, steps=None, after=None, K=1):
                         grads[n] = o.arena.grad_view(i).detach().cpu().clone()
             r = {"logged": logged, "sd": sd, "eid": eid, "grads": grads, "kinks": None}
             if use_engine and device != "cpu":
+                # K > 1: the softmax over the K samples' log-weights (|l_k| ~ 3e6 at G = 20 000, built from fp32
+                # outputs) turns a 1e-3 absolute difference between two correct fp32 evaluations of l_k into a 1e-3
+                # relative difference of that cell's weights: the comparison's noise floor is ~1e-4, not ~3e-6
                 kinks, wg, wp, ref = compare_with_oracle_at_given_slopes(
-                    model, case, eid, sd_in, count, moments, x, eps, masks, labels, case["kl_weights"][t], sd, grads)
+                    model, case, eid, sd_in, count, moments, x, eps, masks, labels, case["kl_weights"][t], sd, grads,
+                    tol=5e-4 if (K or 1) > 1 else 1e-4)
                 r.update(kinks=kinks, oracle_grad=wg, oracle_param=wp, oracle=ref)
             results.append(r)
         replay_training.last_engine = model._engine
