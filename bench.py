@@ -91,41 +91,46 @@ def spawn_ranks(argv, n: int) -> int:
 
 # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks (no sparsity)
 BF16_DENSE_TFLOPS = 2500.0
+PMC_FETCH_KIB, PMC_WRITE_KIB = 0.0, 0.0  # filled from the PMC passes below
 F32_MFMA_TFLOPS = 157.3
 # HBM bytes per launch of the roofline kernel, from the separate rocprofv3 --pmc passes summarised in
-# profiles/r1d_pmc_roofline_kernel.csv (r1b: 48174): 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, in KiB.
-# Algorithmic bytes of the launch: 4 (B*1024 + B*G + 1024*G) = 125.0 MB (X is re-read by the 8 row tiles: 2x fetch).
-HBM_TRAFFIC_PMC_BYTES = (2 * 47450 + 80000) * 1024
+# profiles/r2_pmc_roofline_kernel.csv: 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, in KiB.
+# Algorithmic bytes of the launch: 4 (B*G + 1024*G + B*1024) = 125.0 MB (operands once, the layer's output once); the
+# kernel writes 16 split-K slabs of that output (33.5 MB) for the layer tail to sum.
+HBM_TRAFFIC_PMC_BYTES = int((2 * PMC_FETCH_KIB + PMC_WRITE_KIB) * 1024)
 
 
-def time_dominant_kernel(cfg, device, iters=10):
-    """Roofline leg: the dominant kernel of the step (2 launches per step -- enc-L1 dW and, with the tile transposed,
-    dec-L2 dW -- ~23 % of the GPU time in profiles/r1_bench_kernel_stats.csv) -- the weight-gradient GEMM of a G-wide layer, dW[1024, G] = dY^T[1024, B] .
-    X[B, G] (TN layout, fp32 in / fp32 out, computed as 6 bf16 MFMAs per product = gemm_x3_kernel<TN>) -- launched on
-    the current stream with HIP events around each launch.  Returns (avg seconds per launch, algorithmic FLOPs per
-    launch = 2 M N K)."""
-    from mmvae_amd import ops
-
-    B, G, H1 = cfg["batch"], max(cfg["experts"].values()), 1024
-    g = torch.Generator(device=device).manual_seed(1)
-    dY = torch.randn(B, H1, device=device, generator=g)
-    X = torch.randn(B, G, device=device, generator=g)
-    dW = torch.empty(H1, G, device=device)
-    for _ in range(3):
-        ops.gemm(ops.GEMM_TN, dY, X, out=dW, splitk=1)
-    torch.cuda.synchronize()
-    # one event pair around `iters` back-to-back launches on the launch stream: the average is the kernel's duration
-    # (an event pair per launch would add the ~10 us host launch latency to every sample).  Kept short: after ~1.7 ms
-    # of nothing but this GEMM the chip lowers its clock and the same launch goes from 132 to 170 us
-    # (profiles/r1d: kernel trace of the leg) -- a state the training step, which interleaves lighter kernels, is never in
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        ops.gemm(ops.GEMM_TN, dY, X, out=dW, splitk=1)
-    e1.record()
-    torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) / iters * 1e-3
-    return t, 2.0 * H1 * G * B
+def time_dominant_kernel(model, step, first, steps=8):
+    """Roofline leg: the dominant kernel family of the step is its five G-wide GEMMs (2 B G 1024 FLOP each, half of the
+    step's critical path).  Measured on the first of them, the expert encoder's forward GEMM Y[B, 1024] = X[B, G] .
+    W^T (NT layout, fp32 in / fp32 out, 6 bf16 MFMAs per product, split-K 16 into raw slabs:
+    gemm_x3w_kernel<NT, 256x128>), INSIDE the step: `steps` more training steps are run eagerly (same launches in the
+    same order, not replayed from the graph) with a HIP event pair around that launch on its launch stream
+    (engine probe hook).  Launched alone the same kernel takes 115-127 us (cold clocks and caches,
+    tools/debug/leg_probe.py) against ~103 us where it actually runs.  Returns (median seconds per launch, algorithmic
+    FLOPs per launch = 2 M N K)."""
+    eng = model._engine
+    prev = os.environ.get("MMVAE_NO_GRAPH")
+    os.environ["MMVAE_NO_GRAPH"] = "1"
+    probe = {}
+    try:
+        for p in eng._plans.values():
+            p.probe = probe
+        for i in range(steps):
+            step(first + i)
+        torch.cuda.synchronize()
+    finally:
+        for p in eng._plans.values():
+            p.probe = None
+        if prev is None:
+            os.environ.pop("MMVAE_NO_GRAPH", None)
+        else:
+            os.environ["MMVAE_NO_GRAPH"] = prev
+    pairs = probe.get("enc_l1_fwd", [])[2:]
+    if not pairs:
+        raise RuntimeError("roofline leg: the engine did not run the probed GEMM")
+    ts = sorted(e0.elapsed_time(e1) for e0, e1, _ in pairs)
+    return ts[len(ts) // 2] * 1e-3, pairs[0][2]
 
 
 def cpu_baseline(cfg, seconds):
@@ -340,6 +345,9 @@ def main():
         t = torch.tensor([el], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t)
+    leg = None
+    if on_gpu and a.mode == "train" and feed is None and getattr(model, "_engine", None) and not a.no_engine:
+        leg = time_dominant_kernel(model, step, n_setup + a.warmup + a.steps)  # every rank: the steps exchange gradients
     if getattr(model, "_engine", None):
         model._flush_engine()
     loss = {k: float(v.detach() if torch.is_tensor(v) else v) for k, v in model.logged.items()
@@ -373,23 +381,28 @@ def main():
             "step_tflops": synthetic.flops_per_cell(G, K) * cells_per_s / world / 1e12,
             "last_losses": loss, "setup_steps": n_setup,
         }
-        if on_gpu:
+        if leg is not None:
             from mmvae_amd import _lib
 
-            tk, fl = time_dominant_kernel(cfg, device)
+            tk, fl = leg
             x3 = _lib.load().mmvae_gemm_get_precision() == _lib.GEMM_PRECISION_BF16X3
             # bf16x3: every fp32 product costs 6 bf16 MFMA products, so the matrix-core ceiling for ALGORITHMIC fp32
             # flops is the dense bf16 peak / 6; the exact-f32 mode is bounded by the fp32 MFMA peak.
             peak = BF16_DENSE_TFLOPS / 6.0 if x3 else F32_MFMA_TFLOPS
             out["roofline"] = {"bound": "mfma",
-                               "kernel": ("gemm_x3_kernel<TN,128x160> (bf16x3 MFMA)" if x3 else "gemm_f32_kernel<TN> (f32 MFMA)")
-                                         + ": dW of a G-wide layer",
+                               "kernel": ("gemm_x3w_kernel<NT,256x128> (bf16x3 MFMA, 4 multiplier + 4 stager waves per CU)"
+                                          if x3 else "gemm_f32_kernel<NT> (f32 MFMA)")
+                                         + ": forward GEMM of the G-wide expert encoder layer, split-K 16",
                                "achieved": fl / tk / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl / tk / (peak * 1e12),
-                               "traffic": HBM_TRAFFIC_PMC_BYTES, "us_per_launch": tk * 1e6, "flops_per_launch": fl,
+                               "traffic": HBM_TRAFFIC_PMC_BYTES, "algorithmic_bytes": 4 * (cfg["batch"] * 1024 + (cfg["batch"] + 1024)
+                                                                                               * max(cfg["experts"].values())),
+                               "us_per_launch": tk * 1e6, "flops_per_launch": fl,
+                               "measured": "median of HIP event pairs around this launch on its launch stream in 6 "
+                                           "eagerly launched training steps behind the timed region",
                                "peak_note": "dense bf16 MFMA peak 2500 / 6 MFMA products per fp32 product" if x3
                                             else "dense fp32 MFMA peak",
                                "frac_of_f32_mfma_peak": fl / tk / (F32_MFMA_TFLOPS * 1e12)}
-        else:
+        elif not on_gpu:
             out["rehearsal"] = "CPU plumbing over gloo: launch / exchange / timing logic only, not a measurement"
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_seconds)

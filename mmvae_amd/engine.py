@@ -491,6 +491,8 @@ class _Plan:
         self._ws_bytes = 0
         self._slab_floats = 0
         self._graphs: Optional[list] = None
+        self._probe_next = None         # tag for the next emitted GEMM (measurement hook, see _emit_gemm)
+        self.probe = None               # dict tag -> [(event, event, flops)] while an eager run is being measured
         self._forked = False            # the program has branches on other streams
         self._events: List = []         # the fork / join events of the program (kept alive: see _edge)
         self._runs = 0
@@ -759,8 +761,22 @@ class _Plan:
 
     def _emit_gemm(self, layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, sk, use_ws):
         plan = self
+        tag, self._probe_next = self._probe_next, None
 
         def launch():
+            # measurement hook (bench.py's roofline leg): in an EAGER run with plan.probe set, the tagged GEMM is
+            # bracketed by a timing event pair on its launch stream; never active under capture
+            pr = plan.probe
+            if tag is not None and pr is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream())
+                launch_gemm()
+                e1.record(torch.cuda.current_stream())
+                pr.setdefault(tag, []).append((e0, e1, 2.0 * M * N * K))
+            else:
+                launch_gemm()
+
+        def launch_gemm():
             ws = plan.ws_side if use_ws == "side" else plan.ws
             c_ptr = _p(Cm) if Cm is not None else plan.slab.data_ptr()
             rc = plan.lib.mmvae_gemm_f32(layout, M, N, K, alpha, _p(A), lda, _p(Bm), ldb, c_ptr, ldc, _p(bias), flags | SLACK, sk,
@@ -992,6 +1008,7 @@ class _Plan:
         # ---- forward, encoder side
         cur, ld = x, ldx
         for i, l in enumerate(self.enc_layers):
+            self._probe_next = "enc_l1_fwd" if i == 0 else None
             cur = self.fwd_layer(f"{self.eid}.enc{i}" if i < self.n_expert_enc else f"vae.enc{i}", l, cur, ld, B,
                                  training=train, mask_stream=i)
             ld = l.n_out

@@ -15,9 +15,16 @@ GF = 2.0 * B * G * H1  # one G-wide GEMM
 
 # kernel-name substring -> (label, kind, algorithmic work per launch [bytes or flops])
 TABLE = [
+    # wave-specialised persistent kernel (round 2): 4 multiplier + 4 stager waves per CU
+    ("gemm_x3w_kernel<1; 1; 256; 160", "dW enc-L1 (TN 256x160, bf16x3, grid capped to 185: VAE optimiser beside it)", "x3", GF),
+    ("gemm_x3w_kernel<1; 1; 160; 256", "dW dec-L2 (TN 160x256, bf16x3, side branch on 125 CUs beside the core backward chain)",
+     "x3", GF),
+    ("gemm_x3_kernel<0; 0; 128; 160; 4; 1; true; 1", "dec-L2 fwd + recon epilogue (NT 128x160, bf16x3, 2 x 4-wave kernel)", "x3", GF),
+    ("gemm_x3w_kernel<0; 0; 256; 128", "enc-L1 fwd split-K 16 (NT 256x128, bf16x3)", "x3", GF),
+    ("gemm_x3w_kernel<0; 1; 256; 128", "dX dec-L2 split-K 16 (NN 256x128, bf16x3)", "x3", GF),
+    # (MMVAE_X3W=0: the round-1 kernels)
     ("gemm_x3_kernel<1; 1; 128; 160", "dW enc-L1 (TN 128x160, bf16x3)", "x3", GF),
     ("gemm_x3_kernel<1; 1; 160; 128", "dW dec-L2 (TN 160x128, bf16x3)", "x3", GF),
-    ("gemm_x3_kernel<0; 0; 128; 160; 4; 1; true; 1", "dec-L2 fwd + recon epilogue (NT 128x160, bf16x3)", "x3", GF),
     ("gemm_x3_kernel<0; 0; 128; 128", "enc-L1 fwd split-K 16 (NT 128x128, bf16x3)", "x3", GF),
     ("gemm_x3_kernel<0; 1; 128; 128", "dX dec-L2 split-K 16 (NN 128x128, bf16x3)", "x3", GF),
     ("adam_step_kernel", "clip + Adam over the flat arenas (expert 41 M + VAE 0.36 M params, 28 B each)", "hbm",
@@ -25,7 +32,7 @@ TABLE = [
     # since r1c the G-wide weight gradients leave their norm partials in the GEMM epilogue: the pass covers the rest
     ("sqnorm_kernel", "gradient sum of squares of the ranges no GEMM epilogue covers (~1.5 M floats, 3 launches)",
      "hbm", None),
-    ("gemm_f32_batch_kernel", "7 core-layer weight-gradient GEMMs in one grid (exact f32)", "f32",
+    ("gemm_f32_batch_kernel", "grouped 64x64-tile GEMMs (exact f32): 7 core-layer weight gradients in one grid; the two heads forward; the two heads dX", "f32",
      2.0 * B * (2 * H1 * H2 + 2 * H2 * V + 2 * V * Z + 2 * V * Z)),
     ("fc_bwd_stats_kernel<false>", "column sums / bias gradients (largest: dP 512 x 20000)", "hbm", None),
     ("sum_parts_batch_kernel", "batched fixed-order finishes (bias partials)", "hbm", None),
