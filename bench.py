@@ -91,7 +91,7 @@ def spawn_ranks(argv, n: int) -> int:
 
 # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks (no sparsity)
 BF16_DENSE_TFLOPS = 2500.0
-PMC_FETCH_KIB, PMC_WRITE_KIB = 0.0, 0.0  # filled from the PMC passes below
+PMC_FETCH_KIB, PMC_WRITE_KIB = 60332.6, 32768.0  # rocprofv3 --pmc passes of tools/roofline_kernel.py (see below)
 F32_MFMA_TFLOPS = 157.3
 # HBM bytes per launch of the roofline kernel, from the separate rocprofv3 --pmc passes summarised in
 # profiles/r2_pmc_roofline_kernel.csv: 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, in KiB.

@@ -169,6 +169,7 @@ class StepEngine:
         self.fuse_sqnorm = os.environ.get("MMVAE_FUSE_SQNORM", "1") != "0"
         if os.environ.get("MMVAE_SIDE_STREAM", "0") != "0":
             side_stream = True
+        self.side_stream_asked = bool(side_stream)  # the caller / environment asked for it (not only the dW branch)
         # The decoder's G-wide weight gradient (dW = dP^T h, ~105 us at C2, needed by the optimiser only) on a second
         # stream beside the backward chain of the core layers (~150 us of latency-bound launches that leave most CUs
         # idle): the persistent GEMM kernel is launched with its grid capped to `side_dw` workgroups = CUs, the chain
@@ -181,6 +182,7 @@ class StepEngine:
         # VAE optimiser) on a second branch stream
         self.side_dw2 = int(os.environ.get("MMVAE_SIDE_DW2", "185"))
         self.side_branches = os.environ.get("MMVAE_SIDE_BRANCHES", "1") != "0"
+        self.side_max_rows = int(os.environ.get("MMVAE_SIDE_MAX_ROWS", "640"))  # see _Plan._build
         if self.side_dw:
             side_stream = True
         self.side_stream = torch.cuda.Stream(device=self.device) if side_stream else None
@@ -491,6 +493,7 @@ class _Plan:
         self._ws_bytes = 0
         self._slab_floats = 0
         self._graphs: Optional[list] = None
+        self.use_side = False           # this plan forks work onto the engine's side stream (set in _build)
         self._probe_next = None         # tag for the next emitted GEMM (measurement hook, see _emit_gemm)
         self.probe = None               # dict tag -> [(event, event, flops)] while an eager run is being measured
         self._forked = False            # the program has branches on other streams
@@ -665,7 +668,7 @@ class _Plan:
         if side and sk == 1 and self._fuse_sqnorm(layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags):
             return
         nbytes = self.lib.mmvae_gemm_workspace_bytes(layout, M, N, K, sk)
-        if side and self.eng.side_stream is not None and M * N <= self.eng.side_max_elems:
+        if side and self.use_side and M * N <= self.eng.side_max_elems:
             self._ws_side_bytes = max(getattr(self, "_ws_side_bytes", 0), nbytes)
             hit = self.eng.locate_grad(Cm)
             if hit is None or hit[0] is not self.opt_exp:
@@ -1000,10 +1003,21 @@ class _Plan:
         self.eps = eng.buf("eps", (K, B, Z))
 
         train = self.mode == "train"
-        # branches beside the latency-bound sections (in-order single-rank program only; see MmvaeEngine.side_dw)
-        side_dw = eng.side_dw if (train and eng.side_stream is not None and not eng.overlap and eng.world == 1) else 0
+        # branches beside the latency-bound sections (in-order single-rank program only; see StepEngine.side_dw)
+        # The caps are tuned for the shape where the two weight gradients are SHORTER than the chains they hide behind
+        # (C2: B = 512, K = 1: 105 us of GEMM beside a 190 us chain).  With K samples or bigger batches the GEMMs grow
+        # with the rows while the chains barely do, and a capped GEMM becomes the critical path (measured with the
+        # branches on: C3 4.36 against 4.00 ms, C5 7.03 against 5.93 ms; with adversaries, C4: 1.64 against 1.60 ms).
+        # Small models stay on ONE stream: when the kernels ahead of a fork finish while the host is still enqueuing
+        # the rest of a multi-stream graph, hipGraphLaunch crashes now and then on this runtime (null dereference, box
+        # dependent; only ever seen with the tests' toy shapes, whose whole step is ~100 us -- tools/debug/seg_hunt.sh).
+        # A G-wide weight gradient of >= 5 GFLOP puts the first fork hundreds of microseconds into the replay.
+        big = 2.0 * G * self.dec_layers[-1].n_in * R >= 5e9
+        side_dw = eng.side_dw if (train and eng.side_stream is not None and not eng.overlap and eng.world == 1
+                                  and K == 1 and R <= eng.side_max_rows and not self.has_adv and big) else 0
         early_branch = bool(side_dw and K == 1 and not self.iwae and eng.batch_finish and eng.merge_launches
                             and eng.side_branches)
+        self.use_side = bool(side_dw) or (eng.side_stream_asked and eng.side_stream is not None)
         loss_aside, early_calls = False, []
         # ---- forward, encoder side
         cur, ld = x, ldx
