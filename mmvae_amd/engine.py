@@ -494,8 +494,6 @@ class _Plan:
         self._slab_floats = 0
         self._graphs: Optional[list] = None
         self.use_side = False           # this plan forks work onto the engine's side stream (set in _build)
-        self._prenorm: Dict[int, tuple] = {}  # per optimiser: a norm pass already emitted on a branch (see _build)
-        self._aside = None              # the call list of the early side branch (more can be appended until the first run)
         self._probe_next = None         # tag for the next emitted GEMM (measurement hook, see _emit_gemm)
         self.probe = None               # dict tag -> [(event, event, flops)] while an eager run is being measured
         self._forked = False            # the program has branches on other streams
@@ -957,31 +955,27 @@ class _Plan:
                 self._emit(self.lib.mmvae_adam_step_jobs, c.max_jobs, c.jobs_ptr, _p(a.data), _p(a.grad), _p(a.exp_avg),
                            _p(a.exp_avg_sq), _p(opt.state_dev), g["lr"], b1, b2, g["eps"], g["weight_decay"], gs)
             return
-        npart, partials = self._prenorm.pop(id(opt), None) or self._emit_norm_pass(opt)
+        cover = sorted(self._sq_cover.pop(id(opt), []))
+        if cover:
+            # the fused GEMM epilogues have left the partials of the ranges they wrote; the norm pass runs over the
+            # rest of the arena only, into the slots behind them; adam_prepare sums them all (fp64, slot order)
+            buf = self.eng.sq_buffer(opt)
+            slot, pos = self._sq_used.pop(id(opt)), 0
+            for off, n in cover + [(a.numel, 0)]:
+                if off > pos:
+                    self._emit(self.lib.mmvae_grad_sqnorm, off - pos, a.grad.data_ptr() + 4 * pos, buf.data_ptr() + 4 * slot)
+                    slot += self.lib.mmvae_sqnorm_partials(off - pos)
+                pos = max(pos, off + n)
+            assert slot <= buf.numel()
+            npart, partials = slot, buf
+        else:
+            self._emit(self.lib.mmvae_grad_sqnorm, a.numel, _p(a.grad), _p(opt.partials))
+            partials = opt.partials
         flags = _lib.PREPARE_NORM | (_lib.PREPARE_ADVANCE if (advance and step) else 0)
         self._emit(self.lib.mmvae_adam_prepare, npart, _p(partials), max_norm, gs, b1, b2, _p(opt.state_dev), flags)
         if step:
             self._emit(self.lib.mmvae_adam_step, a.numel, _p(a.data), _p(a.grad), _p(a.exp_avg), _p(a.exp_avg_sq),
                        _p(opt.state_dev), g["lr"], b1, b2, g["eps"], g["weight_decay"], gs)
-
-    def _emit_norm_pass(self, opt: HipAdam):
-        """The sum-of-squares pass of `opt`'s gradient arena; returns (number of partials, their buffer).  Ranges whose
-        partials a fused GEMM epilogue has left are skipped: the pass runs over the rest of the arena only, into the
-        slots behind them; adam_prepare sums them all (fp64, slot order)."""
-        a = opt.arena
-        cover = sorted(self._sq_cover.pop(id(opt), []))
-        if not cover:
-            self._emit(self.lib.mmvae_grad_sqnorm, a.numel, _p(a.grad), _p(opt.partials))
-            return self.lib.mmvae_sqnorm_partials(a.numel), opt.partials
-        buf = self.eng.sq_buffer(opt)
-        slot, pos = self._sq_used.pop(id(opt)), 0
-        for off, n in cover + [(a.numel, 0)]:
-            if off > pos:
-                self._emit(self.lib.mmvae_grad_sqnorm, off - pos, a.grad.data_ptr() + 4 * pos, buf.data_ptr() + 4 * slot)
-                slot += self.lib.mmvae_sqnorm_partials(off - pos)
-            pos = max(pos, off + n)
-        assert slot <= buf.numel()
-        return slot, buf
 
     def _begin_exchange(self, opt: HipAdam):
         """All gradients of `opt` are final here: start their all-reduce on the small-message stream."""
@@ -1122,7 +1116,6 @@ class _Plan:
             if early_branch:  # behind the weight gradient on its stream: one branch, in order (probe: DESIGN.md 5)
                 self._fork()  # (the weight gradient may have stayed on the main stream)
                 self._branch(eng.side_stream, early_calls)
-                self._aside = early_calls
         else:
             self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True)
             S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
@@ -1216,11 +1209,6 @@ class _Plan:
             if not self._fuse_sqnorm(layout, M, N, Kk, 1.0, A, lda, Bm, ldb, Cm, ldc, None, 0, side_cap=eng.side_dw2,
                                      on_side=False):
                 self.gemm(*dw, side=True)
-            # the expert's own norm pass over what no GEMM epilogue covers (biases, BatchNorm, the narrow layers:
-            # two launches) is ready here too: onto the branch, off the critical path ahead of the expert's Adam
-            s2 = len(self._cur)
-            self._prenorm[id(self.opt_exp)] = self._emit_norm_pass(self.opt_exp)
-            calls += self._take(s2)
             self._branch(eng.side_stream, calls)
         elif dw is not None:
             self.gemm(*dw, side=True)
@@ -1253,12 +1241,7 @@ class _Plan:
                         self._emit(lib.mmvae_philox_keep_mask, f.n, f.p_drop, f.out, _p(self.rng_state), f.stream_id, 0)
                     else:
                         self._emit(lib.mmvae_philox_normal, f.n, f.out, _p(self.rng_state), f.stream_id, 0)
-            if self._aside is not None:  # the counter advance (one thread) rides on the side branch, hundreds of us behind the fill
-                s0 = len(self._cur)
-                self._emit(lib.mmvae_philox_advance, _p(self.rng_state), (n_max + 3) // 4)
-                self._aside.extend(self._take(s0))
-            else:
-                self._emit(lib.mmvae_philox_advance, _p(self.rng_state), (n_max + 3) // 4)
+            self._emit(lib.mmvae_philox_advance, _p(self.rng_state), (n_max + 3) // 4)
             self.segments[0] = self._cur + self.segments[0]
             self._cur = []
         self._size_workspaces()
