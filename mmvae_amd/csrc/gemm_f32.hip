@@ -1834,12 +1834,28 @@ int launch_gemm_vec(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) 
 
 int g_precision = MMVAE_GEMM_PRECISION_BF16X3;  // process-wide, set by mmvae_gemm_set_precision
 
+// Compute units of the current device, asked once (256 on MI355X; also the answer when no device can be asked: the
+// planner is callable on a host without a GPU).
+int device_cus() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            return 256;
+        }
+        return n;
+    }();
+    return cus;
+}
+
+
 template <int AFORM, int BFORM, bool VEC, int EPI>
 int launch_gemm_x3(int tile_id, const GemmArgs& g0, int nwork, hipStream_t s) {
     GemmArgs g = g0;
     g.nwork = nwork;
 #if MMVAE_X3_PERSISTENT
-    const int nblocks = nwork < 512 ? nwork : 512;  // 2 resident workgroups per CU: the rest is looped over
+    const int nblocks = nwork < 2 * device_cus() ? nwork : 2 * device_cus();  // 2 resident workgroups per CU: the rest is looped over
 #else
     const int nblocks = nwork;
 #endif
@@ -1863,9 +1879,9 @@ bool x3w_enabled() {
     return !(e && e[0] == '0');
 }
 
-constexpr int X3W_SLOTS = 256;  // one resident workgroup per CU
-int g_wg_cap = 0;               // mmvae_gemm_set_workgroup_cap: > 0 caps the persistent kernel's grid
-int x3w_slots() { return (g_wg_cap > 0 && g_wg_cap < X3W_SLOTS) ? g_wg_cap : X3W_SLOTS; }
+int g_wg_cap = 0;  // mmvae_gemm_set_workgroup_cap: > 0 caps the persistent kernel's grid
+// one resident workgroup per CU
+int x3w_slots() { return (g_wg_cap > 0 && g_wg_cap < device_cus()) ? g_wg_cap : device_cus(); }
 
 template <int AFORM, int BFORM, int EPI>
 int launch_gemm_x3w(int tile_id, const GemmArgs& g0, int nwork, hipStream_t s) {
@@ -1919,7 +1935,7 @@ int bk_of(int layout, int tile_id) {
 // Picks tile id and split-K.  Large outputs: the tile whose (rounds x tile area) is smallest, rounds = number of
 // times the chip's resident-workgroup slots are filled.  Few output tiles (K = G reductions): split-K.
 void plan(int layout, int M, int N, int K, int* tile_id, int* splitk) {
-    const int CUS = 256;
+    const int CUS = device_cus();
     long best_cost = -1;
     int best = 0;
     for (int id = 0; id < (layout == MMVAE_GEMM_NN ? 1 : 2); ++id) {
@@ -1987,7 +2003,7 @@ void plan(int layout, int M, int N, int K, int* tile_id, int* splitk) {
 // (20000 = 125 x 160: a 512 x 20000 output is 628 square tiles = 2 rounds of the 512 resident slots, but 500 tiles of
 // 128x160 = 1 round).  allow_tall: the 160x128 shape has no fused-recon instantiation.
 int x3_tile_for(int M, int N, bool allow_tall) {
-    const long slots = 512;
+    const long slots = 2L * device_cus();  // 2 resident workgroups per CU
     int best = 3;
     long best_cost = -1;
     for (int id = 3; id <= (allow_tall ? 5 : 4); ++id) {

@@ -317,3 +317,58 @@ def test_reloading_a_snapshot_into_a_live_engine_repeats_the_step(name, tmp_path
     got = model.state_dict()
     for k in want:
         assert torch.equal(got[k], want[k]), f"{k} differs after the rollback"
+
+
+def test_closing_the_engine_releases_its_programs_and_training_goes_on(tmp_path, monkeypatch):
+    """StepEngine.close() destroys every captured graph (a plan holds runtime objects that only a cyclic collection
+    would otherwise free); the next step rebuilds and re-captures its plan and continues bit for bit.  The measurement
+    hook of bench.py's roofline leg rides along: in eager runs with a probe set, the tagged forward GEMM of the expert
+    encoder is bracketed by a timing event pair."""
+    import copy
+
+    import pandas as pd
+
+    case, z = H.load_case("two_mod_odd")
+    T = len(case["schedule"])
+
+    def run(close_at):
+        model = MU.build_mirror(case, "cuda", str(tmp_path), use_engine=True)
+        MU.load_state(model, z, "sd0/")
+        model.train()
+        model.trainer.set_stage("training")
+        model.optimizers()
+        probe = {}
+        for rep in range(3):
+            for t in range(T):
+                eid = case["schedule"][t]
+                x, eps, masks, labels = H.step_inputs(z, t)
+                model.kl_annealing_fn.kl_weight = case["kl_weights"][t]
+                model.module.vae.encoder.explicit_eps = eps.cuda()
+                model.module.experts[eid].encoder.explicit_masks = {
+                    int(k.split(".")[4]): m.cuda() for k, m in masks.items()
+                    if k.startswith(f"experts.{eid}.encoder.fc_layers.")}
+                if close_at is not None and (rep, t) == close_at:
+                    eng = model._engine
+                    graphs = sum(1 for p in eng._plans.values() for g in (p._graphs or []) if not isinstance(g, tuple))
+                    assert graphs > 0, "plans should have been captured by now"
+                    eng.close()
+                    assert not eng._plans
+                if close_at is not None and rep == 2:  # last round eagerly, with the probe set
+                    monkeypatch.setenv("MMVAE_NO_GRAPH", "1")
+                    for p in model._engine._plans.values():
+                        p.probe = probe
+                model.training_step((x.cuda(), pd.DataFrame({"dummy": [0] * x.shape[0]}), eid), t)
+                if close_at is not None and rep == 2:
+                    for p in model._engine._plans.values():
+                        p.probe = probe
+        monkeypatch.delenv("MMVAE_NO_GRAPH", raising=False)
+        return copy.deepcopy(model.state_dict()), probe
+
+    want, _ = run(None)
+    got, probe = run((1, 1))
+    for k in want:
+        assert torch.equal(got[k], want[k]), f"{k} differs after close()"
+    pairs = probe.get("enc_l1_fwd", [])
+    assert pairs, "the probe hook did not see the expert encoder's forward GEMM"
+    torch.cuda.synchronize()
+    assert all(e0.elapsed_time(e1) > 0 and flops > 0 for e0, e1, flops in pairs)
