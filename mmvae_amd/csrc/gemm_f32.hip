@@ -292,18 +292,25 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
             // lanes of a half that share q = lane & 3 (strides 4, 8, 16).
             const int q = lane & 3;
             const bool odd = q & 1, hi = q & 2;
-            f32x4 bv[TN];
-#pragma unroll
-            for (int n = 0; n < TN; ++n) {
+            // 256-row tiles (wave-specialised kernel): 160 accumulator registers are live -- the bias vectors are
+            // re-read per row group (L1 hits) instead of being held in 20 more
+            constexpr bool KEEP_BIAS = BM < 256;
+            auto load_bias = [&](int n) {
                 const int col = bn * BN + wn * WTN + n * 32 + (l31 & ~3);
-                bv[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
                 if (g.bias && col < g.N) {
                     if (col + 3 < g.N) {
-                        bv[n] = *reinterpret_cast<const f32x4*>(g.bias + col);
+                        b = *reinterpret_cast<const f32x4*>(g.bias + col);
                     } else {
-                        for (int j = 0; j < g.N - col; ++j) bv[n][j] = g.bias[col + j];
+                        for (int j = 0; j < g.N - col; ++j) b[j] = g.bias[col + j];
                     }
                 }
+                return b;
+            };
+            f32x4 bv[KEEP_BIAS ? TN : 1];
+            if (KEEP_BIAS) {
+#pragma unroll
+                for (int n = 0; n < TN; ++n) bv[KEEP_BIAS ? n : 0] = load_bias(n);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -326,8 +333,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
                         p[2] = hi ? c2 : t0;
                         p[3] = hi ? c3 : t1;
                         const int col = bn * BN + wn * WTN + n * 32 + (l31 & ~3);
+                        const f32x4 bn4 = KEEP_BIAS ? bv[KEEP_BIAS ? n : 0] : load_bias(n);
                         if (row < g.M && col + 3 < g.N) {
-                            p += bv[n];
+                            p += bn4;
                             const f32x4 xv = *reinterpret_cast<const f32x4*>(g.x + (int64_t)xr * g.ldx + col);
                             f32x4 xh, dp;
 #pragma unroll
@@ -340,7 +348,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
                             if (g.xhat) *reinterpret_cast<f32x4*>(g.xhat + (int64_t)row * g.ldxhat + col) = xh;
                             if (g.dP) *reinterpret_cast<f32x4*>(g.dP + (int64_t)row * g.lddp + col) = dp;
                         } else if (row < g.M && col < g.N) {  // G % 4 != 0: the group straddling the edge, element-wise
-                            p += bv[n];
+                            p += bn4;
                             for (int j = 0; j < g.N - col; ++j) {
                                 const float xhj = fmaxf(p[j], 0.f);
                                 const float d = xhj - g.x[(int64_t)xr * g.ldx + col + j];
@@ -2327,8 +2335,10 @@ extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, 
     g.aligned = aligned16(h) && aligned16(W) && (ldh % 4 == 0) && (ldw % 4 == 0);
     if (g.aligned && rows % 4 == 0 && G % 4 == 0 && H % 4 == 0) g.aligned = 2;
     g.x3_vec = 1;  // both operands K-contiguous: rows are clamped one by one, no edge groups
-    // (the wave-specialised kernel's fused-recon instantiation runs out of registers in the epilogue -- 63 spills -- and
-    // measured 134 us against 119 us in the C2 step: the 2 x 4-wave kernel keeps this launch; MMVAE_X3W_RECON=1 to compare)
+    // (the 2 x 4-wave kernel keeps this launch: its two workgroups per CU overlap one's heavy epilogue -- 160 KB of x
+    // read, 160 KB of dP written per tile -- with the other's main loop, while the wave-specialised kernel's epilogue is
+    // done by 4 of its 8 waves with the stagers idle: 1.097 against 1.067 ms per C2 step, also after its spills were
+    // cut from 63 to 9 registers; MMVAE_X3W_RECON=1 to compare)
     const char* e_recon = getenv("MMVAE_X3W_RECON");
     const bool w_recon = e_recon && e_recon[0] == '1';
     const int tile_id = !x3 ? 1 : ((H % X3_BK == 0) ? (w_recon ? x3_tile_regular(rows, G, 1, false) : x3_tile_for(rows, G, false)) : 3);
