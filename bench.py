@@ -390,7 +390,9 @@ def main():
             # flops is the dense bf16 peak / 6; the exact-f32 mode is bounded by the fp32 MFMA peak.
             peak = BF16_DENSE_TFLOPS / 6.0 if x3 else F32_MFMA_TFLOPS
             out["roofline"] = {"bound": "mfma",
-                               "kernel": ("gemm_x3w_kernel<NT,256x128> (bf16x3 MFMA, 4 multiplier + 4 stager waves per CU)"
+                               "kernel": (("gemm_x3w_kernel<NT,256x128> (bf16x3 MFMA, 4 multiplier + 4 stager waves per CU)"
+                                           if os.environ.get("MMVAE_X3W", "1") != "0" else  # off under a gradient exchange
+                                           "gemm_x3_kernel<NT,128x128> (bf16x3 MFMA, 2 x 4 waves per CU)")
                                           if x3 else "gemm_f32_kernel<NT> (f32 MFMA)")
                                          + ": forward GEMM of the G-wide expert encoder layer, split-K 16",
                                "achieved": fl / tk / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl / tk / (peak * 1e12),
