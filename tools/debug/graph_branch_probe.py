@@ -257,3 +257,28 @@ def launch_cut_only():  # the main-stream work as four graphs back to back, noth
 run_multi("main-stream kernels only, ONE graph", lambda: g_whole.replay(), 422)
 run_multi("main-stream kernels only, four graphs back to back", launch_cut_only, 422)
 run_multi("six single-stream graphs + stream events", launch_multi, 422)
+
+
+def p_three(order):
+    """VAE-owned work forks early (where the shared VAE's gradients are final), the expert's small work late:
+    main: R K4b | side: K4a | chain1 | side2: E + Vvae | chain2 | K2 beside Vexp (side, behind K4a) | join | ADAM"""
+    k(50); k(100)
+    fork(side); on(side, 150)            # K4a
+    for _ in range(5):
+        k(20)                            # chain down to the VAE's last layer
+    if order == "branch_first":
+        fork(side2); on(side2, 10, 10, 30, 10)
+        k(35); k(35)
+    else:
+        fork(side2)
+        k(35); k(35)                     # the expert encoder's layers
+        on(side2, 10, 10, 30, 10)
+    fork(side)
+    k(100)                               # K2
+    on(side, 15, 5)                      # the expert's grouped GEMM + sums
+    join(side, side2)
+    k(50); k(5)
+
+
+run("three streams, VAE branch emitted before chain2", lambda: p_three("branch_first"), 475, 700)
+run("three streams, VAE branch emitted after chain2", lambda: p_three("main_first"), 475, 700)
