@@ -181,16 +181,11 @@ class StepEngine:
         # 3 rounds on 185 workgroups as on 256), and the switch for the small branches (loss words, bias column sums,
         # VAE optimiser) on a second branch stream
         self.side_dw2 = int(os.environ.get("MMVAE_SIDE_DW2", "185"))
-        self.side_dw3 = int(os.environ.get("MMVAE_SIDE_DW3", "215"))  # the same cap in the three-stream layout
         self.side_branches = os.environ.get("MMVAE_SIDE_BRANCHES", "1") != "0"
-        # the shared VAE's optimiser forks where the VAE's gradients are final (a second branch stream), the expert's
-        # small work runs beside the expert encoder's weight gradient: see _Plan._build
-        self.vae_early = os.environ.get("MMVAE_VAE_EARLY", "1") != "0"
         self.side_max_rows = int(os.environ.get("MMVAE_SIDE_MAX_ROWS", "640"))  # see _Plan._build
         if self.side_dw:
             side_stream = True
         self.side_stream = torch.cuda.Stream(device=self.device) if side_stream else None
-        self.side2_stream = torch.cuda.Stream(device=self.device) if side_stream else None
         # only the small (latency-bound) weight-gradient GEMMs go aside; chip-filling ones stay in order on the main stream
         self.side_max_elems = int(os.environ.get("MMVAE_SIDE_MAX_ELEMS", 2 * 1024 * 1024))
         self._defer_arg = defer_expert_adam
@@ -493,9 +488,6 @@ class _Plan:
         self._mask_layers: List = []   # (layer, Philox stream id) of every dropout keep mask of the program
         self._gemm_jobs: List = []     # small weight-gradient GEMMs queued for the next mmvae_gemm_batch_f32 launch
         self._sum_jobs: List = []      # reductions queued for the next mmvae_sum_parts_batch launch
-        self._gemm_owner: List = []    # per queued job: the optimiser whose gradient it writes (None: not a gradient)
-        self._sum_owner: List = []
-        self._prenorm: Dict[int, tuple] = {}  # per optimiser: a norm pass already emitted on a branch
         self._sum_keep: List = []
         self._job_tables: List = []    # device job tables of the launches already emitted
         self._ws_bytes = 0
@@ -621,7 +613,6 @@ class _Plan:
         if not self.lib.mmvae_gemm_batch_job_ok(C.addressof(job)):
             return False
         self._gemm_jobs.append(job)
-        self._gemm_owner.append(self._owner_of(Cm))
         self._sum_keep.append((A, Bm, Cm, bias))
         return True
 
@@ -648,30 +639,17 @@ class _Plan:
         self._emit(self.lib.mmvae_gemm_batch_f32, len(arr), jobs_dev.data_ptr(), total.value)
         return True
 
-    def _owner_of(self, dst):
-        hit = self.eng.locate_grad(dst) if dst is not None else None
-        return hit[0] if hit is not None else None
-
-    @staticmethod
-    def _split_by_owner(jobs, owners, owner):
-        if owner is None:
-            return jobs, ([], [])
-        mine = [j for j, o in zip(jobs, owners) if o is owner]
-        keep = [i for i, o in enumerate(owners) if o is not owner]
-        return mine, ([jobs[i] for i in keep], [owners[i] for i in keep])
-
-    def _flush_gemms(self, owner=None):
-        """`owner`: only the queued jobs whose destination is a gradient of that optimiser (None: all of them)."""
-        mine, (self._gemm_jobs, self._gemm_owner) = self._split_by_owner(self._gemm_jobs, self._gemm_owner, owner)
-        if not mine:
+    def _flush_gemms(self):
+        if not self._gemm_jobs:
             return
-        n = len(mine)
-        arr = (_lib.GemmJob * n)(*mine)
+        n = len(self._gemm_jobs)
+        arr = (_lib.GemmJob * n)(*self._gemm_jobs)
         total = C.c_int(0)
         _lib.check(self.lib.mmvae_gemm_batch_prepare(n, C.addressof(arr), C.byref(total)), "mmvae_gemm_batch_prepare")
         jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.eng.device)
         self._job_tables.append(jobs_dev)
         self._emit(self.lib.mmvae_gemm_batch_f32, n, jobs_dev.data_ptr(), total.value)
+        self._gemm_jobs = []
 
     def gemm(self, layout, M, N, K, A, lda, Bm, ldb, Cm, ldc, bias=None, flags=0, alpha=1.0, side=False):
         """Complete GEMM (internal split-K reduce through a workspace when the plan asks for it).  side=True runs it
@@ -763,21 +741,19 @@ class _Plan:
         """Queue dst[rows, cols] (+)= alpha * sum of n_parts partial results at src; see _flush_sums."""
         self._sum_jobs.append(_lib.SumJob(_p(src), _p(dst), part_stride, ld_src, ld_dst, n_parts, rows, cols, float(alpha),
                                           int(flags), 0))
-        self._sum_owner.append(self._owner_of(dst))
         self._sum_keep.append((src, dst))
 
-    def _flush_sums(self, owner=None):
-        """One launch for every reduction queued since the last flush (before anything reads those gradients);
-        `owner`: only those into gradients of that optimiser."""
-        self._flush_gemms(owner)
-        mine, (self._sum_jobs, self._sum_owner) = self._split_by_owner(self._sum_jobs, self._sum_owner, owner)
-        if not mine:
+    def _flush_sums(self):
+        """One launch for every reduction queued since the last flush (before anything reads those gradients)."""
+        self._flush_gemms()
+        if not self._sum_jobs:
             return
-        arr = (_lib.SumJob * len(mine))(*mine)
+        arr = (_lib.SumJob * len(self._sum_jobs))(*self._sum_jobs)
         jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.eng.device)
         self._job_tables.append(jobs_dev)  # lives as long as the plan (the captured graph reads it on every replay)
-        self._emit(self.lib.mmvae_sum_parts_batch, len(mine), jobs_dev.data_ptr(),
-                   max(int(j.rows) * int(j.cols) for j in mine))
+        self._emit(self.lib.mmvae_sum_parts_batch, len(self._sum_jobs), jobs_dev.data_ptr(),
+                   max(int(j.rows) * int(j.cols) for j in self._sum_jobs))
+        self._sum_jobs = []
 
     def gemm_raw(self, layout, M, N, K, A, lda, Bm, ldb) -> int:
         """Raw split-K slabs into the shared slab buffer; returns the slab count."""
@@ -953,14 +929,14 @@ class _Plan:
         self._cur.append(call)
 
     def optimizer(self, opt: HipAdam, max_norm: float, advance: bool = True, step: bool = True, exchange: str = "inline",
-                  join: bool = True, own_jobs: bool = False):
+                  join: bool = True):
         """Fused clip + Adam over one optimiser's arenas.  `exchange` places the gradient all-reduce under data
         parallelism: "inline" (here, on the main stream), "wait" (it was begun earlier with _begin_exchange; the main
         stream joins it here) or "deferred" (it and everything after it run on the communication stream, overlapped
         with the next step).  `join=False`: none of this optimiser's gradients come from the side branch."""
         if join:
             self._join()
-        self._flush_sums(opt if own_jobs else None)  # own_jobs: the other optimiser's queued work belongs to another branch
+        self._flush_sums()
         a = opt.arena
         g = opt.param_groups[0]
         b1, b2 = g["betas"]
@@ -979,31 +955,27 @@ class _Plan:
                 self._emit(self.lib.mmvae_adam_step_jobs, c.max_jobs, c.jobs_ptr, _p(a.data), _p(a.grad), _p(a.exp_avg),
                            _p(a.exp_avg_sq), _p(opt.state_dev), g["lr"], b1, b2, g["eps"], g["weight_decay"], gs)
             return
-        npart, partials = self._prenorm.pop(id(opt), None) or self._emit_norm_pass(opt)
+        cover = sorted(self._sq_cover.pop(id(opt), []))
+        if cover:
+            # the fused GEMM epilogues have left the partials of the ranges they wrote; the norm pass runs over the
+            # rest of the arena only, into the slots behind them; adam_prepare sums them all (fp64, slot order)
+            buf = self.eng.sq_buffer(opt)
+            slot, pos = self._sq_used.pop(id(opt)), 0
+            for off, n in cover + [(a.numel, 0)]:
+                if off > pos:
+                    self._emit(self.lib.mmvae_grad_sqnorm, off - pos, a.grad.data_ptr() + 4 * pos, buf.data_ptr() + 4 * slot)
+                    slot += self.lib.mmvae_sqnorm_partials(off - pos)
+                pos = max(pos, off + n)
+            assert slot <= buf.numel()
+            npart, partials = slot, buf
+        else:
+            self._emit(self.lib.mmvae_grad_sqnorm, a.numel, _p(a.grad), _p(opt.partials))
+            partials = opt.partials
         flags = _lib.PREPARE_NORM | (_lib.PREPARE_ADVANCE if (advance and step) else 0)
         self._emit(self.lib.mmvae_adam_prepare, npart, _p(partials), max_norm, gs, b1, b2, _p(opt.state_dev), flags)
         if step:
             self._emit(self.lib.mmvae_adam_step, a.numel, _p(a.data), _p(a.grad), _p(a.exp_avg), _p(a.exp_avg_sq),
                        _p(opt.state_dev), g["lr"], b1, b2, g["eps"], g["weight_decay"], gs)
-
-    def _emit_norm_pass(self, opt: HipAdam):
-        """The sum-of-squares pass over `opt`'s gradient arena; returns (number of partials, their buffer).  Ranges whose
-        partials a fused GEMM epilogue has left are skipped: the pass runs over the rest of the arena only, into the
-        slots behind them; adam_prepare sums them all (fp64, slot order)."""
-        a = opt.arena
-        cover = sorted(self._sq_cover.pop(id(opt), []))
-        if not cover:
-            self._emit(self.lib.mmvae_grad_sqnorm, a.numel, _p(a.grad), _p(opt.partials))
-            return self.lib.mmvae_sqnorm_partials(a.numel), opt.partials
-        buf = self.eng.sq_buffer(opt)
-        slot, pos = self._sq_used.pop(id(opt)), 0
-        for off, n in cover + [(a.numel, 0)]:
-            if off > pos:
-                self._emit(self.lib.mmvae_grad_sqnorm, off - pos, a.grad.data_ptr() + 4 * pos, buf.data_ptr() + 4 * slot)
-                slot += self.lib.mmvae_sqnorm_partials(off - pos)
-            pos = max(pos, off + n)
-        assert slot <= buf.numel()
-        return slot, buf
 
     def _begin_exchange(self, opt: HipAdam):
         """All gradients of `opt` are final here: start their all-reduce on the small-message stream."""
@@ -1141,12 +1113,9 @@ class _Plan:
             if not self._fuse_sqnorm(TN, G, last.n_in, self.kpad(R), 1.0, self.dP, G, last.inp, last.ld_inp, last.gW,
                                      last.n_in, None, 0, side_cap=side_dw):
                 self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True)
-            if early_branch and not (eng.vae_early and self.cond is None
-                                     and 0 < self.n_expert_enc < len(self.enc_layers)):
-                # behind the weight gradient on its stream: one branch, in order (probe: profiles/r2_branch_order.txt)
+            if early_branch:  # behind the weight gradient on its stream: one branch, in order (probe: DESIGN.md 5)
                 self._fork()  # (the weight gradient may have stayed on the main stream)
                 self._branch(eng.side_stream, early_calls)
-                early_calls = []
         else:
             self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True)
             S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
@@ -1198,8 +1167,6 @@ class _Plan:
             self.gemm(NN, B, HV, Z, self.da, Z, self.var_enc.weight, HV, self.dq, HV, flags=ACC)
             din, S = self.dq, 1
         early = eng.overlap
-        vae_early = bool(side_dw and eng.side_branches and eng.vae_early and early_branch and self.cond is None
-                         and 0 < self.n_expert_enc < len(self.enc_layers))
         if early and len(self.enc_layers) == self.n_expert_enc:  # no VAE-encoder layers: VAE gradients are final
             self._begin_exchange(self.opt_vae)
         for j in range(len(self.enc_layers) - 1, -1, -1):
@@ -1212,8 +1179,6 @@ class _Plan:
             din, S = None, S_next
             if early and j == self.n_expert_enc:  # the last VAE layer is done: what remains is the expert's encoder
                 self._begin_exchange(self.opt_vae)
-            if vae_early and j == self.n_expert_enc and j > 0:
-                self._fork(eng.side2_stream)  # the shared VAE's gradients are final here; its branch is emitted below
         # ---- clip + Adam (reference order: clip vae, clip expert, step vae, step expert)
         # Logged scalars: the step's metrics words (and the pre-clip gradient norms) are copied into a buffer of this
         # plan's own as the last node(s) of the captured program -- the logged tensors are views of it, valid until
@@ -1227,40 +1192,26 @@ class _Plan:
         self._deferred_dw = None
         late_branch = bool(side_dw and eng.side_branches and dw is not None and not self._side_foreign
                            and self.cond is None)
-        owners_ok = all(o is self.opt_vae or o is self.opt_exp for o in self._gemm_owner + self._sum_owner)
-        three = bool(late_branch and vae_early and owners_ok)
         start = len(self._cur)
         self.optimizer(self.opt_vae, self.clip_vae, exchange="wait" if early else "inline",
-                       join=not late_branch, own_jobs=three)
+                       join=not late_branch)
         self.log_norm(self.opt_vae, "grad_norms/vae")
         if late_branch:
-            # The shared VAE's clip + Adam (a chain of small launches) leaves the critical path.  Emission order matters
-            # to the graph executor: the main-stream GEMM is enqueued first, the branches that run beside it behind it
-            # (a branch enqueued first made the GEMM wait for the branch's last node; uncapped, a branch starves behind
-            # the GEMM's one-workgroup-per-CU grid -- profiles/r2_branch_order.txt).
+            # the shared VAE's clip + Adam (a chain of small launches) beside the expert encoder's G-wide weight
+            # gradient, whose persistent grid is capped to the workgroup count that keeps its number of rounds
+            # Emission order matters to the graph executor: the weight gradient is enqueued first and the branch
+            # forks from an event recorded ahead of it (a branch enqueued first made the GEMM wait for the branch's
+            # last node; uncapped, the branch starves behind the GEMM's one-workgroup-per-CU grid -- timelines in
+            # profiles/r2_branch_order.txt).
             calls = self._take(start)
-            self._fork()  # the side stream (behind the decoder's weight gradient) depends on the chain up to here
+            self._fork()  # the branch depends on the chain up to here; its kernels are enqueued behind the GEMM
             layout, M, N, Kk, A, lda, Bm, ldb, Cm, ldc = dw
-            cap = eng.side_dw3 if three else eng.side_dw2
-            if not (cap and self._fuse_sqnorm(layout, M, N, Kk, 1.0, A, lda, Bm, ldb, Cm, ldc, None, 0, side_cap=cap,
-                                              on_side=False)):
+            if not self._fuse_sqnorm(layout, M, N, Kk, 1.0, A, lda, Bm, ldb, Cm, ldc, None, 0, side_cap=eng.side_dw2,
+                                     on_side=False):
                 self.gemm(*dw, side=True)
-            if three:
-                # three streams: the loss words, the decoder-bias column sums and the VAE's optimiser forked where the
-                # VAE's gradients were final (side2: they run beside the expert encoder's backward layers); beside the
-                # weight gradient only the expert's own small work is left -- its grouped GEMMs, sums and norm pass
-                self._branch(eng.side2_stream, early_calls + calls)
-                self._edge(eng.side2_stream, eng.side_stream)  # the bias column sums feed the expert's reductions
-                s2 = len(self._cur)
-                self._flush_sums(self.opt_exp)
-                self._prenorm[id(self.opt_exp)] = self._emit_norm_pass(self.opt_exp)
-                self._branch(eng.side_stream, self._take(s2))
-            else:
-                self._branch(eng.side_stream, early_calls + calls)
-        else:
-            self._cur[start:start] = early_calls  # (nothing was moved aside: they run in line, ahead of the reductions)
-            if dw is not None:
-                self.gemm(*dw, side=True)
+            self._branch(eng.side_stream, calls)
+        elif dw is not None:
+            self.gemm(*dw, side=True)
         if early:  # the expert's exchange + update leave the main stream: its norm is logged from the comm stream
             emit_log_copy()
         self.optimizer(self.opt_exp, self.clip_exp, exchange="deferred" if early else "inline")
