@@ -40,7 +40,7 @@ typedef void* mmvae_stream_t; /* hipStream_t */
 /* ABI version: bumped whenever an entry point is added or a signature changes (mmvae_abi_version() returns the
  * value the library was built with; bindings compare it with the header they were written against).
  *   1  round-1 surface (first 20 entry points)      2  end of round 1 (50 entry points)      3+  round 2 */
-#define MMVAE_ABI_VERSION 3
+#define MMVAE_ABI_VERSION 4
 int mmvae_abi_version(void);
 const char* mmvae_build_arch(void);
 
@@ -122,6 +122,15 @@ int mmvae_decoder_recon_f32(int B, int G, int H, const float* h, int64_t ldh, co
 int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, const float* h, int64_t ldh, const float* W,
                                  int64_t ldw, const float* bias, const float* x, int64_t ldx, float* xhat,
                                  int64_t ldxhat, float* dP, int64_t lddp, float* se_part, mmvae_stream_t stream);
+/* The same launch, also leaving the column sums of dP (= the gradient of the layer's bias when the rows are not
+ * re-weighted afterwards, K = 1) as per-row-tile partials: col_part [mmvae_recon_row_tiles(rows)][G], to be summed over
+ * the row tiles in order (mmvae_sum_parts_batch).  col_part = NULL: exactly mmvae_decoder_recon_rows_f32.  Saves the
+ * separate pass over the [rows, G] gradient (41 MB at C2).  Replaces: autograd of `bias` in components.py:276. */
+int mmvae_recon_row_tiles(int rows);
+int mmvae_decoder_recon_rows_colsum_f32(int rows, int x_rows, int G, int H, const float* h, int64_t ldh, const float* W,
+                                        int64_t ldw, const float* bias, const float* x, int64_t ldx, float* xhat,
+                                        int64_t ldxhat, float* dP, int64_t lddp, float* se_part, float* col_part,
+                                        mmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * FCBlock layer epilogues ("column kernels")

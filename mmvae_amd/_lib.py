@@ -61,6 +61,8 @@ PROTOTYPES = {
     "mmvae_recon_tiles": (_i, [_i]),
     "mmvae_decoder_recon_f32": (_i, [_i, _i, _i, _p, _l, _p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _p]),
     "mmvae_decoder_recon_rows_f32": (_i, [_i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _p]),
+    "mmvae_recon_row_tiles": (_i, [_i]),
+    "mmvae_decoder_recon_rows_colsum_f32": (_i, [_i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _p, _p]),
     "mmvae_fc_workspace_bytes": (_z, [_i, _i]),
     "mmvae_fc_epilogue_fwd": (
         _i,

@@ -83,6 +83,7 @@ struct GemmArgs {
     int c_vec;     // 16-byte epilogue accesses (a group straddling the N edge falls back to elements); 0: element path
     int nwork;     // bf16x3 kernel: work items (output tiles x split-K slices), looped over by <= 512 workgroups
     float* sq_part;  // optional [mt * nt]: sum of squares of the C values this tile stores (unsplit launches only)
+    float* col_part;  // recon epilogue, optional [mt][N]: column sums of dP over this row tile (bias gradient partials)
 };
 
 // HBM -> registers.  r0: first row (KC) / column (RC) of this tile along the non-K axis, Rtot its extent.
@@ -307,6 +308,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
                 }
                 return b;
             };
+            f32x4 cs[TN];  // column sums of dP over this lane's rows (col_part)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) cs[n] = f32x4{0.f, 0.f, 0.f, 0.f};
             f32x4 bv[KEEP_BIAS ? TN : 1];
             if (KEEP_BIAS) {
 #pragma unroll
@@ -347,14 +351,17 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
                             }
                             if (g.xhat) *reinterpret_cast<f32x4*>(g.xhat + (int64_t)row * g.ldxhat + col) = xh;
                             if (g.dP) *reinterpret_cast<f32x4*>(g.dP + (int64_t)row * g.lddp + col) = dp;
+                            cs[n] += dp;
                         } else if (row < g.M && col < g.N) {  // G % 4 != 0: the group straddling the edge, element-wise
                             p += bn4;
                             for (int j = 0; j < g.N - col; ++j) {
                                 const float xhj = fmaxf(p[j], 0.f);
                                 const float d = xhj - g.x[(int64_t)xr * g.ldx + col + j];
                                 sr += d * d;
+                                const float dpj = (p[j] > 0.f) ? 2.f * d : 0.f;
                                 if (g.xhat) g.xhat[(int64_t)row * g.ldxhat + col + j] = xhj;
-                                if (g.dP) g.dP[(int64_t)row * g.lddp + col + j] = (p[j] > 0.f) ? 2.f * d : 0.f;
+                                if (g.dP) g.dP[(int64_t)row * g.lddp + col + j] = dpj;
+                                cs[n][j] += dpj;
                             }
                         }
                     }
@@ -364,7 +371,29 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
                     if (l31 < 4) rowsum[wn * BM + rloc] = sr;
                 }
             }
+            if (g.col_part) {
+                // the 8 lanes that share a 4-column group (q = 0..3, both halves) -> one; then the WGM waves through LDS
+                float* colbuf = lds + WGN * BM;  // [WGM][BN], behind the row sums
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = cs[n][j];
+                        v += __shfl_xor(v, 1, 64);
+                        v += __shfl_xor(v, 2, 64);
+                        v += __shfl_xor(v, 32, 64);
+                        cs[n][j] = v;
+                    }
+                    if (q == 0 && half == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) colbuf[wm * BN + wn * WTN + n * 32 + (l31 & ~3) + j] = cs[n][j];
+                    }
+                }
+            }
         } else {
+        float cs[TN];
+#pragma unroll
+        for (int n = 0; n < TN; ++n) cs[n] = 0.f;
         float bv[TN];
 #pragma unroll
         for (int n = 0; n < TN; ++n) {
@@ -388,13 +417,23 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
                             const float xh = fmaxf(p, 0.f);
                             const float d = xh - g.x[(int64_t)xr * g.ldx + col];
                             s += d * d;
+                            const float dpv = (p > 0.f) ? 2.f * d : 0.f;
                             if (g.xhat) g.xhat[(int64_t)row * g.ldxhat + col] = xh;
-                            if (g.dP) g.dP[(int64_t)row * g.lddp + col] = (p > 0.f) ? 2.f * d : 0.f;
+                            if (g.dP) g.dP[(int64_t)row * g.lddp + col] = dpv;
+                            cs[n] += dpv;
                         }
                     }
                 }
                 s = half_wave_sum(s);
                 if (l31 == 0) rowsum[wn * BM + rloc] = s;
+            }
+        }
+        if (g.col_part) {
+            float* colbuf = lds + WGN * BM;
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                const float v = cs[n] + __shfl_xor(cs[n], 32, 64);
+                if (half == 0) colbuf[wm * BN + wn * WTN + n * 32 + l31] = v;
             }
         }
         }
@@ -408,6 +447,18 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
                 g.se_part[(int64_t)bn * g.M + row] = s;
                 if (bn == g.nt - 1)
                     for (int tz = g.nt; tz < g.se_tiles; ++tz) g.se_part[(int64_t)tz * g.M + row] = 0.f;
+            }
+        }
+        if (g.col_part) {
+            const float* colbuf = lds + WGN * BM;
+            for (int c = tid; c < BN; c += WGM * WGN * 64) {
+                const int col = bn * BN + c;
+                if (col < g.N) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WGM; ++w) sum += colbuf[w * BN + c];  // wave order: reproducible
+                    g.col_part[(int64_t)bm * g.N + col] = sum;
+                }
             }
         }
     }
@@ -2313,10 +2364,20 @@ extern "C" int mmvae_gemm_set_workgroup_cap(int max_workgroups) {
     return MMVAE_OK;
 }
 
+extern "C" int mmvae_recon_row_tiles(int rows) { return rows > 0 ? ceil_div_i(rows, 128) : 0; }
+
 extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, const float* h, int64_t ldh,
                                             const float* W, int64_t ldw, const float* bias, const float* x, int64_t ldx,
                                             float* xhat, int64_t ldxhat, float* dP, int64_t lddp, float* se_part,
                                             mmvae_stream_t stream) {
+    return mmvae_decoder_recon_rows_colsum_f32(rows, x_rows, G, H, h, ldh, W, ldw, bias, x, ldx, xhat, ldxhat, dP, lddp,
+                                               se_part, nullptr, stream);
+}
+
+extern "C" int mmvae_decoder_recon_rows_colsum_f32(int rows, int x_rows, int G, int H, const float* h, int64_t ldh,
+                                                   const float* W, int64_t ldw, const float* bias, const float* x,
+                                                   int64_t ldx, float* xhat, int64_t ldxhat, float* dP, int64_t lddp,
+                                                   float* se_part, float* col_part, mmvae_stream_t stream) {
     if (rows <= 0 || x_rows <= 0 || rows % x_rows != 0 || G <= 0 || H <= 0 || !h || !W || !x || !se_part)
         return MMVAE_ERR_ARG;
     if (ldh < H || ldw < H || ldx < G) return MMVAE_ERR_ARG;
@@ -2342,6 +2403,7 @@ extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, 
     const char* e_recon = getenv("MMVAE_X3W_RECON");
     const bool w_recon = e_recon && e_recon[0] == '1';
     const int tile_id = !x3 ? 1 : ((H % X3_BK == 0) ? (w_recon ? x3_tile_regular(rows, G, 1, false) : x3_tile_for(rows, G, false)) : 3);
+    if (col_part && tile_shape(0, tile_id).bm != 128) return MMVAE_ERR_ARG;  // [mmvae_recon_row_tiles(rows)][G] partials
     g.mt = ceil_div_i(rows, tile_shape(0, tile_id).bm);
     g.nt = ceil_div_i(G, tile_shape(0, tile_id).bn);
     g.se_tiles = mmvae_recon_tiles(G);  // rows nt .. se_tiles-1 of se_part are zeroed by the last column tile
@@ -2352,6 +2414,7 @@ extern "C" int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, 
     g.xhat = xhat;
     g.dP = dP;
     g.se_part = se_part;
+    g.col_part = col_part;
     g.ldx = ldx;
     g.ldxhat = ldxhat;
     g.lddp = lddp;

@@ -167,6 +167,7 @@ class StepEngine:
         self.batch_finish = os.environ.get("MMVAE_BATCH_FINISH", "1") != "0"
         self.batch_gemms = os.environ.get("MMVAE_BATCH_GEMMS", "1") != "0"
         self.fuse_sqnorm = os.environ.get("MMVAE_FUSE_SQNORM", "1") != "0"
+        self.fuse_dp_colsum = os.environ.get("MMVAE_FUSE_DP_COLSUM", "1") != "0"  # decoder-bias gradient from the recon epilogue
         if os.environ.get("MMVAE_SIDE_STREAM", "0") != "0":
             side_stream = True
         self.side_stream_asked = bool(side_stream)  # the caller / environment asked for it (not only the dW branch)
@@ -1063,8 +1064,15 @@ class _Plan:
         self.dP = eng.buf(f"dP.{G}", (R, G)) if train else None
         self.se_part = eng.buf(f"se_part.{G}", (T, R))
         self.w = eng.buf("w", (R,))
-        self._emit(lib.mmvae_decoder_recon_rows_f32, R, B, G, last.n_in, _p(cur), ld, _p(last.W), last.n_in,
-                   _p(last.b), _p(x), ldx, None, 0, _p(self.dP), G, _p(self.se_part))
+        # K = 1: the decoder bias's gradient is the column sum of dP; the epilogue that stores dP leaves its per-row-tile
+        # partials (one reduction job instead of a 41 MB pass).  K > 1 re-weights the rows of dP first: separate pass.
+        self.dp_colpart = None
+        if train and K == 1 and eng.batch_finish and eng.fuse_dp_colsum:
+            nrt = lib.mmvae_recon_row_tiles(R)
+            self.dp_colpart = eng.buf(f"dP.colpart.{G}", (nrt, G))
+            self._defer_sum(self.dp_colpart, nrt, G, 1, G, G, last.gb, G)
+        self._emit(lib.mmvae_decoder_recon_rows_colsum_f32, R, B, G, last.n_in, _p(cur), ld, _p(last.W), last.n_in,
+                   _p(last.b), _p(x), ldx, None, 0, _p(self.dP), G, _p(self.se_part), _p(self.dp_colpart))
         self.recon_row = eng.buf("recon_row", (B,))
         if self.iwae:
             self.rows3 = eng.buf("iwae.rows3", (3, B))
@@ -1103,7 +1111,7 @@ class _Plan:
         if K > 1:
             # dP <- diag(w) dP in place (w = softmax weights of the K-sample bound), dbias = column sums
             self._emit_fc_bwd(R, G, self.dP, None, self.w, self.dP, last.gb)
-        else:
+        elif self.dp_colpart is None:
             start = len(self._cur)
             self._emit_fc_bwd(R, G, self.dP, None, None, None, last.gb)
             if early_branch:  # the bias gradient (a pass over dP) is needed by the optimiser only

@@ -169,6 +169,10 @@ def recon_tiles(G: int) -> int:
     return _lib.load().mmvae_recon_tiles(G)
 
 
+def recon_row_tiles(rows: int) -> int:
+    return _lib.load().mmvae_recon_row_tiles(rows)
+
+
 def decoder_recon(
     h: torch.Tensor,
     W: torch.Tensor,
@@ -180,9 +184,11 @@ def decoder_recon(
     xhat: Optional[torch.Tensor] = None,
     dP: Optional[torch.Tensor] = None,
     se_part: Optional[torch.Tensor] = None,
+    col_part: Optional[torch.Tensor] = None,
 ):
     """Fused last decoder layer + squared error.  h [R,H] (R = K*B rows), W [G,H], x [B,G].
-    Returns (xhat [R,G] | None, dP [R,G] | None, se_part [tiles, R])."""
+    Returns (xhat [R,G] | None, dP [R,G] | None, se_part [tiles, R]).  col_part [recon_row_tiles(R), G] (optional):
+    receives the column sums of dP per row tile (their sum over the tiles is the bias gradient when K = 1)."""
     lib = _lib.load()
     _chk(h, "h"), _chk(W, "W"), _chk(bias, "bias"), _chk(x, "x")
     R, H, ldh = _mat(h, "h")
@@ -199,11 +205,13 @@ def decoder_recon(
         se_part = torch.empty((T, R), dtype=torch.float32, device=h.device)
     ldxh = _mat(xhat, "xhat")[2] if xhat is not None else 0
     lddp = _mat(dP, "dP")[2] if dP is not None else 0
-    rc = lib.mmvae_decoder_recon_rows_f32(
+    if col_part is not None and (tuple(col_part.shape) != (lib.mmvae_recon_row_tiles(R), G) or not col_part.is_contiguous()):
+        raise ValueError(f"decoder_recon: col_part must be a contiguous [{lib.mmvae_recon_row_tiles(R)}, {G}] tensor")
+    rc = lib.mmvae_decoder_recon_rows_colsum_f32(
         R, B, G, H, _ptr(h), ldh, _ptr(W), ldw, _ptr(bias), _ptr(x), ldx, _ptr(xhat), ldxh, _ptr(dP), lddp,
-        _ptr(se_part), _stream(),
+        _ptr(se_part), _ptr(col_part), _stream(),
     )
-    _lib.check(rc, "mmvae_decoder_recon_rows_f32")
+    _lib.check(rc, "mmvae_decoder_recon_rows_colsum_f32")
     return xhat, dP, se_part
 
 

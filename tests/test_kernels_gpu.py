@@ -199,6 +199,13 @@ def test_decoder_recon(ops, R, B, G, H):
     # optional outputs off
     _, _, se2 = ops.decoder_recon(dev(h), dev(W), dev(bias), dev(x), want_xhat=False, want_dP=False)
     assert torch.equal(se2, se_part)
+    # bias-gradient partials out of the same epilogue: column sums of the dP it stored, per 128-row tile
+    col_part = torch.full((ops.recon_row_tiles(R), G), float("nan"), device="cuda")
+    _, dP2, se4 = ops.decoder_recon(dev(h), dev(W), dev(bias), dev(x), col_part=col_part)
+    assert torch.equal(dP2, dP) and torch.equal(se4, se_part)
+    for t in range(col_part.shape[0]):
+        want = dP[128 * t:128 * (t + 1)].double().sum(0)
+        assert rel_l2(col_part[t], want) < 1e-6, t
     # every row of se_part is defined by the call (tile rows the chosen tiling does not use are written as zeros)
     poisoned = torch.full((ops.recon_tiles(G), R), float("nan"), device="cuda")
     _, _, se3 = ops.decoder_recon(dev(h), dev(W), dev(bias), dev(x), want_xhat=False, want_dP=False, se_part=poisoned)
