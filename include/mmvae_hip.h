@@ -302,6 +302,15 @@ int64_t mmvae_sqnorm_partials(int64_t n);
 int mmvae_grad_sqnorm(int64_t n, const float* grad, float* partials, mmvae_stream_t stream);
 int mmvae_adam_prepare(int64_t n_partials, const float* partials, float max_norm, float grad_scale, float beta1,
                        float beta2, float* state, unsigned flags, mmvae_stream_t stream);
+/* The norm pass over 1..4 ranges of a gradient arena (e.g. what no fused GEMM epilogue covers) AND mmvae_adam_prepare
+ * in one launch: range i = grads[i][0 .. lens[i]); its mmvae_sqnorm_partials(lens[i]) partials are written behind each
+ * other at `partials`; the workgroup that finishes last (`ticket`: one zero-initialised word the kernel resets) sums the
+ * n_partials_all partials at partials_all -- these and any written earlier, e.g. by mmvae_gemm_f32_sq -- in their fixed
+ * order and fills state[] as mmvae_adam_prepare(flags | MMVAE_PREPARE_NORM) does.  Same numbers as the separate launches. */
+int mmvae_grad_sqnorm_ranges_prepare(int n_ranges, const float* const* grads, const int64_t* lens, float* partials,
+                                     unsigned* ticket, int64_t n_partials_all, const float* partials_all, float max_norm,
+                                     float grad_scale, float beta1, float beta2, float* state, unsigned flags,
+                                     mmvae_stream_t stream);
 int mmvae_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* state,
                     float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                     mmvae_stream_t stream);

@@ -439,10 +439,9 @@ __global__ __launch_bounds__(1024) void sum_rows_kernel(int H, int64_t n, const 
 // ---------------------------------------------------------------- clip + Adam over a flat arena
 constexpr int64_t SQN_CHUNK = 1 << 16;  // floats per workgroup of the norm pass (fixed -> reproducible)
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(int64_t n, const float* __restrict__ g,
-                                                     float* __restrict__ partials) {
-    __shared__ float red[4];
-    const int64_t beg = (int64_t)blockIdx.x * SQN_CHUNK;
+// Sum of squares of chunk `chunk` (SQN_CHUNK floats) of g[0..n): the value of one partial.  Valid in thread 0.
+__device__ __forceinline__ float sqnorm_chunk(int64_t n, const float* __restrict__ g, int64_t chunk, float* red) {
+    const int64_t beg = chunk * SQN_CHUNK;
     int64_t end = beg + SQN_CHUNK;
     if (end > n) end = n;
     float s = 0.f;
@@ -477,15 +476,23 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(int64_t n, const float* __r
         for (int64_t i = beg + threadIdx.x; i < end; i += 256) s += g[i] * g[i];
     }
     s = wave_sum(s);
+    __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void adam_prepare_kernel(int64_t np, const float* __restrict__ partials,
-                                                           float max_norm, float grad_scale, float beta1, float beta2,
-                                                           float* __restrict__ state, unsigned flags) {
-    __shared__ double red[256];
+__global__ __launch_bounds__(256) void sqnorm_kernel(int64_t n, const float* __restrict__ g,
+                                                     float* __restrict__ partials) {
+    __shared__ float red[4];
+    const float s = sqnorm_chunk(n, g, blockIdx.x, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// Global norm (fp64 sum of the partials, fixed order) -> clip coefficient, step count, bias corrections in state[].
+__device__ __forceinline__ void adam_prepare_body(int64_t np, const float* partials, float max_norm, float grad_scale,
+                                                  float beta1, float beta2, float* __restrict__ state, unsigned flags,
+                                                  double* red) {
     double s = 0.0;
     if (flags & MMVAE_PREPARE_NORM)
         for (int64_t i = threadIdx.x; i < np; i += 256) s += (double)partials[i];
@@ -511,6 +518,49 @@ __global__ __launch_bounds__(256) void adam_prepare_kernel(int64_t np, const flo
         state[3] = 1.f - powf(beta1, step);
         state[4] = 1.f - powf(beta2, step);
     }
+}
+
+__global__ __launch_bounds__(256) void adam_prepare_kernel(int64_t np, const float* __restrict__ partials,
+                                                           float max_norm, float grad_scale, float beta1, float beta2,
+                                                           float* __restrict__ state, unsigned flags) {
+    __shared__ double red[256];
+    adam_prepare_body(np, partials, max_norm, grad_scale, beta1, beta2, state, flags, red);
+}
+
+// The norm pass over up to 4 ranges of a gradient arena (what no fused GEMM epilogue covers) and adam_prepare in ONE
+// launch: every workgroup leaves its chunk's partial, the workgroup that arrives last (a ticket counter, reset for the
+// next step) sums ALL the optimiser's partials in their fixed order.  Same numbers as the separate launches.
+struct SqRanges {
+    const float* g[4];
+    int64_t n[4];
+    int nb[4];
+    int nr;
+};
+__global__ __launch_bounds__(256) void sqnorm_ranges_prepare_kernel(SqRanges r, float* __restrict__ partials,
+                                                                    unsigned* __restrict__ ticket, int64_t np_all,
+                                                                    const float* partials_all, float max_norm,
+                                                                    float grad_scale, float beta1, float beta2,
+                                                                    float* __restrict__ state, unsigned flags) {
+    __shared__ float red[4];
+    __shared__ double dred[256];
+    __shared__ int last;
+    int b = blockIdx.x, k = 0;
+    while (k + 1 < r.nr && b >= r.nb[k]) {
+        b -= r.nb[k];
+        ++k;
+    }
+    const float s = sqnorm_chunk(r.n[k], r.g[k], b, red);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = s;
+        __threadfence();  // the partial is visible device-wide before the ticket is taken
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x == 0) *ticket = 0u;
+    __threadfence();  // acquire: the other workgroups' partials
+    adam_prepare_body(np_all, const_cast<const float*>(reinterpret_cast<const volatile float*>(partials_all)), max_norm,
+                      grad_scale, beta1, beta2, state, flags, dred);
 }
 
 #ifndef MMVAE_ADAM_NT
@@ -1006,6 +1056,30 @@ extern "C" int mmvae_adam_prepare(int64_t n_partials, const float* partials, flo
     if ((flags & MMVAE_PREPARE_NORM) && n_partials > 0 && !partials) return MMVAE_ERR_ARG;
     MMVAE_LAUNCH(adam_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n_partials, partials, max_norm,
                        grad_scale, beta1, beta2, state, flags);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_grad_sqnorm_ranges_prepare(int n_ranges, const float* const* grads, const int64_t* lens,
+                                                float* partials, unsigned* ticket, int64_t n_partials_all,
+                                                const float* partials_all, float max_norm, float grad_scale,
+                                                float beta1, float beta2, float* state, unsigned flags,
+                                                mmvae_stream_t stream) {
+    if (n_ranges < 1 || n_ranges > 4 || !grads || !lens || !partials || !ticket || !partials_all || !state ||
+        n_partials_all <= 0)
+        return MMVAE_ERR_ARG;
+    SqRanges r = {};
+    r.nr = n_ranges;
+    int total = 0;
+    for (int i = 0; i < n_ranges; ++i) {
+        if (!grads[i] || lens[i] <= 0) return MMVAE_ERR_ARG;
+        r.g[i] = grads[i];
+        r.n[i] = lens[i];
+        r.nb[i] = (int)mmvae_sqnorm_partials(lens[i]);
+        total += r.nb[i];
+    }
+    MMVAE_LAUNCH(sqnorm_ranges_prepare_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, r, partials, ticket,
+                 n_partials_all, partials_all, max_norm, grad_scale, beta1, beta2, state, flags | MMVAE_PREPARE_NORM);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }

@@ -167,6 +167,7 @@ class StepEngine:
         self.batch_finish = os.environ.get("MMVAE_BATCH_FINISH", "1") != "0"
         self.batch_gemms = os.environ.get("MMVAE_BATCH_GEMMS", "1") != "0"
         self.fuse_sqnorm = os.environ.get("MMVAE_FUSE_SQNORM", "1") != "0"
+        self.fuse_norm_prepare = os.environ.get("MMVAE_FUSE_NORM_PREPARE", "1") != "0"  # norm pass + adam_prepare: one launch
         self.fuse_dp_colsum = os.environ.get("MMVAE_FUSE_DP_COLSUM", "1") != "0"  # decoder-bias gradient from the recon epilogue
         if os.environ.get("MMVAE_SIDE_STREAM", "0") != "0":
             side_stream = True
@@ -957,23 +958,32 @@ class _Plan:
                            _p(a.exp_avg_sq), _p(opt.state_dev), g["lr"], b1, b2, g["eps"], g["weight_decay"], gs)
             return
         cover = sorted(self._sq_cover.pop(id(opt), []))
-        if cover:
-            # the fused GEMM epilogues have left the partials of the ranges they wrote; the norm pass runs over the
-            # rest of the arena only, into the slots behind them; adam_prepare sums them all (fp64, slot order)
-            buf = self.eng.sq_buffer(opt)
-            slot, pos = self._sq_used.pop(id(opt)), 0
-            for off, n in cover + [(a.numel, 0)]:
-                if off > pos:
-                    self._emit(self.lib.mmvae_grad_sqnorm, off - pos, a.grad.data_ptr() + 4 * pos, buf.data_ptr() + 4 * slot)
-                    slot += self.lib.mmvae_sqnorm_partials(off - pos)
-                pos = max(pos, off + n)
-            assert slot <= buf.numel()
-            npart, partials = slot, buf
-        else:
-            self._emit(self.lib.mmvae_grad_sqnorm, a.numel, _p(a.grad), _p(opt.partials))
-            partials = opt.partials
         flags = _lib.PREPARE_NORM | (_lib.PREPARE_ADVANCE if (advance and step) else 0)
-        self._emit(self.lib.mmvae_adam_prepare, npart, _p(partials), max_norm, gs, b1, b2, _p(opt.state_dev), flags)
+        # ranges of the arena the norm pass still has to read: everything no fused GEMM epilogue has covered (those have
+        # left their partials in the first slots of the buffer); adam_prepare sums all partials (fp64, slot order)
+        ranges, pos = [], 0
+        for off, n in cover + [(a.numel, 0)]:
+            if off > pos:
+                ranges.append((pos, off - pos))
+            pos = max(pos, off + n)
+        buf = self.eng.sq_buffer(opt) if cover else opt.partials
+        slot = self._sq_used.pop(id(opt)) if cover else 0
+        nparts = [self.lib.mmvae_sqnorm_partials(n) for _, n in ranges]
+        npart = slot + sum(nparts)
+        assert npart <= buf.numel()
+        if self.eng.fuse_norm_prepare and 1 <= len(ranges) <= 4 and opt.reducer is None and not self.eng.overlap:
+            # one launch: the ranges' partials + (last workgroup to finish) the fp64 sum, clip coefficient, step count
+            gp = (C.c_void_p * len(ranges))(*[a.grad.data_ptr() + 4 * o for o, _ in ranges])
+            ln = (C.c_int64 * len(ranges))(*[n for _, n in ranges])
+            ticket = self.eng.buf(f"sqticket.{id(opt)}", (1,), torch.int32)
+            self._sum_keep.append((gp, ln, ticket))
+            self._emit(self.lib.mmvae_grad_sqnorm_ranges_prepare, len(ranges), C.addressof(gp), C.addressof(ln),
+                       buf.data_ptr() + 4 * slot, _p(ticket), npart, _p(buf), max_norm, gs, b1, b2, _p(opt.state_dev), flags)
+        else:
+            for (o, n), k in zip(ranges, nparts):
+                self._emit(self.lib.mmvae_grad_sqnorm, n, a.grad.data_ptr() + 4 * o, buf.data_ptr() + 4 * slot)
+                slot += k
+            self._emit(self.lib.mmvae_adam_prepare, npart, _p(buf), max_norm, gs, b1, b2, _p(opt.state_dev), flags)
         if step:
             self._emit(self.lib.mmvae_adam_step, a.numel, _p(a.data), _p(a.grad), _p(a.exp_avg), _p(a.exp_avg_sq),
                        _p(opt.state_dev), g["lr"], b1, b2, g["eps"], g["weight_decay"], gs)
