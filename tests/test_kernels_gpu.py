@@ -442,6 +442,52 @@ def test_clip_adam_matches_torch(ops):
     assert rel_l2(v, opt.state[pt]["exp_avg_sq"]) < 5e-5
 
 
+def test_norm_ranges_and_prepare_in_one_launch_equal_the_separate_launches(ops):
+    """mmvae_grad_sqnorm_ranges_prepare: the partials of up to 4 arena ranges + adam_prepare by the workgroup that finishes
+    last -- bit for bit what mmvae_grad_sqnorm per range followed by mmvae_adam_prepare leave (partials and state words),
+    with partials a fused GEMM epilogue wrote earlier in front; the ticket word is back at zero (replayable)."""
+    import ctypes as C
+
+    from mmvae_amd import _lib
+
+    lib = _lib.load()
+    arena = dev(rnd(1_300_000, seed=5, scale=2.0))
+    ranges = [(16, 200_000), (400_004, 65_536), (600_000, 3), (700_001, 555_555)]  # offsets / lengths in floats
+    pre = dev(rnd(7, seed=6).abs())  # partials left by earlier kernels (slots 0..6)
+    s = torch.cuda.current_stream().cuda_stream
+    for nr in (1, 2, 4):
+        rs = ranges[:nr]
+        nparts = [lib.mmvae_sqnorm_partials(n) for _, n in rs]
+        total = pre.numel() + sum(nparts)
+        # separate launches
+        p_ref = torch.zeros(total, device="cuda")
+        p_ref[: pre.numel()] = pre
+        slot = pre.numel()
+        for (o, n), k in zip(rs, nparts):
+            assert lib.mmvae_grad_sqnorm(n, arena.data_ptr() + 4 * o, p_ref.data_ptr() + 4 * slot, s) == 0
+            slot += k
+        st_ref = torch.tensor([3.0, 0, 0, 0, 0, 0, 0, 0], device="cuda")
+        flags = _lib.PREPARE_NORM | _lib.PREPARE_ADVANCE
+        assert lib.mmvae_adam_prepare(total, p_ref.data_ptr(), 10.0, 0.5, 0.9, 0.999, st_ref.data_ptr(), flags, s) == 0
+        # one launch, twice (the second run proves the ticket was reset)
+        for rep in range(2):
+            p_got = torch.zeros(total, device="cuda")
+            p_got[: pre.numel()] = pre
+            st_got = torch.tensor([3.0, 0, 0, 0, 0, 0, 0, 0], device="cuda")
+            ticket = torch.zeros(1, dtype=torch.int32, device="cuda") if rep == 0 else ticket
+            gp = (C.c_void_p * nr)(*[arena.data_ptr() + 4 * o for o, _ in rs])
+            ln = (C.c_int64 * nr)(*[n for _, n in rs])
+            rc = lib.mmvae_grad_sqnorm_ranges_prepare(nr, C.addressof(gp), C.addressof(ln),
+                                                      p_got.data_ptr() + 4 * pre.numel(), ticket.data_ptr(), total,
+                                                      p_got.data_ptr(), 10.0, 0.5, 0.9, 0.999, st_got.data_ptr(),
+                                                      _lib.PREPARE_ADVANCE, s)
+            assert rc == 0
+            torch.cuda.synchronize()
+            assert torch.equal(p_got, p_ref), (nr, rep)
+            assert torch.equal(st_got, st_ref), (nr, rep, st_got.tolist(), st_ref.tolist())
+            assert int(ticket) == 0
+
+
 def test_philox_streams(ops):
     rng = torch.tensor([1234, 0], dtype=torch.int64, device="cuda")
     m1 = ops.philox_keep_mask((512, 1024), 0.1, rng)
