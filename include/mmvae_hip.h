@@ -360,6 +360,10 @@ typedef struct {
 } mmvae_philox_job;
 int mmvae_philox_fill_jobs(int n_jobs, const mmvae_philox_job* jobs_dev, int64_t max_n, uint64_t* rng_state,
                            mmvae_stream_t stream);
+/* The same fills, and rng_state[1] += advance_by by the workgroup that finishes last (`ticket`: one zero-initialised word
+ * the kernel resets): no separate mmvae_philox_advance launch.  Same numbers. */
+int mmvae_philox_fill_jobs_advance(int n_jobs, const mmvae_philox_job* jobs_dev, int64_t max_n, uint64_t* rng_state,
+                                   uint64_t advance_by, unsigned* ticket, mmvae_stream_t stream);
 /* rng_state[1] += by  (one call at the end of a step whose fills used distinct stream_ids with advance = 0). */
 int mmvae_philox_advance(uint64_t* rng_state, uint64_t by, mmvae_stream_t stream);
 

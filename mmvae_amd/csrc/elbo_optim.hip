@@ -784,8 +784,10 @@ __global__ void philox_advance_kernel(uint64_t* rng, uint64_t by) { rng[1] += by
 // Several fills of one step (the dropout keep-masks and the rsample noise) in one launch: workgroup column blockIdx.y
 // serves job y with the arithmetic of philox_mask_kernel / philox_normal_kernel (counter-based: the numbers depend on
 // (offset, stream id, element) only, not on the launch shape).
-__global__ __launch_bounds__(256) void philox_fill_jobs_kernel(const mmvae_philox_job* __restrict__ jobs,
-                                                               const uint64_t* __restrict__ rng) {
+// advance_by > 0 (with a ticket word): the workgroup that finishes last adds it to the counter -- every workgroup has read
+// the counter by then -- so that the step needs no separate mmvae_philox_advance launch.
+__global__ __launch_bounds__(256) void philox_fill_jobs_kernel(const mmvae_philox_job* __restrict__ jobs, uint64_t* rng,
+                                                               uint64_t advance_by, unsigned* ticket) {
     const mmvae_philox_job job = jobs[blockIdx.y];
     const uint64_t seed = rng[0], off = rng[1];
     const int64_t n = job.n, nq = (n + 3) / 4;
@@ -812,6 +814,13 @@ __global__ __launch_bounds__(256) void philox_fill_jobs_kernel(const mmvae_philo
                 const int64_t i = q * 4 + j;
                 if (i < n) out[i] = nv[j];
             }
+        }
+    }
+    if (advance_by && ticket) {
+        __syncthreads();  // every thread of this workgroup is done with `off`
+        if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x * gridDim.y - 1) {
+            *ticket = 0u;
+            rng[1] = off + advance_by;
         }
     }
 }
@@ -1145,7 +1154,18 @@ extern "C" int mmvae_philox_fill_jobs(int n_jobs, const mmvae_philox_job* jobs_d
                                       mmvae_stream_t stream) {
     if (n_jobs <= 0 || n_jobs > 65535 || !jobs_dev || max_n <= 0 || !rng_state) return MMVAE_ERR_ARG;
     MMVAE_LAUNCH(philox_fill_jobs_kernel, dim3(grid_for((max_n + 3) / 4, 256, 2048), n_jobs), dim3(256), 0,
-                 (hipStream_t)stream, jobs_dev, rng_state);
+                 (hipStream_t)stream, jobs_dev, rng_state, (uint64_t)0, (unsigned*)nullptr);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_philox_fill_jobs_advance(int n_jobs, const mmvae_philox_job* jobs_dev, int64_t max_n,
+                                              uint64_t* rng_state, uint64_t advance_by, unsigned* ticket,
+                                              mmvae_stream_t stream) {
+    if (n_jobs <= 0 || n_jobs > 65535 || !jobs_dev || max_n <= 0 || !rng_state || !ticket || advance_by == 0)
+        return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(philox_fill_jobs_kernel, dim3(grid_for((max_n + 3) / 4, 256, 2048), n_jobs), dim3(256), 0,
+                 (hipStream_t)stream, jobs_dev, rng_state, advance_by, ticket);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }

@@ -881,8 +881,11 @@ class _Plan:
         if need_dx == "raw":
             return self.gemm_raw(NN, rows, l.n_in, l.n_out, l.dz, l.n_out, l.W, l.n_in)
         if need_dx == "full":
-            self.gemm(NN, rows, l.n_in, l.n_out, l.dz, l.n_out, l.W, l.n_in, dx_out, l.n_in, flags=dx_flags,
-                      alpha=dx_alpha)
+            # a small complete product: one grouped launch without split-K instead of slabs + a reduction launch
+            if not self._gemm_group([(NN, rows, l.n_in, l.n_out, l.dz, l.n_out, l.W, l.n_in, dx_out, l.n_in, None,
+                                      dx_flags, dx_alpha)]):
+                self.gemm(NN, rows, l.n_in, l.n_out, l.dz, l.n_out, l.W, l.n_in, dx_out, l.n_in, flags=dx_flags,
+                          alpha=dx_alpha)
         return 0
 
     def _bias_partials(self, rows, N, dbias):
@@ -1252,6 +1255,14 @@ class _Plan:
                 arr = (_lib.PhiloxJob * len(fills))(*fills)
                 jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(eng.device)
                 self._job_tables.append(jobs_dev)
+                if eng.fuse_norm_prepare:  # (same switch: launches folded through a last-ticket workgroup)
+                    ticket = eng.buf("philox.ticket", (1,), torch.int32)
+                    self._emit(lib.mmvae_philox_fill_jobs_advance, len(fills), jobs_dev.data_ptr(), n_max,
+                               _p(self.rng_state), (n_max + 3) // 4, _p(ticket))
+                    self.segments[0] = self._cur + self.segments[0]
+                    self._cur = []
+                    self._size_workspaces()
+                    return
                 self._emit(lib.mmvae_philox_fill_jobs, len(fills), jobs_dev.data_ptr(), n_max, _p(self.rng_state))
             else:
                 for f in fills:
