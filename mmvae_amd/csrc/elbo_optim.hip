@@ -1164,7 +1164,9 @@ extern "C" int mmvae_philox_fill_jobs_advance(int n_jobs, const mmvae_philox_job
                                               mmvae_stream_t stream) {
     if (n_jobs <= 0 || n_jobs > 65535 || !jobs_dev || max_n <= 0 || !rng_state || !ticket || advance_by == 0)
         return MMVAE_ERR_ARG;
-    MMVAE_LAUNCH(philox_fill_jobs_kernel, dim3(grid_for((max_n + 3) / 4, 256, 2048), n_jobs), dim3(256), 0,
+    // 128 workgroups per job (grid-stride): every workgroup takes a ticket on ONE word, and 2048 x jobs same-address
+    // atomics took longer (19.7 us) than the launch they save
+    MMVAE_LAUNCH(philox_fill_jobs_kernel, dim3(grid_for((max_n + 3) / 4, 256, 128), n_jobs), dim3(256), 0,
                  (hipStream_t)stream, jobs_dev, rng_state, advance_by, ticket);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
