@@ -302,6 +302,11 @@ int64_t mmvae_sqnorm_partials(int64_t n);
 int mmvae_grad_sqnorm(int64_t n, const float* grad, float* partials, mmvae_stream_t stream);
 int mmvae_adam_prepare(int64_t n_partials, const float* partials, float max_norm, float grad_scale, float beta1,
                        float beta2, float* state, unsigned flags, mmvae_stream_t stream);
+/* mmvae_adam_step with a rider: workgroup 0 also copies copy_n floats copy_src -> copy_dst (both must not overlap the
+ * arenas) -- the step's logged scalars into a log buffer without a launch of their own.  copy_n = 0: mmvae_adam_step. */
+int mmvae_adam_step_copy(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                         const float* state, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         float grad_scale, int copy_n, const float* copy_src, float* copy_dst, mmvae_stream_t stream);
 /* The norm pass over 1..4 ranges of a gradient arena (e.g. what no fused GEMM epilogue covers) AND mmvae_adam_prepare
  * in one launch: range i = grads[i][0 .. lens[i]); its mmvae_sqnorm_partials(lens[i]) partials are written behind each
  * other at `partials`; the workgroup that finishes last (`ticket`: one zero-initialised word the kernel resets) sums the

@@ -578,7 +578,12 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 __global__ __launch_bounds__(256) void adam_step_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         const float* __restrict__ state, float lr, float b1, float b2,
-                                                        float eps, float wd, float grad_scale, int vec) {
+                                                        float eps, float wd, float grad_scale, int vec, int copy_n,
+                                                        const float* copy_src, float* copy_dst) {
+    // optional rider: a small device-to-device copy (the step's logged scalars into the plan's log buffer) done by
+    // workgroup 0 -- instead of a launch of its own behind the longest kernel of the step
+    if (copy_n > 0 && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < copy_n; i += blockDim.x) copy_dst[i] = copy_src[i];
     const float gmul = state[2] * grad_scale;
     const float step_size = lr / state[3];
     const float inv_bc2_sqrt = 1.f / sqrtf(state[4]);
@@ -1099,7 +1104,22 @@ extern "C" int mmvae_adam_step(int64_t n, float* param, const float* grad, float
     if (n <= 0 || !param || !grad || !exp_avg || !exp_avg_sq || !state) return MMVAE_ERR_ARG;
     const int vec = aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq);
     MMVAE_LAUNCH(adam_step_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream, n, param,
-                       grad, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps, weight_decay, grad_scale, vec);
+                       grad, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps, weight_decay, grad_scale, vec, 0,
+                       (const float*)nullptr, (float*)nullptr);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_adam_step_copy(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                    const float* state, float lr, float beta1, float beta2, float eps,
+                                    float weight_decay, float grad_scale, int copy_n, const float* copy_src,
+                                    float* copy_dst, mmvae_stream_t stream) {
+    if (n <= 0 || !param || !grad || !exp_avg || !exp_avg_sq || !state) return MMVAE_ERR_ARG;
+    if (copy_n < 0 || copy_n > 65536 || (copy_n > 0 && (!copy_src || !copy_dst))) return MMVAE_ERR_ARG;
+    const int vec = aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq);
+    MMVAE_LAUNCH(adam_step_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream, n, param,
+                       grad, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps, weight_decay, grad_scale, vec, copy_n,
+                       copy_src, copy_dst);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }

@@ -934,7 +934,7 @@ class _Plan:
         self._cur.append(call)
 
     def optimizer(self, opt: HipAdam, max_norm: float, advance: bool = True, step: bool = True, exchange: str = "inline",
-                  join: bool = True):
+                  join: bool = True, tail_copy=None):
         """Fused clip + Adam over one optimiser's arenas.  `exchange` places the gradient all-reduce under data
         parallelism: "inline" (here, on the main stream), "wait" (it was begun earlier with _begin_exchange; the main
         stream joins it here) or "deferred" (it and everything after it run on the communication stream, overlapped
@@ -987,7 +987,11 @@ class _Plan:
                 self._emit(self.lib.mmvae_grad_sqnorm, n, a.grad.data_ptr() + 4 * o, buf.data_ptr() + 4 * slot)
                 slot += k
             self._emit(self.lib.mmvae_adam_prepare, npart, _p(buf), max_norm, gs, b1, b2, _p(opt.state_dev), flags)
-        if step:
+        if step and tail_copy is not None:  # (n, src, dst): the step's logged scalars ride on this launch
+            self._emit(self.lib.mmvae_adam_step_copy, a.numel, _p(a.data), _p(a.grad), _p(a.exp_avg), _p(a.exp_avg_sq),
+                       _p(opt.state_dev), g["lr"], b1, b2, g["eps"], g["weight_decay"], gs, tail_copy[0],
+                       _p(tail_copy[1]), _p(tail_copy[2]))
+        elif step:
             self._emit(self.lib.mmvae_adam_step, a.numel, _p(a.data), _p(a.grad), _p(a.exp_avg), _p(a.exp_avg_sq),
                        _p(opt.state_dev), g["lr"], b1, b2, g["eps"], g["weight_decay"], gs)
 
@@ -1235,12 +1239,18 @@ class _Plan:
             self.gemm(*dw, side=True)
         if early:  # the expert's exchange + update leave the main stream: its norm is logged from the comm stream
             emit_log_copy()
-        self.optimizer(self.opt_exp, self.clip_exp, exchange="deferred" if early else "inline")
+        # in-order program: the log copy rides on the expert's Adam launch (its words -- losses, both norms -- are final
+        # once adam_prepare has run) when the expert's norm is a state word inside the metrics buffer
+        ride = (not early and eng.fuse_norm_prepare and self.cond is None
+                and eng._state_slot.get(id(self.opt_exp)) is not None)
+        self.optimizer(self.opt_exp, self.clip_exp, exchange="deferred" if early else "inline",
+                       tail_copy=(256, self.metrics, self.log_buf) if ride else None)
         if early:
             self.exp_norm_log = torch.zeros(1, dtype=torch.float32, device=eng.device)
         else:
             self.log_norm(self.opt_exp, "grad_norms/expert")
-            emit_log_copy()
+            if not ride:
+                emit_log_copy()
         self.segments.append(self._cur)
         self._cur = []
         # noise: Philox fills (production) or explicit buffers (parity mode), at the head of the program
