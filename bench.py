@@ -126,10 +126,11 @@ def time_dominant_kernel(model, step, first, steps=8):
             os.environ.pop("MMVAE_NO_GRAPH", None)
         else:
             os.environ["MMVAE_NO_GRAPH"] = prev
-    pairs = probe.get("enc_l1_fwd", [])[2:]
+    pairs = probe.get("enc_l1_fwd", [])[2:]  # (event, event, flops, event) per launch; the first two steps warm up
     if not pairs:
         raise RuntimeError("roofline leg: the engine did not run the probed GEMM")
-    ts = sorted(e0.elapsed_time(e1) for e0, e1, _ in pairs)
+    # e0 -> e1 brackets the launch and one event marker; e1 -> e2 is an empty pair = the marker alone: subtracted
+    ts = sorted(e0.elapsed_time(e1) - e1.elapsed_time(e2) for e0, e1, _, e2 in pairs)
     return ts[len(ts) // 2] * 1e-3, pairs[0][2]
 
 
@@ -399,8 +400,8 @@ def main():
                                "traffic": HBM_TRAFFIC_PMC_BYTES, "algorithmic_bytes": 4 * (cfg["batch"] * 1024 + (cfg["batch"] + 1024)
                                                                                                * max(cfg["experts"].values())),
                                "us_per_launch": tk * 1e6, "flops_per_launch": fl,
-                               "measured": "median of HIP event pairs around this launch on its launch stream in 6 "
-                                           "eagerly launched training steps behind the timed region",
+                               "measured": "median over 6 eagerly launched training steps behind the timed region of the HIP "
+                                           "event pair around this launch on its launch stream, minus an empty event pair",
                                "peak_note": "dense bf16 MFMA peak 2500 / 6 MFMA products per fp32 product" if x3
                                             else "dense fp32 MFMA peak",
                                "frac_of_f32_mfma_peak": fl / tk / (F32_MFMA_TFLOPS * 1e12)}

@@ -773,11 +773,12 @@ class _Plan:
             # bracketed by a timing event pair on its launch stream; never active under capture
             pr = plan.probe
             if tag is not None and pr is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                 e0.record(torch.cuda.current_stream())
                 launch_gemm()
                 e1.record(torch.cuda.current_stream())
-                pr.setdefault(tag, []).append((e0, e1, 2.0 * M * N * K))
+                e2.record(torch.cuda.current_stream())  # e1 -> e2: what one event marker itself costs on this stream
+                pr.setdefault(tag, []).append((e0, e1, 2.0 * M * N * K, e2))
             else:
                 launch_gemm()
 

@@ -371,4 +371,4 @@ def test_closing_the_engine_releases_its_programs_and_training_goes_on(tmp_path,
     pairs = probe.get("enc_l1_fwd", [])
     assert pairs, "the probe hook did not see the expert encoder's forward GEMM"
     torch.cuda.synchronize()
-    assert all(e0.elapsed_time(e1) > 0 and flops > 0 for e0, e1, flops in pairs)
+    assert all(e0.elapsed_time(e1) > 0 and flops > 0 and e1.elapsed_time(e2) >= 0 for e0, e1, flops, e2 in pairs)
