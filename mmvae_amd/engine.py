@@ -683,9 +683,9 @@ class _Plan:
 
     def _edge(self, src, dst):
         """dst waits for everything enqueued so far on src (None = the current stream at run time): a graph edge under
-        capture.  The event lives as long as the plan: torch's Stream.wait_stream creates an event and drops it at once,
-        and destroying an event in the middle of a stream capture left the runtime with a dangling reference --
-        box-dependent segmentation faults inside later hipGraphLaunch calls (tools/debug/seg_hunt.sh)."""
+        capture.  The event lives as long as the plan (torch's Stream.wait_stream would create one and drop it at once,
+        in the middle of the capture: legal, but one variable less in a multi-stream capture on a runtime whose graph
+        launches are fragile -- DESIGN.md section 4, "a runtime hazard")."""
         ev = torch.cuda.Event()
         self._events.append(ev)
 
