@@ -39,5 +39,9 @@ class CLVAE(VAE):
 
     def after_reparameterize(self, z: torch.Tensor, metadata: pd.DataFrame, **kwargs) -> torch.Tensor:
         if self.conditionals:
+            if z.dim() != 2:
+                # the K-sample ELBO is this build's extension, conditional layers are the reference's: the reference
+                # routes one latent row per cell through the cell's condition blocks and defines nothing for K > 1
+                raise ValueError("conditional layers are defined for one latent sample per cell (encoder n_samples = 1)")
             return self.conditionals(z, metadata, **kwargs)
         return z

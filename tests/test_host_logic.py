@@ -245,3 +245,18 @@ def test_graft_entry_build_passes():
     import __graft_entry__ as entry
 
     entry.build()
+
+
+def test_conditional_layers_refuse_more_than_one_latent_sample():
+    """K > 1 is this build's extension, conditional layers are the reference's (one latent row per cell through the
+    cell's blocks): the combination has no definition and is refused instead of being mis-indexed."""
+    import pandas as pd
+    import torch
+
+    from mmvae_amd.modules.clvae import CLVAE
+
+    class _Stub:
+        conditionals = object()
+
+    with pytest.raises(ValueError, match="one latent sample"):
+        CLVAE.after_reparameterize(_Stub(), torch.zeros(3, 4, 8), pd.DataFrame({"a": [0] * 4}))
