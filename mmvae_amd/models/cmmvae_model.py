@@ -240,6 +240,10 @@ class CMMVAEModel(BaseModel):
 
         optim_dict = {"experts": {eid: make(m.parameters()) for eid, m in self.module.experts.items()},
                       "vae": make(self.module.vae.parameters())}
+        if getattr(self.module.vae, "conditionals", None) is not None and optim_cls == "Adam":
+            # condition blocks absent from a rank's batch have no gradient there: under data parallelism the set of
+            # parameters that step is the union over the ranks (HipAdam._allreduce)
+            optim_dict["vae"].sparse_presence = True
         if len(self.module.adversarials) > 0:
             optim_dict["adversarials"] = {i: make(m.parameters(), head_packs(m) if optim_cls == "Adam" else None)
                                           for i, m in enumerate(self.module.adversarials, start=1)}

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import backend, ops
+from . import dist as mdist
 
 
 def _pad4(n: int) -> int:
@@ -130,6 +131,7 @@ class HipAdam(torch.optim.Optimizer):
             _ARENA_OF[id(p)] = (self, i)
         self._direct: set = set()  # parameters whose gradient a kernel wrote straight into the arena this step
         self.managed: set = set()  # parameters only ever written that way (condition blocks of the grouped kernels)
+        self.sparse_presence = False  # some parameters get no gradient in some steps (condition blocks): set by the model
         self._walk = None
         self.max_grad_norm = max_grad_norm
         self.grad_scale = 1.0  # 1 / world_size under DDP (gradient averaging)
@@ -174,9 +176,22 @@ class HipAdam(torch.optim.Optimizer):
         return self.state_dev[1].clone()  # detached from the state word, which the next pass overwrites
 
     def _allreduce(self) -> None:
-        if self.reducer is not None:
-            self.reducer.launch(self.arena.grad)
-            self.reducer.wait()
+        """Sum the gradient arena over the ranks.  A parameter takes part in the step when ANY rank produced a gradient
+        for it (DDP with unused parameters: the ranks that did not use it contribute zeros, every rank then steps it
+        identically) -- with condition blocks, which blocks a rank saw is a per-rank fact, so the local "no gradient"
+        list is replaced by the intersection over the ranks (one small MAX all-reduce of presence flags; only for
+        optimisers declared to hold such blocks: the call sequence must be the same on every rank)."""
+        if self.reducer is None:
+            return
+        self.reducer.launch(self.arena.grad)
+        if (self.managed or self.sparse_presence) and mdist.collectives_active():
+            n = len(self.arena.params)
+            present = torch.ones(n, dtype=torch.int32, device=self.arena.grad.device)
+            if self._inactive:
+                present[torch.as_tensor(self._inactive, dtype=torch.long, device=present.device)] = 0
+            torch.distributed.all_reduce(present, op=torch.distributed.ReduceOp.MAX, group=self.reducer.small_group)
+            self._inactive = torch.nonzero(present == 0).flatten().tolist()
+        self.reducer.wait()
 
     def _gather(self) -> List[int]:
         """Autograd gradients into the arena; returns the parameters without a gradient this step.  Parameters managed

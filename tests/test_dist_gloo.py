@@ -129,3 +129,54 @@ def test_bucket_ranges_cover_the_arena_exactly():
         assert rs[0].start == 0 and rs[-1].stop == n
         assert all(a.stop == b.start for a, b in zip(rs, rs[1:]))
         assert all(len(r) <= max(bb // 4, 1) for r in rs)
+
+
+def _presence_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      MMVAE_DIST_TIMEOUT_S="120")
+    torch.set_num_threads(1)
+    from mmvae_amd import backend, dist as mdist
+    from mmvae_amd.optim import HipAdam
+
+    assert mdist.init_from_env("gloo") == world
+    with backend.cpu_plumbing():
+        torch.manual_seed(3)
+        params = [torch.nn.Parameter(torch.randn(5, 3)) for _ in range(4)]
+        opt = HipAdam(params, lr=1e-2, weight_decay=0.0)
+        opt.sparse_presence = True
+        opt.reducer = mdist.GradAllReducer(side_stream=False)
+        opt.grad_scale = 1.0 / world
+        before = [p.detach().clone() for p in params]
+        g = torch.Generator().manual_seed(100)
+        grads = [torch.randn(5, 3, generator=g) for _ in range(4)]  # the same numbers on both ranks
+        mine = {0: (0, 1), 1: (1, 2)}[rank]  # rank 0 saw blocks 0 and 1, rank 1 blocks 1 and 2; nobody saw block 3
+        for i in mine:
+            params[i].grad = grads[i].clone() * (rank + 1)
+        opt.step()
+        torch.save({"after": [p.detach().clone() for p in params], "before": before, "steps": [int(v) for v in opt.host_steps()]},
+                   os.path.join(out_dir, f"presence{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_parameters_seen_by_any_rank_step_on_every_rank(tmp_path):
+    """Condition blocks: which parameters got a gradient is a per-rank fact.  Under data parallelism a parameter steps
+    when ANY rank produced a gradient for it (ranks that did not contribute zeros), identically on every rank; a
+    parameter nobody saw is skipped (no moment decay, no step count) -- torch.optim.Adam under DDP with unused
+    parameters."""
+    world, port = 2, _free_port()
+    mp.spawn(_presence_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "presence0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "presence1.pt"))
+    for a, b in zip(r0["after"], r1["after"]):
+        assert torch.equal(a, b), "ranks diverged"
+    for i in range(3):
+        assert not torch.equal(r0["after"][i], r0["before"][i]), f"block {i} was seen by a rank and must step"
+    assert torch.equal(r0["after"][3], r0["before"][3]), "block 3 was seen by nobody and must not move"
+    assert list(r0["steps"]) == [1, 1, 1, 0] and list(r1["steps"]) == [1, 1, 1, 0]
+    # the update itself: Adam's first step moves every entry by lr * sign(averaged gradient)
+    g = torch.Generator().manual_seed(100)
+    grads = [torch.randn(5, 3, generator=g) for _ in range(4)]
+    avg = [grads[0] * 1 / 2, grads[1] * (1 + 2) / 2, grads[2] * 2 / 2]
+    for i in range(3):
+        want = r0["before"][i] - 1e-2 * torch.sign(avg[i])
+        assert torch.allclose(r0["after"][i], want, atol=1e-6), i
