@@ -1295,8 +1295,15 @@ class _Plan:
         self._cur = []
         if not self.explicit:
             n = self.K * self.B * self.Z
-            self._emit(lib.mmvae_philox_normal, n, _p(self.eps), _p(self.rng_state), rng.STREAM_NORMAL, 0)
-            self._emit(lib.mmvae_philox_advance, _p(self.rng_state), (n + 3) // 4)
+            if eng.merge_launches and eng.fuse_norm_prepare:  # one launch: the fill's last workgroup advances the counter
+                arr = (_lib.PhiloxJob * 1)(_lib.PhiloxJob(_p(self.eps), n, rng.STREAM_NORMAL, 0.0, 1))
+                jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(eng.device)
+                self._job_tables.append(jobs_dev)
+                self._emit(lib.mmvae_philox_fill_jobs_advance, 1, jobs_dev.data_ptr(), n, _p(self.rng_state),
+                           (n + 3) // 4, _p(eng.buf("philox.ticket", (1,), torch.int32)))
+            else:
+                self._emit(lib.mmvae_philox_normal, n, _p(self.eps), _p(self.rng_state), rng.STREAM_NORMAL, 0)
+                self._emit(lib.mmvae_philox_advance, _p(self.rng_state), (n + 3) // 4)
             self.segments[0] = self._cur + self.segments[0]
             self._cur = []
         self._size_workspaces()
