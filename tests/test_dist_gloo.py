@@ -180,3 +180,94 @@ def test_parameters_seen_by_any_rank_step_on_every_rank(tmp_path):
     for i in range(3):
         want = r0["before"][i] - 1e-2 * torch.sign(avg[i])
         assert torch.allclose(r0["after"][i], want, atol=1e-6), i
+
+
+def _cond_batch(case, z, t=0):
+    eid = case["schedule"][t]
+    x, eps, masks, labels = H.step_inputs(z, t)
+    meta = {c: [f"{c}_{int(i)}" for i in idx] for c, idx in labels.items()}
+    meta.update(H.cond_inputs(case, z, t, eid)[0])
+    return eid, x, eps, masks, pd.DataFrame(meta)
+
+
+def _cond_step(model, case, x, eps, masks, meta, eid, rows):
+    import random
+
+    from mmvae_amd import backend
+
+    with backend.cpu_plumbing():
+        model.kl_annealing_fn.kl_weight = case["kl_weights"][0]
+        model.module.vae.encoder.explicit_eps = eps[rows]
+        model.module.experts[eid].encoder.explicit_masks = {
+            int(k.split(".")[4]): m[rows] for k, m in masks.items() if k.startswith(f"experts.{eid}.encoder.fc_layers.")}
+        random.seed(case["seed"] * 100)
+        model.training_step((x[rows], meta.iloc[rows].reset_index(drop=True), eid), 0)
+
+
+def _cond_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      MMVAE_DIST_TIMEOUT_S="120")
+    torch.set_num_threads(1)
+    from mmvae_amd import dist as mdist
+
+    assert mdist.init_from_env("gloo") == world
+    case, z = H.load_case("cond_seq")
+    eid, x, eps, masks, meta = _cond_batch(case, z)
+    B = x.shape[0] // world
+    rows = slice(rank * B, (rank + 1) * B)
+    with tempfile.TemporaryDirectory() as d:
+        model = _build(case, d)
+        MU.load_state(model, z, "sd0/")
+        mdist.broadcast_parameters(model)
+        mdist.attach(model, mdist.GradAllReducer(bucket_bytes=1 << 16, side_stream=False))
+        _cond_step(model, case, x, eps, masks, meta, eid, rows)
+        flat = torch.cat([p.detach().flatten() for _, p in model.module.named_parameters()])
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], g) for g in gathered), "ranks diverged"
+        if rank == 0:
+            torch.save({n: p.detach().clone() for n, p in model.module.named_parameters()},
+                       os.path.join(out_dir, "cond_dp.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_of_a_conditional_model_matches_the_manual_union(tmp_path):
+    """Conditional layers under data parallelism (module path, CPU plumbing over gloo): the two ranks see different
+    conditions; every block seen by either steps on both with the averaged gradient (zeros from the rank that did not
+    see it), blocks seen by neither are skipped -- equal to a one-process computation of exactly that."""
+    world, port = 2, _free_port()
+    mp.spawn(_cond_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    dp = torch.load(os.path.join(tmp_path, "cond_dp.pt"))
+    case, z = H.load_case("cond_seq")
+    eid, x, eps, masks, meta = _cond_batch(case, z)
+    B = x.shape[0] // world
+    with tempfile.TemporaryDirectory() as d:
+        from mmvae_amd import backend
+
+        shard = []
+        for r in range(world):
+            m = _build(case, d)
+            MU.load_state(m, z, "sd0/")
+            for o in m.optimizers():
+                o.step = lambda closure=None: None  # gradients only
+            _cond_step(m, case, x, eps, masks, meta, eid, slice(r * B, (r + 1) * B))
+            shard.append([(o.arena.grad.clone(), set(o._inactive)) for o in m.optimizers()])
+        m = _build(case, d)
+        MU.load_state(m, z, "sd0/")
+        seen_by_one_only = 0
+        with backend.cpu_plumbing():
+            for i, o in enumerate(m.optimizers()):
+                if i not in (m.optimizer_map["vae"], m.optimizer_map["experts"][eid]):
+                    continue
+                o.arena.grad.copy_(sum(g for g, _ in (s[i] for s in shard)))
+                absent_everywhere = sorted(set.intersection(*[s[i][1] for s in shard]))
+                seen_by_one_only += len(set.union(*[s[i][1] for s in shard])) - len(absent_everywhere)
+                o.grad_scale = 1.0 / world
+                o.set_clip(10.0)
+                o._gather = lambda absent=absent_everywhere: list(absent)
+                o.step()
+        assert seen_by_one_only > 0, "the shards must differ in the conditions they hold for this test to mean anything"
+        skip = H.bn_fed_biases(H.spec_from_case(case))
+        for n, p in m.module.named_parameters():
+            if n not in skip:
+                assert H.rel_l2(dp[n], p.detach()) < 1e-5, n
