@@ -271,3 +271,44 @@ def test_two_rank_step_of_a_conditional_model_matches_the_manual_union(tmp_path)
         for n, p in m.module.named_parameters():
             if n not in skip:
                 assert H.rel_l2(dp[n], p.detach()) < 1e-5, n
+
+
+def _adv_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      MMVAE_DIST_TIMEOUT_S="120")
+    torch.set_num_threads(1)
+    from mmvae_amd import backend, dist as mdist
+
+    assert mdist.init_from_env("gloo") == world
+    case, z = H.load_case("adversarial")
+    with tempfile.TemporaryDirectory() as d:
+        model = _build(case, d)
+        MU.load_state(model, z, "sd0/")
+        mdist.broadcast_parameters(model)
+        mdist.attach(model, mdist.GradAllReducer(bucket_bytes=1 << 16, side_stream=False))
+        for t in range(2):  # discriminator + generator phases, two modalities
+            eid = case["schedule"][t]
+            x, eps, masks, labels = H.step_inputs(z, t)
+            B = x.shape[0] // world
+            rows = slice(rank * B, (rank + 1) * B)
+            meta = pd.DataFrame({c: [f"{c}_{int(i)}" for i in idx] for c, idx in labels.items()}).iloc[rows]
+            with backend.cpu_plumbing():
+                model.kl_annealing_fn.kl_weight = case["kl_weights"][t]
+                model.module.vae.encoder.explicit_eps = eps[rows]
+                model.module.experts[eid].encoder.explicit_masks = {
+                    int(k.split(".")[4]): m[rows] for k, m in masks.items()
+                    if k.startswith(f"experts.{eid}.encoder.fc_layers.")}
+                model.training_step((x[rows], meta.reset_index(drop=True), eid), t)
+        flat = torch.cat([p.detach().flatten() for _, p in model.module.named_parameters()])
+        assert torch.isfinite(flat).all()
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], g) for g in gathered), "ranks diverged"
+    dist.destroy_process_group()
+
+
+def test_two_rank_adversarial_steps_keep_the_replicas_identical():
+    """Discriminator and generator phases under data parallelism (module path, gloo): every optimiser of the step --
+    adversaries, shared VAE, active expert -- exchanges its gradients; the replicas stay bit-identical."""
+    world, port = 2, _free_port()
+    mp.spawn(_adv_worker, args=(world, port, ""), nprocs=world, join=True)
