@@ -341,6 +341,10 @@ int mmvae_adam_step_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, float* para
  * job kernels return at once for them); mmvae_adam_prepare then sums the n_jobs partials. */
 int mmvae_grad_sqnorm_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, const float* grad, float* partials,
                            mmvae_stream_t stream);
+/* grad[job.offset .. +job.len) = 0 for every job whose `reserved` word is 1 (the others return at once): segments that
+ * take part in this step only because another rank produced a gradient for them -- this rank contributes zeros to the
+ * all-reduce that follows. */
+int mmvae_grad_zero_flagged_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, float* grad, mmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Device RNG (k15): Philox4x32-10 streams for production mode (parity mode passes explicit masks / eps).

@@ -709,6 +709,16 @@ __global__ __launch_bounds__(256) void sqnorm_jobs_kernel(const mmvae_adam_job* 
     if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Zero the gradient segment of every job whose `reserved` word is 1: the condition blocks that step on this rank only
+// because ANOTHER rank saw them (data parallelism: this rank contributes zeros to their all-reduce).  Same fixed launch
+// size as the other job kernels; everything else returns at once.
+__global__ __launch_bounds__(256) void zero_flagged_jobs_kernel(const mmvae_adam_job* __restrict__ jobs,
+                                                                float* __restrict__ g) {
+    const mmvae_adam_job job = jobs[blockIdx.x];
+    if (job.reserved != 1) return;
+    for (int i = threadIdx.x; i < job.len; i += 256) g[job.offset + i] = 0.f;
+}
+
 // Diagnostics: stand-in for a collective that runs beside the step.  Each workgroup holds `lds`
 // bytes of LDS (so that a CU cannot host its usual two GEMM workgroups beside it) and spins for `micros` microseconds of
 // the constant 100 MHz wall clock; every wave reaches the exit condition, the grid always drains.
@@ -1138,6 +1148,13 @@ extern "C" int mmvae_grad_sqnorm_jobs(int n_jobs, const mmvae_adam_job* jobs_dev
                                       mmvae_stream_t stream) {
     if (n_jobs <= 0 || !jobs_dev || !grad || !partials) return MMVAE_ERR_ARG;
     MMVAE_LAUNCH(sqnorm_jobs_kernel, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, grad, partials);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_grad_zero_flagged_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, float* grad, mmvae_stream_t stream) {
+    if (n_jobs <= 0 || !jobs_dev || !grad) return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(zero_flagged_jobs_kernel, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, grad);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }

@@ -128,8 +128,9 @@ class StepEngine:
         if not all(isinstance(o, HipAdam) and o._hip for o in opts):
             return None
         if cl is not None:
-            # ranks see different conditions: which blocks step is a per-rank fact, the flat exchange is not built for it
-            if mdist.collectives_active() or os.environ.get("MMVAE_DP_OVERLAP", "") == "1":
+            # ranks see different conditions: the blocks that step are the UNION over the ranks (_CondProgram.load);
+            # MMVAE_ENGINE_CONDITIONALS_DP=0 sends such a model back to the module path under data parallelism
+            if mdist.collectives_active() and os.environ.get("MMVAE_ENGINE_CONDITIONALS_DP", "1") == "0":
                 return None
             if not _CondProgram.supported(cl, model.get_optimizers()["vae"], m.vae.encoder.mean_encoder.out_features):
                 return None
@@ -1155,6 +1156,10 @@ class _Plan:
                                dx_out=self.dz_lat if self.cond is None else self.cond.d_out)
         if self.cond is not None:
             self.cond.emit_backward(self.dz_lat)
+            if mdist.collectives_active() and train:
+                # blocks another rank saw and this one did not: zeros into the exchange (job table of this step)
+                self._emit(lib.mmvae_grad_zero_flagged_jobs, self.cond.max_jobs, self.cond.jobs_ptr,
+                           _p(self.cond.opt.arena.grad))
         if not rest:
             raise _lib.HipLibraryError("engine: decoder needs at least two layers")
         # gradient-reversed adversary gradient on z (first sample) joins here
@@ -1689,7 +1694,9 @@ class _CondProgram:
         jpb = (Z * Z + 16383) // 16384 + 1  # jobs of one block: weight chunks + bias
         b1, b2 = self.opt.param_groups[0]["betas"]
         n_dense_jobs = len(self.opt.job_table(self.dense, b1, b2)) if train else 0
-        self.max_jobs = n_dense_jobs + sum(min(R, len(e["w_idx"])) for e in self.entries.values()) * jpb if train else 0
+        # blocks that can step: at most one per cell of the batch -- of EVERY rank's batch under data parallelism
+        cells = R * (mdist.world_size() if mdist.collectives_active() else 1)
+        self.max_jobs = n_dense_jobs + sum(min(cells, len(e["w_idx"])) for e in self.entries.values()) * jpb if train else 0
         # ---- static device tables, filled by load(): one padded cond_tables set per position
         self.P = cond_tables.words(R)
         self.lay = cond_tables.layout(R)
@@ -1806,9 +1813,25 @@ class _CondProgram:
         if self.train:
             act = np.concatenate(active)
             b1, b2 = self.opt.param_groups[0]["betas"]
-            jobs = self.opt.job_table(act, b1, b2)
+            absent_here = None
+            if mdist.collectives_active():
+                # Data parallelism: a parameter steps when ANY rank produced a gradient for it (the others contribute
+                # zeros; DDP's semantics for unused parameters, HipAdam._allreduce on the module path).  One MAX
+                # all-reduce of presence flags per step, on the host path ahead of the replay; every rank then builds
+                # the same job table, and marks the segments it did not write itself for zeroing.
+                n = len(self.opt.arena.params)
+                present = torch.zeros(n, dtype=torch.int32, device=self.eng.device)
+                present[torch.as_tensor(act, dtype=torch.long, device=self.eng.device)] = 1
+                torch.distributed.all_reduce(present, op=torch.distributed.ReduceOp.MAX,
+                                             group=self.opt.reducer.small_group if self.opt.reducer is not None else None)
+                union = np.flatnonzero(present.cpu().numpy()).astype(np.int64)
+                absent_here = np.setdiff1d(union, act, assume_unique=False)
+                act = union
+            jobs, owner = self.opt.job_table(act, b1, b2, with_owner=True)
             if len(jobs) > self.max_jobs:
                 raise _lib.HipLibraryError("engine: conditional job table overflow")
+            if absent_here is not None and len(absent_here):
+                jobs["reserved"][np.isin(act[owner], absent_here)] = 1  # zeroed ahead of the exchange
             pack[self.idx_words:self.idx_words + 6 * len(jobs)] = jobs.view(np.int32)
             self._active = act
         self.ring.take()[:] = pack

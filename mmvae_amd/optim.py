@@ -256,9 +256,10 @@ class HipAdam(torch.optim.Optimizer):
             self._steps = np.full(len(self.arena.params), int(round(float(self.state_dev[0]))), dtype=np.int64)
         return self._steps
 
-    def job_table(self, active, b1, b2):
+    def job_table(self, active, b1, b2, with_owner: bool = False):
         """`mmvae_adam_job` records (numpy structured array) of the parameters `active` (indices into the arena) for
-        their NEXT step: a job per <= 16384-element chunk carrying the tensor's own bias corrections."""
+        their NEXT step: a job per <= 16384-element chunk carrying the tensor's own bias corrections.  `with_owner`:
+        also the position in `active` of the parameter every job belongs to."""
         import numpy as np
 
         a = self.arena
@@ -278,7 +279,7 @@ class HipAdam(torch.optim.Optimizer):
         jobs["offset"] = off[owner] + k * J
         jobs["len"] = np.minimum(num[owner] - k * J, J)
         jobs["bc1"], jobs["bc2"] = bc1[owner], bc2[owner]
-        return jobs
+        return (jobs, owner) if with_owner else jobs
 
     def _step_partial(self, g, b1, b2, norm_valid: bool):
         """A step in which some parameters have no gradient, or after such a step: torch.optim.Adam semantics --

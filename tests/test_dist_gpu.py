@@ -113,7 +113,14 @@ def _run(rank, world, port, out_dir, use_engine, name="two_mod_odd"):
             x, eps, masks, labels = H.step_inputs(z, t % len(case["schedule"]))
             B = x.shape[0] // world
             rows = slice(rank * B, (rank + 1) * B)  # each rank trains its own cells
-            meta = {c: [f"{c}_{int(i)}" for i in idx[rows]] for c, idx in labels.items()} or {"dummy": [0] * B}
+            meta = {c: [f"{c}_{int(i)}" for i in idx[rows]] for c, idx in labels.items()}
+            if case.get("cond"):  # the two ranks hold different conditions: the blocks that step are their union
+                import random
+
+                tt = t % len(case["schedule"])
+                meta.update({k: v[rows] for k, v in H.cond_inputs(case, z, tt, eid)[0].items()})
+                random.seed(case["seed"] * 100 + tt)
+            meta = meta or {"dummy": [0] * B}
             model.module.vae.encoder.explicit_eps = eps[rows].cuda()
             enc = model.module.experts[eid].encoder
             enc.explicit_masks = {int(k.split(".")[4]): m[rows].cuda() for k, m in masks.items()
@@ -200,7 +207,7 @@ def two_processes_share_the_gpu(tmp_path_factory):
 
 
 @pytest.mark.timeout(2 * RUN_DEADLINE_S + 60)
-@pytest.mark.parametrize("name", ["two_mod_odd", "adversarial"])
+@pytest.mark.parametrize("name", ["two_mod_odd", "adversarial", "cond_seq"])
 def test_two_ranks_on_one_gpu_engine_equals_module_path(tmp_path, name, two_processes_share_the_gpu):
     """`adversarial`: the discriminator / generator phases exchange their (small) arenas inline, between graph segments."""
     world = 2
