@@ -135,6 +135,9 @@ def _run(rank, world, port, out_dir, use_engine, name="two_mod_odd"):
             gathered = [torch.empty_like(flat) for _ in range(world)]
             dist.all_gather(gathered, flat)
             assert all(torch.equal(gathered[0], g) for g in gathered), f"ranks diverged at step {t}"
+        if use_engine and case.get("cond"):
+            plans = model._engine._plans
+            assert plans and all(p.cond is not None for p in plans.values()), "the conditional layers must run in the engine"
         if rank == 0:
             skip = H.bn_fed_biases(H.spec_from_case(case))
             torch.save({n: p.detach().cpu() for n, p in model.module.named_parameters() if n not in skip},
