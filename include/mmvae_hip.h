@@ -341,9 +341,10 @@ int mmvae_adam_step_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, float* para
  * job kernels return at once for them); mmvae_adam_prepare then sums the n_jobs partials. */
 int mmvae_grad_sqnorm_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, const float* grad, float* partials,
                            mmvae_stream_t stream);
-/* grad[job.offset .. +job.len) = 0 for every job whose `reserved` word is 1 (the others return at once): segments that
- * take part in this step only because another rank produced a gradient for them -- this rank contributes zeros to the
- * all-reduce that follows. */
+/* grad[job.offset .. +job.len) = 0 for every job whose `reserved` word is 1 or 2 (the others return at once).  1: a
+ * segment that takes part in this step only because another rank produced a gradient for it -- this rank contributes
+ * zeros to the all-reduce that follows.  2: a "retired" segment (stepped last time, not now): zeroed so that a dense
+ * all-reduce never sums stale values; mmvae_grad_sqnorm_jobs / mmvae_adam_step_jobs skip such jobs. */
 int mmvae_grad_zero_flagged_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, float* grad, mmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -644,6 +644,7 @@ __global__ __launch_bounds__(256) void adam_step_jobs_kernel(const mmvae_adam_jo
                                                              float lr, float b1, float b2, float eps, float wd,
                                                              float grad_scale) {
     const mmvae_adam_job job = jobs[blockIdx.x];
+    if (job.reserved == 2) return;  // a retired segment (zeroed for the exchange, takes no step)
     const float gmul = state[2] * grad_scale;
     const float step_size = lr / job.bc1;
     const float inv_bc2_sqrt = 1.f / sqrtf(job.bc2);
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(256) void sqnorm_jobs_kernel(const mmvae_adam_job* 
     __shared__ float red[4];
     const mmvae_adam_job job = jobs[blockIdx.x];
     const int64_t o = job.offset;
-    const int n = job.len;
+    const int n = job.reserved == 2 ? 0 : job.len;  // retired segments do not count
     float s = 0.f;
     if ((o & 3) == 0) {
         const int nv = n >> 2;
@@ -709,13 +710,14 @@ __global__ __launch_bounds__(256) void sqnorm_jobs_kernel(const mmvae_adam_job* 
     if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// Zero the gradient segment of every job whose `reserved` word is 1: the condition blocks that step on this rank only
-// because ANOTHER rank saw them (data parallelism: this rank contributes zeros to their all-reduce).  Same fixed launch
-// size as the other job kernels; everything else returns at once.
+// Zero the gradient segment of every job whose `reserved` word is 1 -- the condition blocks that step on this rank only
+// because ANOTHER rank saw them (data parallelism: this rank contributes zeros to their all-reduce) -- or 2 -- segments
+// that stepped last time and do not now ("retired": zeroed once so that the dense all-reduce never sums stale values;
+// the norm and Adam job kernels skip them).  Same fixed launch size as the other job kernels.
 __global__ __launch_bounds__(256) void zero_flagged_jobs_kernel(const mmvae_adam_job* __restrict__ jobs,
                                                                 float* __restrict__ g) {
     const mmvae_adam_job job = jobs[blockIdx.x];
-    if (job.reserved != 1) return;
+    if (job.reserved != 1 && job.reserved != 2) return;
     for (int i = threadIdx.x; i < job.len; i += 256) g[job.offset + i] = 0.f;
 }
 

@@ -1697,6 +1697,8 @@ class _CondProgram:
         # blocks that can step: at most one per cell of the batch -- of EVERY rank's batch under data parallelism
         cells = R * (mdist.world_size() if mdist.collectives_active() else 1)
         self.max_jobs = n_dense_jobs + sum(min(cells, len(e["w_idx"])) for e in self.entries.values()) * jpb if train else 0
+        if mdist.collectives_active():
+            self.max_jobs += self.max_jobs - n_dense_jobs  # + the segments retired from the previous step's union
         # ---- static device tables, filled by load(): one padded cond_tables set per position
         self.P = cond_tables.words(R)
         self.lay = cond_tables.layout(R)
@@ -1832,6 +1834,23 @@ class _CondProgram:
                 raise _lib.HipLibraryError("engine: conditional job table overflow")
             if absent_here is not None and len(absent_here):
                 jobs["reserved"][np.isin(act[owner], absent_here)] = 1  # zeroed ahead of the exchange
+            if absent_here is not None:
+                # segments that stepped last time and do not now: zeroed once (the dense all-reduce of the arena would
+                # otherwise sum their stale values on every step), skipped by the norm / Adam job kernels
+                prev = getattr(self.eng, "_cond_prev_union", None)  # engine-wide: every plan steps the same VAE arena
+                carry = np.empty(0, dtype=np.int64)
+                if prev is not None:
+                    retired = np.setdiff1d(prev, act)
+                    if len(retired):
+                        rj, r_owner = self.opt.job_table(retired, b1, b2, with_owner=True)
+                        room = self.max_jobs - len(jobs)
+                        if len(rj) > room:  # (another species' plan left more than this table holds: the rest next time)
+                            fits = r_owner < (r_owner[room] if room > 0 else 0)
+                            carry = retired[(r_owner[room] if room > 0 else 0):]
+                            rj = rj[fits]
+                        rj["reserved"] = 2
+                        jobs = np.concatenate([jobs, rj])
+                self.eng._cond_prev_union = np.union1d(act, carry)
             pack[self.idx_words:self.idx_words + 6 * len(jobs)] = jobs.view(np.int32)
             self._active = act
         self.ring.take()[:] = pack
