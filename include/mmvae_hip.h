@@ -341,11 +341,18 @@ int mmvae_adam_step_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, float* para
  * job kernels return at once for them); mmvae_adam_prepare then sums the n_jobs partials. */
 int mmvae_grad_sqnorm_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, const float* grad, float* partials,
                            mmvae_stream_t stream);
-/* grad[job.offset .. +job.len) = 0 for every job whose `reserved` word is 1 or 2 (the others return at once).  1: a
+/* grad[job.offset .. +job.len) = 0 for every job whose `reserved & 3` is 1 or 2 (the others return at once).  1: a
  * segment that takes part in this step only because another rank produced a gradient for it -- this rank contributes
  * zeros to the all-reduce that follows.  2: a "retired" segment (stepped last time, not now): zeroed so that a dense
  * all-reduce never sums stale values; mmvae_grad_sqnorm_jobs / mmvae_adam_step_jobs skip such jobs. */
 int mmvae_grad_zero_flagged_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, float* grad, mmvae_stream_t stream);
+/* Gather the first n_jobs segments of a job table into a staging buffer and scatter them back: a gradient exchange over
+ * the tensors that took part moves the staging buffer instead of the whole arena (conditional layers: hundreds of
+ * blocks out of thousands).  Job j's place is (reserved >> 2) * 128 floats -- the host lays the segments out back to
+ * back, each rounded up to 128 floats (padding zero-filled by the pack); the low 2 bits of `reserved` stay the flags of
+ * mmvae_grad_zero_flagged_jobs. */
+int mmvae_jobs_pack(int n_jobs, const mmvae_adam_job* jobs_dev, const float* arena, float* staging, mmvae_stream_t stream);
+int mmvae_jobs_unpack(int n_jobs, const mmvae_adam_job* jobs_dev, float* arena, const float* staging, mmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Device RNG (k15): Philox4x32-10 streams for production mode (parity mode passes explicit masks / eps).

@@ -95,6 +95,8 @@ PROTOTYPES = {
     "mmvae_adam_step_jobs": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _f, _p]),
     "mmvae_grad_sqnorm_jobs": (_i, [_i, _p, _p, _p, _p]),
     "mmvae_grad_zero_flagged_jobs": (_i, [_i, _p, _p, _p]),
+    "mmvae_jobs_pack": (_i, [_i, _p, _p, _p, _p]),
+    "mmvae_jobs_unpack": (_i, [_i, _p, _p, _p, _p]),
     "mmvae_philox_keep_mask": (_i, [_l, _f, _p, _p, _u64, _i, _p]),
     "mmvae_philox_normal": (_i, [_l, _p, _p, _u64, _i, _p]),
     "mmvae_philox_advance": (_i, [_p, _u64, _p]),

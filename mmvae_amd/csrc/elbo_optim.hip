@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void adam_step_jobs_kernel(const mmvae_adam_jo
                                                              float lr, float b1, float b2, float eps, float wd,
                                                              float grad_scale) {
     const mmvae_adam_job job = jobs[blockIdx.x];
-    if (job.reserved == 2) return;  // a retired segment (zeroed for the exchange, takes no step)
+    if ((job.reserved & 3) == 2) return;  // a retired segment (zeroed for the exchange, takes no step)
     const float gmul = state[2] * grad_scale;
     const float step_size = lr / job.bc1;
     const float inv_bc2_sqrt = 1.f / sqrtf(job.bc2);
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(256) void sqnorm_jobs_kernel(const mmvae_adam_job* 
     __shared__ float red[4];
     const mmvae_adam_job job = jobs[blockIdx.x];
     const int64_t o = job.offset;
-    const int n = job.reserved == 2 ? 0 : job.len;  // retired segments do not count
+    const int n = (job.reserved & 3) == 2 ? 0 : job.len;  // retired segments do not count
     float s = 0.f;
     if ((o & 3) == 0) {
         const int nv = n >> 2;
@@ -717,8 +717,29 @@ __global__ __launch_bounds__(256) void sqnorm_jobs_kernel(const mmvae_adam_job* 
 __global__ __launch_bounds__(256) void zero_flagged_jobs_kernel(const mmvae_adam_job* __restrict__ jobs,
                                                                 float* __restrict__ g) {
     const mmvae_adam_job job = jobs[blockIdx.x];
-    if (job.reserved != 1 && job.reserved != 2) return;
+    if ((job.reserved & 3) != 1 && (job.reserved & 3) != 2) return;
     for (int i = threadIdx.x; i < job.len; i += 256) g[job.offset + i] = 0.f;
+}
+
+// Gather / scatter the segments of a job table into / out of a staging buffer: the gradient exchange of a step in which
+// only some tensors took part moves the staging buffer instead of the whole arena.  Job j's place in it is written by
+// the host into the upper bits of its `reserved` word: (reserved >> 2) * 128 floats (segments are laid out back to back,
+// each rounded up to 128 floats; the low 2 bits stay the zero / retire flags).
+template <bool PACK>
+__global__ __launch_bounds__(256) void jobs_pack_kernel(const mmvae_adam_job* __restrict__ jobs, float* __restrict__ arena,
+                                                        float* __restrict__ staging) {
+    const mmvae_adam_job job = jobs[blockIdx.x];
+    float* a = arena + job.offset;
+    float* s = staging + (int64_t)((unsigned)job.reserved >> 2) * 128;
+    const int n = job.len, padded = (n + 127) & ~127;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        if (PACK)
+            s[i] = a[i];
+        else
+            a[i] = s[i];
+    }
+    if (PACK)  // the padding is part of the exchanged range: defined (zero) on every rank
+        for (int i = n + threadIdx.x; i < padded; i += 256) s[i] = 0.f;
 }
 
 // Diagnostics: stand-in for a collective that runs beside the step.  Each workgroup holds `lds`
@@ -1150,6 +1171,24 @@ extern "C" int mmvae_grad_sqnorm_jobs(int n_jobs, const mmvae_adam_job* jobs_dev
                                       mmvae_stream_t stream) {
     if (n_jobs <= 0 || !jobs_dev || !grad || !partials) return MMVAE_ERR_ARG;
     MMVAE_LAUNCH(sqnorm_jobs_kernel, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, grad, partials);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_jobs_pack(int n_jobs, const mmvae_adam_job* jobs_dev, const float* arena, float* staging,
+                               mmvae_stream_t stream) {
+    if (n_jobs <= 0 || !jobs_dev || !arena || !staging) return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(jobs_pack_kernel<true>, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev,
+                 const_cast<float*>(arena), staging);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_jobs_unpack(int n_jobs, const mmvae_adam_job* jobs_dev, float* arena, const float* staging,
+                                 mmvae_stream_t stream) {
+    if (n_jobs <= 0 || !jobs_dev || !arena || !staging) return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(jobs_pack_kernel<false>, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, arena,
+                 const_cast<float*>(staging));
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }

@@ -168,6 +168,7 @@ class StepEngine:
         self.batch_finish = os.environ.get("MMVAE_BATCH_FINISH", "1") != "0"
         self.batch_gemms = os.environ.get("MMVAE_BATCH_GEMMS", "1") != "0"
         self.fuse_sqnorm = os.environ.get("MMVAE_FUSE_SQNORM", "1") != "0"
+        self.cond_packed_exchange = os.environ.get("MMVAE_COND_PACKED_EXCHANGE", "1") != "0"  # 0: dense VAE arena
         self.fuse_norm_prepare = os.environ.get("MMVAE_FUSE_NORM_PREPARE", "1") != "0"  # norm pass + adam_prepare: one launch
         self.fuse_dp_colsum = os.environ.get("MMVAE_FUSE_DP_COLSUM", "1") != "0"  # decoder-bias gradient from the recon epilogue
         if os.environ.get("MMVAE_SIDE_STREAM", "0") != "0":
@@ -1485,14 +1486,26 @@ class _Plan:
         red = opt.reducer
         eng = self.eng
         main = torch.cuda.current_stream()
+
+        def reduce_small():
+            c = self.cond
+            if c is not None and opt is self.opt_vae and c.n_exchange and eng.cond_packed_exchange:
+                # conditional layers: only the union's segments travel (pack -> all-reduce -> unpack, on this stream)
+                lib, st = self.lib, c.staging
+                _lib.check(lib.mmvae_jobs_pack(c.n_exchange, c.jobs_ptr, _p(opt.arena.grad), _p(st), _s()), "mmvae_jobs_pack")
+                red.reduce_here(st[: c.exchange_floats], small=True)
+                _lib.check(lib.mmvae_jobs_unpack(c.n_exchange, c.jobs_ptr, _p(opt.arena.grad), _p(st), _s()), "mmvae_jobs_unpack")
+            else:
+                red.reduce_here(opt.arena.grad, small=True)
+
         if kind == "ar_inline":
             if red is not None:
-                red.reduce_here(opt.arena.grad, small=True)
+                reduce_small()
         elif kind == "ar_begin":
             eng.small_stream.wait_stream(main)
             if red is not None:
                 with torch.cuda.stream(eng.small_stream):
-                    red.reduce_here(opt.arena.grad, small=True)
+                    reduce_small()
         elif kind == "ar_wait":
             main.wait_stream(eng.small_stream)
         elif kind == "ar_deferred":
@@ -1697,6 +1710,10 @@ class _CondProgram:
         # blocks that can step: at most one per cell of the batch -- of EVERY rank's batch under data parallelism
         cells = R * (mdist.world_size() if mdist.collectives_active() else 1)
         self.max_jobs = n_dense_jobs + sum(min(cells, len(e["w_idx"])) for e in self.entries.values()) * jpb if train else 0
+        self.n_exchange, self.exchange_floats, self.staging = 0, 0, None
+        if mdist.collectives_active() and train:
+            # gradient exchange over the union's segments only: staging for every job of a full table
+            self.staging = eng.buf("cond.exchange", (self.max_jobs * 16384,))
         if mdist.collectives_active():
             self.max_jobs += self.max_jobs - n_dense_jobs  # + the segments retired from the previous step's union
         # ---- static device tables, filled by load(): one padded cond_tables set per position
@@ -1834,6 +1851,17 @@ class _CondProgram:
                 raise _lib.HipLibraryError("engine: conditional job table overflow")
             if absent_here is not None and len(absent_here):
                 jobs["reserved"][np.isin(act[owner], absent_here)] = 1  # zeroed ahead of the exchange
+            self.n_exchange = 0
+            if absent_here is not None:
+                # the exchange moves the union's segments only: each job's place in the staging buffer, back to back in
+                # units of 128 floats, rides in the upper bits of its `reserved` word (mmvae_jobs_pack)
+                units = (jobs["len"].astype(np.int64) + 127) // 128
+                pos = np.cumsum(units) - units
+                self.exchange_floats = int(units.sum()) * 128
+                if self.exchange_floats > self.staging.numel() or int(pos[-1] if len(pos) else 0) >= (1 << 29):
+                    raise _lib.HipLibraryError("engine: conditional exchange staging overflow")
+                jobs["reserved"] |= (pos.astype(np.int64) << 2).astype(np.int32)
+                self.n_exchange = len(jobs)
             if absent_here is not None:
                 # segments that stepped last time and do not now: zeroed once (the dense all-reduce of the arena would
                 # otherwise sum their stale values on every step), skipped by the norm / Adam job kernels
