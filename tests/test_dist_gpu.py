@@ -138,6 +138,10 @@ def _run(rank, world, port, out_dir, use_engine, name="two_mod_odd"):
         if use_engine and case.get("cond"):
             plans = model._engine._plans
             assert plans and all(p.cond is not None for p in plans.values()), "the conditional layers must run in the engine"
+            # (at this toy size the 128-float rounding of the tiny blocks makes the staging as long as the arena; at the
+            # reference's size the union is a few hundred 64 KB blocks of 4 937)
+            assert all(p.cond.n_exchange > 0 and p.cond.exchange_floats > 0 for p in plans.values()), \
+                "the exchange must have gone through the packed segments of the union"
         if rank == 0:
             skip = H.bn_fed_biases(H.spec_from_case(case))
             torch.save({n: p.detach().cpu() for n, p in model.module.named_parameters() if n not in skip},

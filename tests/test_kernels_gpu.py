@@ -488,6 +488,53 @@ def test_norm_ranges_and_prepare_in_one_launch_equal_the_separate_launches(ops):
             assert int(ticket) == 0
 
 
+def test_job_segments_pack_unpack_and_flags(ops):
+    """mmvae_jobs_pack / _unpack (the exchange of the tensors that took part: segments laid out back to back in units of
+    128 floats, position in the upper bits of the job's `reserved` word) and the flag semantics of the job kernels:
+    reserved & 3 == 1 -> zeroed ahead of the exchange, == 2 -> zeroed and skipped by the norm / Adam job kernels."""
+    import numpy as np
+
+    from mmvae_amd import _lib
+    from mmvae_amd.optim import HipAdam
+
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    arena = dev(rnd(200_000, seed=11))
+    segs = [(16, 16384, 0), (40_000, 128, 1), (50_000, 7, 0), (60_000, 16384, 2), (90_004, 300, 0)]  # offset, len, flag
+    jobs = np.zeros(len(segs), dtype=np.dtype(HipAdam.JOB_DTYPE))
+    pos = 0
+    for j, (o, n, f) in enumerate(segs):
+        jobs[j]["offset"], jobs[j]["len"], jobs[j]["bc1"], jobs[j]["bc2"] = o, n, 0.1, 0.001
+        jobs[j]["reserved"] = f | (pos << 2)
+        pos += (n + 127) // 128
+    jobs_dev = torch.frombuffer(bytearray(jobs.tobytes()), dtype=torch.uint8).cuda()
+    staging = torch.full((pos * 128,), float("nan"), device="cuda")
+    assert lib.mmvae_jobs_pack(len(segs), jobs_dev.data_ptr(), arena.data_ptr(), staging.data_ptr(), s) == 0
+    p = 0
+    for o, n, _ in segs:
+        assert torch.equal(staging[p * 128: p * 128 + n], arena[o:o + n])
+        pad = (n + 127) // 128 * 128 - n
+        assert torch.equal(staging[p * 128 + n: p * 128 + n + pad], torch.zeros(pad, device="cuda"))
+        p += (n + 127) // 128
+    back = torch.zeros_like(arena)
+    assert lib.mmvae_jobs_unpack(len(segs), jobs_dev.data_ptr(), back.data_ptr(), (2 * staging).data_ptr(), s) == 0
+    touched = torch.zeros_like(arena, dtype=torch.bool)
+    for o, n, _ in segs:
+        assert torch.equal(back[o:o + n], 2 * arena[o:o + n])
+        touched[o:o + n] = True
+    assert float(back[~touched].abs().max()) == 0.0
+    # flags
+    g = arena.clone()
+    assert lib.mmvae_grad_zero_flagged_jobs(len(segs), jobs_dev.data_ptr(), g.data_ptr(), s) == 0
+    for o, n, f in segs:
+        assert torch.equal(g[o:o + n], torch.zeros(n, device="cuda") if f else arena[o:o + n])
+    partials = torch.full((len(segs),), float("nan"), device="cuda")
+    assert lib.mmvae_grad_sqnorm_jobs(len(segs), jobs_dev.data_ptr(), arena.data_ptr(), partials.data_ptr(), s) == 0
+    for j, (o, n, f) in enumerate(segs):
+        want = 0.0 if f == 2 else float((arena[o:o + n].double() ** 2).sum())
+        assert abs(float(partials[j]) - want) <= 1e-5 * max(want, 1.0), j
+
+
 def test_philox_streams(ops):
     rng = torch.tensor([1234, 0], dtype=torch.int64, device="cuda")
     m1 = ops.philox_keep_mask((512, 1024), 0.1, rng)
