@@ -40,7 +40,7 @@ typedef void* mmvae_stream_t; /* hipStream_t */
 /* ABI version: bumped whenever an entry point is added or a signature changes (mmvae_abi_version() returns the
  * value the library was built with; bindings compare it with the header they were written against).
  *   1  round-1 surface (first 20 entry points)      2  end of round 1 (50 entry points)      3+  round 2 */
-#define MMVAE_ABI_VERSION 4
+#define MMVAE_ABI_VERSION 5
 int mmvae_abi_version(void);
 const char* mmvae_build_arch(void);
 
@@ -412,6 +412,76 @@ int mmvae_gemm_sq_partials(int layout, int M, int N, int K, int operands_regular
 int mmvae_gemm_f32_sq(int layout, int M, int N, int K, float alpha, const float* A, int64_t lda, const float* B,
                       int64_t ldb, float* C, int64_t ldc, const float* bias, unsigned flags, float* sq_partials,
                       int64_t sq_capacity, mmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Pre-split operands of the bf16x3 GEMMs (r3)
+ * replaces: the same nn.Linear forward / backward dispatches as mmvae_gemm_f32 (components.py:276 and its autograd)
+ *
+ * The bf16x3 GEMMs split every fp32 operand element exactly into three bf16 pieces a = p0 + p1 + p2 (p0 = the top 16
+ * bits of a, p1 = the top 16 bits of a - p0, p2 = a - p0 - p1).  Done inside the GEMM, each element is split once per
+ * tile that reads it (10 x on the G-wide layers of the step) by vector instructions that take the matrix cores' issue
+ * slots.  An operand whose producer writes the three planes once -- mmvae_split_planes_f32, or a fused producer
+ * epilogue -- is moved global -> LDS by LDS-DMA with no vector work at all.
+ *
+ * (Exact while the residuals are normal numbers, |a| >= 2^-110; smaller values lose what does not fit the pieces' bit
+ * patterns, an absolute error below 2^-126 -- the GEMMs' in-kernel split is the same function.)
+ * Plane layout: planes[p][row][col], bf16 bit patterns, row-major like the fp32 matrix (`ld` and `plane_stride` in
+ * bf16 elements, both multiples of 8; base 16-byte aligned; 3 * plane_stride * 2 < 4 GiB).  Rows the consumer reads
+ * beyond the matrix (the zero slack rows of a weight-gradient GEMM whose K is padded to 32) must hold zeros.
+ *
+ * mmvae_gemm_planes_f32 = mmvae_gemm_f32 (sq_partials == NULL) or mmvae_gemm_f32_sq (sq_partials != NULL) with
+ * optional planes per operand.  Kernels exist for TN with both operands pre-split and for NT / NN with a pre-split A;
+ * an operand whose planes cannot be used (other combinations, shapes off the wave-specialised kernel: K % 32 != 0,
+ * rows-contiguous extent % 8 != 0, small outputs, MMVAE_GEMM_PRECISION_F32) is read from its fp32 form when that
+ * pointer is non-NULL, otherwise the call fails with MMVAE_ERR_ARG.  Results are bit-identical to mmvae_gemm_f32 on
+ * the fp32 operands (same products, same order).  mmvae_gemm_planes_supported: 1 when a launch of that shape with
+ * those operands pre-split would read them from planes.
+ * ------------------------------------------------------------------------------------------------------------ */
+int mmvae_split_planes_f32(int rows, int cols /* % 8 == 0 */, const float* src, int64_t ld_src, uint16_t* planes,
+                           int64_t ld, int64_t plane_stride, mmvae_stream_t stream);
+int mmvae_gemm_planes_f32(int layout, int M, int N, int K, float alpha, const float* A, int64_t lda, const uint16_t* Ap,
+                          int64_t ldap, int64_t a_plane_stride, const float* B, int64_t ldb, const uint16_t* Bp,
+                          int64_t ldbp, int64_t b_plane_stride, float* C, int64_t ldc, const float* bias, unsigned flags,
+                          int splitk, float* workspace, size_t workspace_bytes, float* sq_partials, int64_t sq_capacity,
+                          mmvae_stream_t stream);
+int mmvae_gemm_planes_supported(int layout, int M, int N, int K, int splitk, int a_planes, int b_planes);
+/* mmvae_decoder_recon_rows_colsum_f32 with planes on either side of it:
+ *   dP_planes != NULL  the epilogue also writes the three bf16 planes of dP (G % 8 == 0; dP itself may then be NULL):
+ *                      the weight-gradient and input-gradient GEMMs that consume dP read it pre-split.
+ *   hp != NULL         the decoder's hidden activations h pre-split (h may then be NULL): runs the wave-specialised
+ *                      kernel (256-row tiles; col_part keeps its [mmvae_recon_row_tiles(rows)][G] layout, one partial
+ *                      per 128-row half) when the shape fills the chip, otherwise falls back to the fp32 h if given.
+ *                      (Measured slower than the two-workgroup kernel on fp32 h at C2: its epilogue is done by 4 of
+ *                      the 8 waves; kept for shapes where the main loop dominates.)
+ * Same products in the same order as the fp32 form. */
+int mmvae_decoder_recon_planes_f32(int rows, int x_rows, int G, int H, const float* h, int64_t ldh, const uint16_t* hp,
+                                   int64_t ldhp, int64_t h_plane_stride, const float* W, int64_t ldw, const float* bias,
+                                   const float* x, int64_t ldx, float* xhat, int64_t ldxhat, float* dP, int64_t lddp,
+                                   uint16_t* dP_planes, int64_t lddpp, int64_t dp_plane_stride, float* se_part,
+                                   float* col_part, mmvae_stream_t stream);
+/* mmvae_fc_epilogue_fwd / _bwd that also write the three bf16 planes of their output (d_out / the final dz_out; N even):
+ * the layer tails that produce an operand of a G-wide weight-gradient GEMM (the decoder's last hidden activations, the
+ * gradient at the expert encoder's first layer) split it on the way out. */
+int mmvae_fc_epilogue_fwd_planes(int B, int N, const float* in, int64_t ld_in, int n_slabs, const float* bias,
+                                 const mmvae_bn_params* bn, int training, int relu, const uint8_t* keep_mask,
+                                 float dropout_p, float* z_out, float* a_out, float* d_out, int64_t ld_out,
+                                 float* save_mean, float* save_invstd, float* workspace, size_t workspace_bytes,
+                                 uint16_t* d_planes, int64_t ldp, int64_t plane_stride, mmvae_stream_t stream);
+/* mmvae_fc_epilogue_fwd with a piggy-backed pass: extra workgroups of its second launch split the unrelated fp32
+ * matrix sp_src [sp_rows, sp_cols] into its bf16 planes (as mmvae_split_planes_f32).  The engine splits its input
+ * batch this way beside the first layer's tail: as a launch of its own the pass sits on the critical path of the step. */
+int mmvae_fc_epilogue_fwd_split(int B, int N, const float* in, int64_t ld_in, int n_slabs, const float* bias,
+                                const mmvae_bn_params* bn, int training, int relu, const uint8_t* keep_mask,
+                                float dropout_p, float* z_out, float* a_out, float* d_out, int64_t ld_out,
+                                float* save_mean, float* save_invstd, float* workspace, size_t workspace_bytes,
+                                int sp_rows, int sp_cols, const float* sp_src, int64_t sp_ld_src, uint16_t* sp_planes,
+                                int64_t sp_ld, int64_t sp_plane_stride, mmvae_stream_t stream);
+int mmvae_fc_epilogue_bwd_planes(int B, int N, const float* din, int64_t ld_in, int n_slabs, const float* addend,
+                                 const float* addend_a, const float* row_scale, const uint8_t* keep_mask, float dropout_p,
+                                 int relu, const float* a_act, const float* z, const float* gamma, const float* save_mean,
+                                 const float* save_invstd, int has_bn, float* dz_out, int64_t ld_out, float* dbias,
+                                 float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes,
+                                 uint16_t* dz_planes, int64_t ldp, int64_t plane_stride, mmvae_stream_t stream);
 
 /* Grouped launch of independent small GEMMs (same math and layouts as mmvae_gemm_f32, exact-f32 MFMA, 64x64 tiles,
  * unsplit, alpha / bias / relu / accumulate epilogue): ONE grid covers the tiles of every job.  Used for the

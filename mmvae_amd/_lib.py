@@ -107,6 +107,29 @@ PROTOTYPES = {
     "mmvae_sum_parts_batch": (_i, [_i, _p, _l, _p]),
     "mmvae_gemm_sq_partials": (_i, [_i, _i, _i, _i, _i]),
     "mmvae_gemm_f32_sq": (_i, [_i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _u, _p, _l, _p]),
+    "mmvae_split_planes_f32": (_i, [_i, _i, _p, _l, _p, _l, _l, _p]),
+    "mmvae_gemm_planes_f32": (
+        _i,
+        [_i, _i, _i, _i, _f, _p, _l, _p, _l, _l, _p, _l, _p, _l, _l, _p, _l, _p, _u, _i, _p, _z, _p, _l, _p],
+    ),
+    "mmvae_gemm_planes_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "mmvae_decoder_recon_planes_f32": (
+        _i,
+        [_i, _i, _i, _i, _p, _l, _p, _l, _l, _p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _l, _l, _p, _p, _p],
+    ),
+    "mmvae_fc_epilogue_fwd_planes": (
+        _i,
+        [_i, _i, _p, _l, _i, _p, C.POINTER(BnParams), _i, _i, _p, _f, _p, _p, _p, _l, _p, _p, _p, _z, _p, _l, _l, _p],
+    ),
+    "mmvae_fc_epilogue_fwd_split": (
+        _i,
+        [_i, _i, _p, _l, _i, _p, C.POINTER(BnParams), _i, _i, _p, _f, _p, _p, _p, _l, _p, _p, _p, _z,
+         _i, _i, _p, _l, _p, _l, _l, _p],
+    ),
+    "mmvae_fc_epilogue_bwd_planes": (
+        _i,
+        [_i, _i, _p, _l, _i, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _i, _p, _l, _p, _p, _p, _p, _z, _p, _l, _l, _p],
+    ),
     "mmvae_csr_to_dense_f32": (_i, [_i, _i, _l, _p, _p, _p, _p, _l, _p]),
     "mmvae_csr_to_dense_i32_f32": (_i, [_i, _i, _l, _p, _p, _p, _p, _l, _p]),
     "mmvae_csr_spmm_wt_i32_f32": (_i, [_i, _i, _i, _l, _p, _p, _p, _p, _l, _p, _p, _l, _p]),

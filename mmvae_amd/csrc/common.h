@@ -48,3 +48,30 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
+
+// Exact three-way bf16 split of an fp32 value by truncation: a = p0 + p1 + p2, each piece an fp32 bit pattern whose low
+// 16 bits are zero (p0 = top 16 bits of a, p1 = top 16 bits of a - p0, p2 = a - p0 - p1: 3 x 8 = 24 significant bits).
+// The bf16x3 GEMMs (gemm_dev.h) multiply such pieces; producers that write pre-split planes use the same function.
+__device__ __forceinline__ void x3_split(float a, unsigned& p0, unsigned& p1, unsigned& p2) {
+    const unsigned u = __float_as_uint(a);
+    p0 = u & 0xFFFF0000u;
+    const float r1 = a - __uint_as_float(p0);
+    p1 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(p1);
+    p2 = __float_as_uint(r2);  // <= 8 significant bits left: already a bf16 value
+}
+
+// Column-per-lane kernels (lane = column c, c even on even lanes): the three bf16 pieces of v, packed with the right
+// neighbour's into one dword per plane and stored by the even lane at planes[p][r][c .. c + 1].  Both lanes of a pair
+// must be active (N even).
+__device__ __forceinline__ void store_planes_lanepair(unsigned short* __restrict__ P, int64_t ldp, int64_t pstride, int r,
+                                                      int c, float v, int lane) {
+    unsigned q[3];
+    x3_split(v, q[0], q[1], q[2]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const unsigned mine = q[p] >> 16;
+        const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+        if (!(lane & 1)) *reinterpret_cast<unsigned*>(P + p * pstride + (int64_t)r * ldp + c) = mine | (other << 16);
+    }
+}

@@ -42,7 +42,37 @@ struct FwdArgs {
     float* save_invstd;
     float* ws;  // [2][RC][N] per-chunk (mean, M2)
     int B, N, RC;
+    unsigned short* d_planes;  // optional: the three bf16 planes of d_out (pre-split operand of a bf16x3 GEMM)
+    int64_t ldp, pstride;
+    // optional piggy-backed pass (fc_fwd_apply): the workgroup rows beyond the layer's own grid (blockIdx.y >= RC) split
+    // an unrelated fp32 matrix [sp_rows, 8 * sp_groups] into its bf16 planes -- the engine's input batch, beside the
+    // first layer's tail, where a launch of its own would sit on the critical path of the step
+    const float* sp_src;
+    unsigned short* sp_planes;
+    int64_t sp_ld_src, sp_ld, sp_pstride;
+    int sp_rows, sp_groups;
 };
+
+__device__ __forceinline__ void split_rows_job(const FwdArgs& a, int wg, int nwg) {
+    const int64_t total = (int64_t)a.sp_rows * a.sp_groups;
+    for (int64_t idx = (int64_t)wg * CT + threadIdx.x; idx < total; idx += (int64_t)nwg * CT) {
+        const int row = (int)(idx / a.sp_groups), gq = (int)(idx - (int64_t)row * a.sp_groups);
+        const float* sp = a.sp_src + (int64_t)row * a.sp_ld_src + 8 * gq;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        unsigned q[8][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x3_split(v0[j], q[j][0], q[j][1], q[j][2]);
+            x3_split(v1[j], q[4 + j][0], q[4 + j][1], q[4 + j][2]);
+        }
+        unsigned short* dp = a.sp_planes + (int64_t)row * a.sp_ld + 8 * gq;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint4*>(dp + p * a.sp_pstride) =
+                make_uint4((q[0][p] >> 16) | q[1][p], (q[2][p] >> 16) | q[3][p], (q[4][p] >> 16) | q[5][p],
+                           (q[6][p] >> 16) | q[7][p]);
+    }
+}
 
 // Sum of `v` over the 4 waves for each of the 64 columns; result valid in every thread.  Fixed order.
 __device__ __forceinline__ float block_colsum(float v, float (*red)[CW], int w, int lane) {
@@ -124,6 +154,10 @@ __global__ __launch_bounds__(CT) void fc_fwd_stats_kernel(const FwdArgs a) {
 // Pass 2 (or the only pass without training BN): normalise / activate / drop this chunk's rows.
 template <bool HAS_BN>
 __global__ __launch_bounds__(CT) void fc_fwd_apply_kernel(const FwdArgs a) {
+    if ((int)blockIdx.y >= a.RC) {  // (block-uniform) the piggy-backed split job
+        split_rows_job(a, ((int)blockIdx.y - a.RC) * gridDim.x + blockIdx.x, ((int)gridDim.y - a.RC) * gridDim.x);
+        return;
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * CW + lane;
     const int chunk = blockIdx.y;
@@ -191,6 +225,7 @@ __global__ __launch_bounds__(CT) void fc_fwd_apply_kernel(const FwdArgs a) {
             float d = y;
             if (a.mask) d = a.mask[(int64_t)r * a.N + c] ? y * a.keep_scale : 0.f;
             a.d_out[o] = d;
+            if (a.d_planes) store_planes_lanepair(a.d_planes, a.ldp, a.pstride, r, c, d, lane);
         }
     }
 }
@@ -217,6 +252,8 @@ struct BwdArgs {
     float* dbeta;
     float* ws;  // [3][RC][N] per-chunk column sums: dy, dy*xhat, xhat
     int B, N, RC;
+    unsigned short* dz_planes;  // optional: the three bf16 planes of the final dz_out
+    int64_t ldp, pstride;
 };
 
 __device__ __forceinline__ float bwd_dy(const BwdArgs& a, int r, int c, float g) {
@@ -256,6 +293,7 @@ __global__ __launch_bounds__(CT) void fc_bwd_stats_kernel(const BwdArgs a) {
             const float dy = bwd_dy(a, r, c, gs[i]);
             const int64_t oo = (int64_t)r * a.ld_out + c;
             if (a.dz_out) a.dz_out[oo] = dy;
+            if (!HAS_BN && a.dz_planes) store_planes_lanepair(a.dz_planes, a.ldp, a.pstride, r, c, dy, lane);
             s1 += dy;
             if (HAS_BN) {
                 const float xh = (a.z[oo] - mean) * invstd;
@@ -309,7 +347,9 @@ __global__ __launch_bounds__(CT) void fc_bwd_apply_kernel(const BwdArgs a) {
         const int64_t oo = (int64_t)r * a.ld_out + c;
         const float dy = a.dz_out[oo];
         const float xh = (a.z[oo] - mean) * invstd;
-        a.dz_out[oo] = gam * invstd * (dy - m1 - xh * m2);
+        const float dz = gam * invstd * (dy - m1 - xh * m2);
+        a.dz_out[oo] = dz;
+        if (a.dz_planes) store_planes_lanepair(a.dz_planes, a.ldp, a.pstride, r, c, dz, lane);
     }
 }
 
@@ -375,11 +415,17 @@ extern "C" size_t mmvae_fc_workspace_bytes(int B, int N) {
     return (size_t)3 * (size_t)ceil_div_i(B, RPC) * (size_t)N * sizeof(float);
 }
 
-extern "C" int mmvae_fc_epilogue_fwd(int B, int N, const float* in, int64_t ld_in, int n_slabs, const float* bias,
-                                     const mmvae_bn_params* bn, int training, int relu, const uint8_t* keep_mask,
-                                     float dropout_p, float* z_out, float* a_out, float* d_out, int64_t ld_out,
-                                     float* save_mean, float* save_invstd, float* workspace, size_t workspace_bytes,
-                                     mmvae_stream_t stream) {
+static int fc_fwd_impl(int B, int N, const float* in, int64_t ld_in, int n_slabs, const float* bias,
+                       const mmvae_bn_params* bn, int training, int relu, const uint8_t* keep_mask, float dropout_p,
+                       float* z_out, float* a_out, float* d_out, int64_t ld_out, float* save_mean, float* save_invstd,
+                       float* workspace, size_t workspace_bytes, uint16_t* d_planes, int64_t ldp, int64_t pstride,
+                       mmvae_stream_t stream, int sp_rows = 0, int sp_cols = 0, const float* sp_src = nullptr,
+                       int64_t sp_ld_src = 0, uint16_t* sp_planes = nullptr, int64_t sp_ld = 0, int64_t sp_pstride = 0) {
+    if (d_planes && (!d_out || N % 2 != 0 || ldp < N || ldp % 2 != 0 || pstride < (int64_t)B * ldp)) return MMVAE_ERR_ARG;
+    if (sp_planes && (sp_rows <= 0 || sp_cols <= 0 || sp_cols % 8 != 0 || !sp_src || sp_ld_src < sp_cols || sp_ld < sp_cols ||
+                      sp_ld % 8 != 0 || sp_pstride % 8 != 0 || sp_pstride < (int64_t)sp_rows * sp_ld ||
+                      (reinterpret_cast<uintptr_t>(sp_planes) & 15u)))
+        return MMVAE_ERR_ARG;
     if (B <= 0 || N <= 0 || !in || n_slabs < 1 || ld_in < N || ld_out < N) return MMVAE_ERR_ARG;
     if (!a_out && !d_out) return MMVAE_ERR_ARG;
     if (keep_mask && (dropout_p < 0.f || dropout_p >= 1.f || !d_out)) return MMVAE_ERR_ARG;
@@ -416,26 +462,74 @@ extern "C" int mmvae_fc_epilogue_fwd(int B, int N, const float* in, int64_t ld_i
     a.B = B;
     a.N = N;
     a.RC = ceil_div_i(B, RPC);
+    a.d_planes = reinterpret_cast<unsigned short*>(d_planes);
+    a.ldp = ldp;
+    a.pstride = pstride;
     const dim3 grid(ceil_div_i(N, CW), a.RC);
+    dim3 grid_apply = grid;
+    if (sp_planes) {
+        a.sp_src = sp_src;
+        a.sp_planes = reinterpret_cast<unsigned short*>(sp_planes);
+        a.sp_ld_src = sp_ld_src;
+        a.sp_ld = sp_ld;
+        a.sp_pstride = sp_pstride;
+        a.sp_rows = sp_rows;
+        a.sp_groups = sp_cols / 8;
+        // ~3 workgroups per CU for the split job, as rows of the layer's own grid width
+        grid_apply.y = a.RC + ceil_div_i(768, (int)grid.x);
+    }
     hipStream_t s = (hipStream_t)stream;
     if (stats) {
         MMVAE_LAUNCH(fc_fwd_stats_kernel, grid, dim3(CT), 0, s, a);
         MMVAE_LAUNCH_CHECK();
     }
     if (bn)
-        MMVAE_LAUNCH(fc_fwd_apply_kernel<true>, grid, dim3(CT), 0, s, a);
+        MMVAE_LAUNCH(fc_fwd_apply_kernel<true>, grid_apply, dim3(CT), 0, s, a);
     else
-        MMVAE_LAUNCH(fc_fwd_apply_kernel<false>, grid, dim3(CT), 0, s, a);
+        MMVAE_LAUNCH(fc_fwd_apply_kernel<false>, grid_apply, dim3(CT), 0, s, a);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }
 
-extern "C" int mmvae_fc_epilogue_bwd(int B, int N, const float* din, int64_t ld_in, int n_slabs, const float* addend,
-                                     const float* addend_a, const float* row_scale, const uint8_t* keep_mask, float dropout_p, int relu,
-                                     const float* a_act, const float* z, const float* gamma, const float* save_mean,
-                                     const float* save_invstd, int has_bn, float* dz_out, int64_t ld_out, float* dbias,
-                                     float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes,
+extern "C" int mmvae_fc_epilogue_fwd(int B, int N, const float* in, int64_t ld_in, int n_slabs, const float* bias,
+                                     const mmvae_bn_params* bn, int training, int relu, const uint8_t* keep_mask,
+                                     float dropout_p, float* z_out, float* a_out, float* d_out, int64_t ld_out,
+                                     float* save_mean, float* save_invstd, float* workspace, size_t workspace_bytes,
                                      mmvae_stream_t stream) {
+    return fc_fwd_impl(B, N, in, ld_in, n_slabs, bias, bn, training, relu, keep_mask, dropout_p, z_out, a_out, d_out, ld_out,
+                       save_mean, save_invstd, workspace, workspace_bytes, nullptr, 0, 0, stream);
+}
+
+extern "C" int mmvae_fc_epilogue_fwd_planes(int B, int N, const float* in, int64_t ld_in, int n_slabs, const float* bias,
+                                            const mmvae_bn_params* bn, int training, int relu, const uint8_t* keep_mask,
+                                            float dropout_p, float* z_out, float* a_out, float* d_out, int64_t ld_out,
+                                            float* save_mean, float* save_invstd, float* workspace,
+                                            size_t workspace_bytes, uint16_t* d_planes, int64_t ldp, int64_t plane_stride,
+                                            mmvae_stream_t stream) {
+    return fc_fwd_impl(B, N, in, ld_in, n_slabs, bias, bn, training, relu, keep_mask, dropout_p, z_out, a_out, d_out, ld_out,
+                       save_mean, save_invstd, workspace, workspace_bytes, d_planes, ldp, plane_stride, stream);
+}
+
+extern "C" int mmvae_fc_epilogue_fwd_split(int B, int N, const float* in, int64_t ld_in, int n_slabs, const float* bias,
+                                           const mmvae_bn_params* bn, int training, int relu, const uint8_t* keep_mask,
+                                           float dropout_p, float* z_out, float* a_out, float* d_out, int64_t ld_out,
+                                           float* save_mean, float* save_invstd, float* workspace, size_t workspace_bytes,
+                                           int sp_rows, int sp_cols, const float* sp_src, int64_t sp_ld_src,
+                                           uint16_t* sp_planes, int64_t sp_ld, int64_t sp_plane_stride,
+                                           mmvae_stream_t stream) {
+    if (!sp_planes) return MMVAE_ERR_ARG;
+    return fc_fwd_impl(B, N, in, ld_in, n_slabs, bias, bn, training, relu, keep_mask, dropout_p, z_out, a_out, d_out, ld_out,
+                       save_mean, save_invstd, workspace, workspace_bytes, nullptr, 0, 0, stream, sp_rows, sp_cols, sp_src,
+                       sp_ld_src, sp_planes, sp_ld, sp_plane_stride);
+}
+
+static int fc_bwd_impl(int B, int N, const float* din, int64_t ld_in, int n_slabs, const float* addend,
+                       const float* addend_a, const float* row_scale, const uint8_t* keep_mask, float dropout_p, int relu,
+                       const float* a_act, const float* z, const float* gamma, const float* save_mean,
+                       const float* save_invstd, int has_bn, float* dz_out, int64_t ld_out, float* dbias, float* dgamma,
+                       float* dbeta, float* workspace, size_t workspace_bytes, uint16_t* dz_planes, int64_t ldp,
+                       int64_t pstride, mmvae_stream_t stream) {
+    if (dz_planes && (!dz_out || N % 2 != 0 || ldp < N || ldp % 2 != 0 || pstride < (int64_t)B * ldp)) return MMVAE_ERR_ARG;
     if (B <= 0 || N <= 0 || !din || n_slabs < 1 || ld_in < N || ld_out < N) return MMVAE_ERR_ARG;
     if (relu && !a_act) return MMVAE_ERR_ARG;
     if (keep_mask && (dropout_p < 0.f || dropout_p >= 1.f)) return MMVAE_ERR_ARG;
@@ -468,6 +562,9 @@ extern "C" int mmvae_fc_epilogue_bwd(int B, int N, const float* din, int64_t ld_
     a.B = B;
     a.N = N;
     a.RC = ceil_div_i(B, RPC);
+    a.dz_planes = reinterpret_cast<unsigned short*>(dz_planes);
+    a.ldp = ldp;
+    a.pstride = pstride;
     const dim3 grid(ceil_div_i(N, CW), a.RC);
     hipStream_t s = (hipStream_t)stream;
     if (has_bn) {
@@ -483,6 +580,30 @@ extern "C" int mmvae_fc_epilogue_bwd(int B, int N, const float* din, int64_t ld_
     }
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
+}
+
+extern "C" int mmvae_fc_epilogue_bwd(int B, int N, const float* din, int64_t ld_in, int n_slabs, const float* addend,
+                                     const float* addend_a, const float* row_scale, const uint8_t* keep_mask, float dropout_p, int relu,
+                                     const float* a_act, const float* z, const float* gamma, const float* save_mean,
+                                     const float* save_invstd, int has_bn, float* dz_out, int64_t ld_out, float* dbias,
+                                     float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes,
+                                     mmvae_stream_t stream) {
+    return fc_bwd_impl(B, N, din, ld_in, n_slabs, addend, addend_a, row_scale, keep_mask, dropout_p, relu, a_act, z, gamma,
+                       save_mean, save_invstd, has_bn, dz_out, ld_out, dbias, dgamma, dbeta, workspace, workspace_bytes,
+                       nullptr, 0, 0, stream);
+}
+
+extern "C" int mmvae_fc_epilogue_bwd_planes(int B, int N, const float* din, int64_t ld_in, int n_slabs,
+                                            const float* addend, const float* addend_a, const float* row_scale,
+                                            const uint8_t* keep_mask, float dropout_p, int relu, const float* a_act,
+                                            const float* z, const float* gamma, const float* save_mean,
+                                            const float* save_invstd, int has_bn, float* dz_out, int64_t ld_out,
+                                            float* dbias, float* dgamma, float* dbeta, float* workspace,
+                                            size_t workspace_bytes, uint16_t* dz_planes, int64_t ldp,
+                                            int64_t plane_stride, mmvae_stream_t stream) {
+    return fc_bwd_impl(B, N, din, ld_in, n_slabs, addend, addend_a, row_scale, keep_mask, dropout_p, relu, a_act, z, gamma,
+                       save_mean, save_invstd, has_bn, dz_out, ld_out, dbias, dgamma, dbeta, workspace, workspace_bytes,
+                       dz_planes, ldp, plane_stride, stream);
 }
 
 extern "C" int mmvae_layernorm_fwd(int B, int N, const float* x, int64_t ldx, float eps, float* y, int64_t ldy,

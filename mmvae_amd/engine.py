@@ -105,6 +105,26 @@ def _supported_block(block: FCBlock) -> bool:
     return True
 
 
+class _PlaneBuf:
+    """Three bf16 planes of an engine buffer [rows, cols] (int16 [3, rows + 32, cols]); the 32 slack rows of every plane
+    stay zero: a weight-gradient GEMM runs its K over them (kpad)."""
+
+    def __init__(self, eng: "StepEngine", name: str, rows: int, cols: int):
+        self.rows, self.cols, self.ld = rows, cols, cols
+        self.data = eng.buf(name, (3, rows + 32, cols), torch.int16)
+        self.pstride = (rows + 32) * cols
+
+    def ptr(self) -> int:
+        return self.data.data_ptr()
+
+    def args(self):
+        """(planes pointer, leading dimension, plane stride) as the C-ABI takes them"""
+        return self.data.data_ptr(), self.ld, self.pstride
+
+
+_NOPL = (None, 0, 0)
+
+
 class StepEngine:
     @staticmethod
     def try_build(model) -> Optional["StepEngine"]:
@@ -171,6 +191,11 @@ class StepEngine:
         self.cond_packed_exchange = os.environ.get("MMVAE_COND_PACKED_EXCHANGE", "1") != "0"  # 0: dense VAE arena
         self.fuse_norm_prepare = os.environ.get("MMVAE_FUSE_NORM_PREPARE", "1") != "0"  # norm pass + adam_prepare: one launch
         self.fuse_dp_colsum = os.environ.get("MMVAE_FUSE_DP_COLSUM", "1") != "0"  # decoder-bias gradient from the recon epilogue
+        # Operands of the G-wide GEMMs written once as bf16 planes by their producers (include/mmvae_hip.h, "Pre-split
+        # operands") instead of being split inside every GEMM tile that reads them; K = 1 training programs
+        self.planes = os.environ.get("MMVAE_PLANES", "1") != "0"
+        self.planes_enc = os.environ.get("MMVAE_PLANES_ENC", "1") != "0"  # x, dY -> the first layer's weight gradient
+        self.planes_dec = os.environ.get("MMVAE_PLANES_DEC", "0") != "0"  # dP, h -> the last layer's dW and dX
         if os.environ.get("MMVAE_SIDE_STREAM", "0") != "0":
             side_stream = True
         self.side_stream_asked = bool(side_stream)  # the caller / environment asked for it (not only the dW branch)
@@ -553,7 +578,7 @@ class _Plan:
         return sk.value
 
     def _fuse_sqnorm(self, layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, side_cap: int = 0,
-                     on_side: bool = True) -> bool:
+                     on_side: bool = True, planes=None) -> bool:
         """Unsplit weight-gradient GEMM straight into a gradient arena: let its epilogue also leave the partial sums of
         squares of what it stores (mmvae_gemm_f32_sq), so that the clip's norm pass does not read the 82 MB back.  Only
         without a gradient exchange: under data parallelism the norm is that of the REDUCED gradients."""
@@ -580,9 +605,16 @@ class _Plan:
         self._sq_cover.setdefault(id(opt), []).append((off, M * N))
         plan = self
 
+        ap, bp = (planes[0].args() if planes and planes[0] else _NOPL), (planes[1].args() if planes and planes[1] else _NOPL)
+
         def launch():
-            rc = plan.lib.mmvae_gemm_f32_sq(layout, M, N, K, alpha, _p(A), lda, _p(Bm), ldb, _p(Cm), ldc, _p(bias), flags | SLACK,
-                                            buf.data_ptr() + 4 * base, n_part, _s())
+            if planes:
+                rc = plan.lib.mmvae_gemm_planes_f32(layout, M, N, K, alpha, _p(A), lda, *ap, _p(Bm), ldb, *bp, _p(Cm), ldc,
+                                                    _p(bias), flags | SLACK, 1, None, 0, buf.data_ptr() + 4 * base, n_part,
+                                                    _s())
+            else:
+                rc = plan.lib.mmvae_gemm_f32_sq(layout, M, N, K, alpha, _p(A), lda, _p(Bm), ldb, _p(Cm), ldc, _p(bias),
+                                                flags | SLACK, buf.data_ptr() + 4 * base, n_part, _s())
             if rc != 0:
                 raise _lib.HipLibraryError(f"mmvae_gemm_f32_sq failed with code {rc} (layout {layout}, {M}x{N}x{K})")
 
@@ -655,7 +687,7 @@ class _Plan:
         self._emit(self.lib.mmvae_gemm_batch_f32, n, jobs_dev.data_ptr(), total.value)
         self._gemm_jobs = []
 
-    def gemm(self, layout, M, N, K, A, lda, Bm, ldb, Cm, ldc, bias=None, flags=0, alpha=1.0, side=False):
+    def gemm(self, layout, M, N, K, A, lda, Bm, ldb, Cm, ldc, bias=None, flags=0, alpha=1.0, side=False, planes=None):
         """Complete GEMM (internal split-K reduce through a workspace when the plan asks for it).  side=True runs it
         on the engine's side stream (weight gradients: off the backward critical path) with its own workspace."""
         if side and self.eng.batch_gemms and self._queue_gemm(layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags):
@@ -666,10 +698,10 @@ class _Plan:
             # pending reduction of the backward pass in ONE mmvae_sum_parts_batch launch (a reduce launch per GEMM is
             # ~5 us of pure launch cost)
             slabs = self.eng.buf(f"dwslabs.{self._next_defer_id()}", (sk, M, N))
-            self._emit_gemm(layout, M, N, K, 1.0, A, lda, Bm, ldb, slabs, N, None, RAW, sk, False)
+            self._emit_gemm(layout, M, N, K, 1.0, A, lda, Bm, ldb, slabs, N, None, RAW, sk, False, planes=planes)
             self._defer_sum(slabs, sk, M * N, M, N, N, Cm, ldc, alpha, flags & ACC)
             return
-        if side and sk == 1 and self._fuse_sqnorm(layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags):
+        if side and sk == 1 and self._fuse_sqnorm(layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, planes=planes):
             return
         nbytes = self.lib.mmvae_gemm_workspace_bytes(layout, M, N, K, sk)
         if side and self.use_side and M * N <= self.eng.side_max_elems:
@@ -678,10 +710,10 @@ class _Plan:
             if hit is None or hit[0] is not self.opt_exp:
                 self._side_foreign = True
             self._fork()
-            self._emit_gemm(layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, sk, "side")
+            self._emit_gemm(layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, sk, "side", planes=planes)
             return
         self._ws_bytes = max(self._ws_bytes, nbytes)
-        self._emit_gemm(layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, sk, True)
+        self._emit_gemm(layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, sk, True, planes=planes)
 
     def _edge(self, src, dst):
         """dst waits for everything enqueued so far on src (None = the current stream at run time): a graph edge under
@@ -696,6 +728,35 @@ class _Plan:
             d = dst if dst is not None else torch.cuda.current_stream()
             ev.record(s)
             d.wait_event(ev)
+
+        self._cur.append(call)
+
+    def _next_x_split_job(self, l: _LayerRef, rows: int):
+        """The next piece of the input batch's split for a layer whose tail is a column-kernel launch (fwd_layer's slab
+        path), or None."""
+        jobs = getattr(self, "_x_split_jobs", None)
+        if not jobs:
+            return None
+        p_drop = l.p if self.mode == "train" else 0.0
+        if l.bn is None and p_drop == 0 and self._plan_gemm(NT, rows, l.n_out, l.n_in) == 1:
+            return None  # this layer's tail is fused into its GEMM
+        return jobs.pop(0)
+
+    def _record_event(self, stream):
+        """Event recorded on `stream` (None = the main stream at run time) at this point of the program."""
+        ev = torch.cuda.Event()
+        self._events.append(ev)
+
+        def call():
+            ev.record(stream if stream is not None else torch.cuda.current_stream())
+
+        self._cur.append(call)
+        return ev
+
+    def _wait_event(self, ev, stream=None):
+        """`stream` (None = main) waits for an event of _record_event: one graph edge from that node only."""
+        def call():
+            (stream if stream is not None else torch.cuda.current_stream()).wait_event(ev)
 
         self._cur.append(call)
 
@@ -759,16 +820,19 @@ class _Plan:
                    max(int(j.rows) * int(j.cols) for j in self._sum_jobs))
         self._sum_jobs = []
 
-    def gemm_raw(self, layout, M, N, K, A, lda, Bm, ldb) -> int:
+    def gemm_raw(self, layout, M, N, K, A, lda, Bm, ldb, planes=None) -> int:
         """Raw split-K slabs into the shared slab buffer; returns the slab count."""
         sk = self._plan_gemm(layout, M, N, K)
         self._slab_floats = max(self._slab_floats, sk * M * N)
-        self._emit_gemm(layout, M, N, K, 1.0, A, lda, Bm, ldb, None, N, None, RAW, sk, False)
+        self._emit_gemm(layout, M, N, K, 1.0, A, lda, Bm, ldb, None, N, None, RAW, sk, False, planes=planes)
         return sk
 
-    def _emit_gemm(self, layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, sk, use_ws):
+    def _emit_gemm(self, layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, sk, use_ws, planes=None):
+        """planes: (A planes or None, B planes or None) -- pre-split forms of the operands (_PlaneBuf); the fp32 pointers
+        stay the library's fallback for shapes the planes kernels do not take."""
         plan = self
         tag, self._probe_next = self._probe_next, None
+        ap, bp = (planes[0].args() if planes and planes[0] else _NOPL), (planes[1].args() if planes and planes[1] else _NOPL)
 
         def launch():
             # measurement hook (bench.py's roofline leg): in an EAGER run with plan.probe set, the tagged GEMM is
@@ -787,8 +851,14 @@ class _Plan:
         def launch_gemm():
             ws = plan.ws_side if use_ws == "side" else plan.ws
             c_ptr = _p(Cm) if Cm is not None else plan.slab.data_ptr()
-            rc = plan.lib.mmvae_gemm_f32(layout, M, N, K, alpha, _p(A), lda, _p(Bm), ldb, c_ptr, ldc, _p(bias), flags | SLACK, sk,
-                                         ws.data_ptr() if use_ws else None, ws.numel() * 4 if use_ws else 0, _s())
+            if planes:
+                rc = plan.lib.mmvae_gemm_planes_f32(layout, M, N, K, alpha, _p(A), lda, *ap, _p(Bm), ldb, *bp, c_ptr, ldc,
+                                                    _p(bias), flags | SLACK, sk, ws.data_ptr() if use_ws else None,
+                                                    ws.numel() * 4 if use_ws else 0, None, 0, _s())
+            else:
+                rc = plan.lib.mmvae_gemm_f32(layout, M, N, K, alpha, _p(A), lda, _p(Bm), ldb, c_ptr, ldc, _p(bias),
+                                             flags | SLACK, sk, ws.data_ptr() if use_ws else None,
+                                             ws.numel() * 4 if use_ws else 0, _s())
             if rc != 0:
                 raise _lib.HipLibraryError(f"mmvae_gemm_f32 failed with code {rc} (layout {layout}, {M}x{N}x{K})")
 
@@ -804,7 +874,8 @@ class _Plan:
 
     # ---- one FCBlock layer forward: cur [rows, n_in] -> l.d
     def fwd_layer(self, tag: str, l: _LayerRef, cur: torch.Tensor, ld_cur: int, rows: int, training: bool = True,
-                  mask_tag: Optional[str] = None, mask_stream: Optional[int] = None):
+                  mask_tag: Optional[str] = None, mask_stream: Optional[int] = None, planes_out: Optional[_PlaneBuf] = None,
+                  after_gemm=None, inp_planes: Optional[_PlaneBuf] = None, split_job=None):
         """`mask_tag`: name of the keep-mask buffer when it must differ from the layer's other buffers (the two phases
         of an adversary share activations but draw fresh masks); `mask_stream`: its Philox stream id."""
         eng = self.eng
@@ -824,8 +895,12 @@ class _Plan:
         if l.bn is None and p_drop == 0 and sk == 1:
             self.gemm(NT, rows, l.n_out, l.n_in, cur, ld_cur, l.W, l.n_in, l.d, l.n_out, bias=l.b,
                       flags=RELU if l.relu else 0)
+            if planes_out is not None:  # no column kernel behind this GEMM: a split pass of its own
+                self._emit(self.lib.mmvae_split_planes_f32, rows, l.n_out, _p(l.d), l.n_out, *planes_out.args())
             return l.d
-        S = self.gemm_raw(NT, rows, l.n_out, l.n_in, cur, ld_cur, l.W, l.n_in)
+        S = self.gemm_raw(NT, rows, l.n_out, l.n_in, cur, ld_cur, l.W, l.n_in, planes=(inp_planes, None) if inp_planes else None)
+        if after_gemm is not None:
+            after_gemm()
         bnp = None
         if l.bn is not None:
             bn = l.bn
@@ -835,11 +910,16 @@ class _Plan:
         plan = self
 
         def call():
-            rc = plan.lib.mmvae_fc_epilogue_fwd(rows, l.n_out, plan.slab.data_ptr(), l.n_out, S, _p(l.b),
-                                                C.byref(bnp) if bnp is not None else None, int(training), int(l.relu),
-                                                _p(l.mask), p_drop, _p(l.z), _p(l.a), _p(l.d), l.n_out, _p(l.mean),
-                                                _p(l.invstd),
-                                                plan.fcws.data_ptr(), plan.fcws.numel() * 4, _s())
+            args = (rows, l.n_out, plan.slab.data_ptr(), l.n_out, S, _p(l.b),
+                    C.byref(bnp) if bnp is not None else None, int(training), int(l.relu),
+                    _p(l.mask), p_drop, _p(l.z), _p(l.a), _p(l.d), l.n_out, _p(l.mean), _p(l.invstd),
+                    plan.fcws.data_ptr(), plan.fcws.numel() * 4)
+            if split_job is not None:  # extra workgroups of the tail split an unrelated matrix (the input batch)
+                rc = plan.lib.mmvae_fc_epilogue_fwd_split(*args, *split_job, _s())
+            elif planes_out is not None:  # the layer tail also leaves the bf16 planes of its output
+                rc = plan.lib.mmvae_fc_epilogue_fwd_planes(*args, *planes_out.args(), _s())
+            else:
+                rc = plan.lib.mmvae_fc_epilogue_fwd(*args, _s())
             if rc != 0:
                 raise _lib.HipLibraryError(f"mmvae_fc_epilogue_fwd failed with code {rc}")
 
@@ -848,8 +928,11 @@ class _Plan:
 
     # ---- one layer backward.  din: tensor [rows, n_out] or None (= shared slab buffer holding S_in raw slabs)
     def bwd_layer(self, l: _LayerRef, din, S_in: int, addend=None, need_dx: str = "raw", dx_out=None, dx_flags=0,
-                  dx_alpha=1.0):
+                  dx_alpha=1.0, dz_planes: Optional[_PlaneBuf] = None, inp_planes: Optional[_PlaneBuf] = None):
+        """dz_planes / inp_planes: pre-split forms of this layer's output gradient (written by its column kernel) and of
+        its input -- both operands of its weight-gradient GEMM."""
         rows = l.rows
+        dw_planes = (dz_planes, inp_planes) if (dz_planes is not None and inp_planes is not None) else None
         plan = self
         relu_src = l.a if l.a is not None else l.d
         has_bn = l.bn is not None
@@ -862,11 +945,14 @@ class _Plan:
             din_ptr = _p(din) if din is not None else plan.slab.data_ptr()
             ws = own_ws if own_ws is not None else plan.fcws
             # `addend` is a gradient on the hidden representation = the activation BEFORE dropout: it bypasses the mask
-            rc = plan.lib.mmvae_fc_epilogue_bwd(
-                rows, l.n_out, din_ptr, l.n_out, S_in, None, _p(addend), None, _p(l.mask), l.p, int(l.relu),
-                _p(relu_src) if l.relu else None, _p(l.z), _p(l.bn.weight) if has_bn else None, _p(l.mean),
-                _p(l.invstd), int(has_bn), _p(l.dz), l.n_out, _p(l.gb) if own_ws is None else None,
-                _p(l.ggamma) if has_bn else None, _p(l.gbeta) if has_bn else None, ws.data_ptr(), ws.numel() * 4, _s())
+            args = (rows, l.n_out, din_ptr, l.n_out, S_in, None, _p(addend), None, _p(l.mask), l.p, int(l.relu),
+                    _p(relu_src) if l.relu else None, _p(l.z), _p(l.bn.weight) if has_bn else None, _p(l.mean),
+                    _p(l.invstd), int(has_bn), _p(l.dz), l.n_out, _p(l.gb) if own_ws is None else None,
+                    _p(l.ggamma) if has_bn else None, _p(l.gbeta) if has_bn else None, ws.data_ptr(), ws.numel() * 4)
+            if dw_planes is not None:
+                rc = plan.lib.mmvae_fc_epilogue_bwd_planes(*args, *dz_planes.args(), _s())
+            else:
+                rc = plan.lib.mmvae_fc_epilogue_bwd(*args, _s())
             if rc != 0:
                 raise _lib.HipLibraryError(f"mmvae_fc_epilogue_bwd failed with code {rc}")
 
@@ -878,9 +964,10 @@ class _Plan:
             # (side-branch mode) the first layer's chip-filling weight gradient is emitted behind the shared VAE's
             # optimiser: by then the decoder's weight gradient on the side branch has released its CUs
             self._deferred_dw = (TN, l.n_out, l.n_in, k_rows, l.dz, l.n_out, l.inp, l.ld_inp, l.gW, l.n_in)
+            self._deferred_dw_planes = dw_planes
             self._defer_next_dw = False
         else:
-            self.gemm(TN, l.n_out, l.n_in, k_rows, l.dz, l.n_out, l.inp, l.ld_inp, l.gW, l.n_in, side=True)
+            self.gemm(TN, l.n_out, l.n_in, k_rows, l.dz, l.n_out, l.inp, l.ld_inp, l.gW, l.n_in, side=True, planes=dw_planes)
         if need_dx == "raw":
             return self.gemm_raw(NN, rows, l.n_in, l.n_out, l.dz, l.n_out, l.W, l.n_in)
         if need_dx == "full":
@@ -1040,12 +1127,69 @@ class _Plan:
                             and eng.side_branches)
         self.use_side = bool(side_dw) or (eng.side_stream_asked and eng.side_stream is not None)
         loss_aside, early_calls = False, []
+        # ---- pre-split operands of the G-wide GEMMs (K = 1 training programs on the wave-specialised kernels): the
+        # decoder side (dP from the reconstruction epilogue, the last hidden activations from their layer tail) feeds
+        # dW = dP^T h and dX = dP W; the encoder side (the gradient at the first layer from its column kernel, x from a
+        # split pass) feeds dW = dY^T x.  The forward GEMM of the first layer keeps reading x as fp32: the split pass
+        # would sit in front of it (17 us for 8 us gained), while beside the forward chain it is free.
+        l0, lastl = self.enc_layers[0], self.dec_layers[-1]
+        pl_on = bool(eng.planes and train and K == 1 and not self.iwae and lib.mmvae_gemm_get_precision() == 1)
+        self.pl_dec = bool(pl_on and eng.planes_dec and G % 8 == 0 and lastl.n_in % 8 == 0 and len(self.dec_layers) >= 2
+                           and lib.mmvae_gemm_planes_supported(TN, G, lastl.n_in, self.kpad(R), 1, 1, 1)
+                           and lib.mmvae_gemm_planes_supported(NN, R, lastl.n_in, G, 0, 1, 0))
+        self.pl_enc = bool(pl_on and eng.planes_enc and l0.n_in % 8 == 0 and l0.n_out % 8 == 0 and l0.bn is not None
+                           and lib.mmvae_gemm_planes_supported(TN, l0.n_out, l0.n_in, self.kpad(B), 1, 1, 1))
+        self.xp = _PlaneBuf(eng, f"xp.{l0.n_in}", B, l0.n_in) if self.pl_enc else None
+        self.dYp = _PlaneBuf(eng, f"dYp.{l0.n_out}", B, l0.n_out) if self.pl_enc else None
+        self.hp = _PlaneBuf(eng, f"hp.{lastl.n_in}", R, lastl.n_in) if self.pl_dec else None
+        self.dPp = _PlaneBuf(eng, f"dPp.{G}", R, G) if self.pl_dec else None
+        self._x_split_ev = None
+        x_split_late = False
+        x_split_hook = None
+        if self.pl_enc:
+            split_x = len(self._cur)
+            self._emit(lib.mmvae_split_planes_f32, B, l0.n_in, _p(x), ldx, *self.xp.args())
+            x_calls = self._take(split_x)
+            xs_mode = os.environ.get("MMVAE_PLANES_XSPLIT", "tail")
+            if xs_mode == "fwd" and early_branch:
+                # on the side stream, forked BEHIND the first layer's GEMM: beside the latency-bound forward chain.
+                # (Forked at the head of the program it ran beside that GEMM and took its CUs: 57 us instead of 17.
+                # Measured un-profiled: any fork this early costs the captured program ~80 us -- the graph executor
+                # serialises the main chain behind it -- so this is not the default.)
+                def x_split_hook():
+                    self._fork()
+                    self._branch(eng.side_stream, x_calls)
+                    self._x_split_ev = self._record_event(eng.side_stream)
+            elif xs_mode == "branch" and side_dw:
+                # at the head of the existing side branch, ahead of the decoder's weight gradient (beside the start of
+                # the backward chain): no fork of its own -- but it delays that chain by ~30 us
+                self._x_split_side = x_calls
+            elif xs_mode == "tail":
+                # piggy-backed on the tail launches of the forward chain (extra workgroups of fc_fwd_apply), a fifth of
+                # the rows each: those launches are latency-bound (5-13 us with the memory system idle), 20 MB of
+                # streaming beside each is nearly free -- as one pass beside the first tail it cost 12 us, as a launch
+                # of its own 17-22 us on the critical path, forked onto a second stream ~80 us (graph executor)
+                n_jobs = int(os.environ.get("MMVAE_PLANES_XSPLIT_JOBS", "3"))
+                per = (B + n_jobs - 1) // n_jobs
+                xpp, xld, xps = self.xp.args()
+                self._x_split_jobs = [(min(per, B - r0), l0.n_in, _p(x) + 4 * r0 * ldx, ldx, xpp + 2 * r0 * xld, xld, xps)
+                                      for r0 in range(0, B, per)]
+            elif xs_mode == "head":
+                # at the head of the program, on the main stream: 17 us, and the first layer's forward GEMM reads the
+                # planes too (8 us back)
+                self._cur.extend(x_calls)
+                self._x_head = True
+            else:  # one stream: just ahead of its consumer (emitted there)
+                self._x_split_call = x_calls
+                x_split_late = True
         # ---- forward, encoder side
         cur, ld = x, ldx
         for i, l in enumerate(self.enc_layers):
             self._probe_next = "enc_l1_fwd" if i == 0 else None
             cur = self.fwd_layer(f"{self.eid}.enc{i}" if i < self.n_expert_enc else f"vae.enc{i}", l, cur, ld, B,
-                                 training=train, mask_stream=i)
+                                 training=train, mask_stream=i, after_gemm=x_split_hook if i == 0 else None,
+                                 inp_planes=self.xp if (i == 0 and getattr(self, "_x_head", False)) else None,
+                                 split_job=self._next_x_split_job(l, B))
             ld = l.n_out
         q, HV = cur, self.enc_layers[-1].n_out
         # ---- heads + reparameterisation
@@ -1073,8 +1217,14 @@ class _Plan:
             cur, ld = self.cond.emit_forward(self.z)
         for i, l in enumerate(self.dec_layers[:-1]):
             cur = self.fwd_layer(f"{self.eid}.dec{i}.K{K}", l, cur, ld, R, training=train,
-                                 mask_stream=len(self.enc_layers) + i)
+                                 mask_stream=len(self.enc_layers) + i,
+                                 planes_out=self.hp if (self.pl_dec and i == len(self.dec_layers) - 2) else None,
+                                 split_job=None if (self.pl_dec and i == len(self.dec_layers) - 2)
+                                 else self._next_x_split_job(l, R))
             ld = l.n_out
+        for job in getattr(self, "_x_split_jobs", []):  # tails the chain did not have: passes of their own
+            self._emit(lib.mmvae_split_planes_f32, *job)
+        self._x_split_jobs = []
         last = self.dec_layers[-1]
         fused_last = last.relu and last.bn is None and last.p == 0
         if not fused_last:
@@ -1091,8 +1241,14 @@ class _Plan:
             nrt = lib.mmvae_recon_row_tiles(R)
             self.dp_colpart = eng.buf(f"dP.colpart.{G}", (nrt, G))
             self._defer_sum(self.dp_colpart, nrt, G, 1, G, G, last.gb, G)
-        self._emit(lib.mmvae_decoder_recon_rows_colsum_f32, R, B, G, last.n_in, _p(cur), ld, _p(last.W), last.n_in,
-                   _p(last.b), _p(x), ldx, None, 0, _p(self.dP), G, _p(self.se_part), _p(self.dp_colpart))
+        if self.pl_dec:  # the epilogue that produces dP also leaves its bf16 planes (MMVAE_PLANES_KEEP_DP=1: and dP)
+            keep_dp = os.environ.get("MMVAE_PLANES_KEEP_DP", "0") != "0"
+            self._emit(lib.mmvae_decoder_recon_planes_f32, R, B, G, last.n_in, _p(cur), ld, None, 0, 0, _p(last.W),
+                       last.n_in, _p(last.b), _p(x), ldx, None, 0, _p(self.dP) if keep_dp else None, G, *self.dPp.args(),
+                       _p(self.se_part), _p(self.dp_colpart))
+        else:
+            self._emit(lib.mmvae_decoder_recon_rows_colsum_f32, R, B, G, last.n_in, _p(cur), ld, _p(last.W), last.n_in,
+                       _p(last.b), _p(x), ldx, None, 0, _p(self.dP), G, _p(self.se_part), _p(self.dp_colpart))
         self.recon_row = eng.buf("recon_row", (B,))
         if self.iwae:
             self.rows3 = eng.buf("iwae.rows3", (3, B))
@@ -1136,17 +1292,27 @@ class _Plan:
             self._emit_fc_bwd(R, G, self.dP, None, None, None, last.gb)
             if early_branch:  # the bias gradient (a pass over dP) is needed by the optimiser only
                 early_calls += self._take(start)
+        dx_pl = (self.dPp, None) if self.pl_dec else None
+        dw_pl = (self.dPp, self.hp) if self.pl_dec else None
         if side_dw:  # input gradient first (the chain waits for it), then the weight gradient on the side branch
-            S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
+            S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in, planes=dx_pl)
+            xs = getattr(self, "_x_split_side", None)
+            if xs:
+                self._fork()
+                self._branch(eng.side_stream, xs)
+                self._x_split_ev = self._record_event(eng.side_stream)
+                self._x_split_side = None
             if not self._fuse_sqnorm(TN, G, last.n_in, self.kpad(R), 1.0, self.dP, G, last.inp, last.ld_inp, last.gW,
-                                     last.n_in, None, 0, side_cap=side_dw):
-                self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True)
+                                     last.n_in, None, 0, side_cap=side_dw, planes=dw_pl):
+                self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True,
+                          planes=dw_pl)
             if early_branch:  # behind the weight gradient on its stream: one branch, in order (probe: DESIGN.md 5)
                 self._fork()  # (the weight gradient may have stayed on the main stream)
                 self._branch(eng.side_stream, early_calls)
         else:
-            self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True)
-            S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
+            self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True,
+                      planes=dw_pl)
+            S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in, planes=dx_pl)
         rest = self.dec_layers[:-1]
         for j in range(len(rest) - 1, -1, -1):
             l = rest[j]
@@ -1207,7 +1373,11 @@ class _Plan:
             addend = self.adv_grad_into.get(id(hid)) if l.return_hidden else None
             if j == 0 and side_dw:
                 self._defer_next_dw = True
-            S_next = self.bwd_layer(l, din, S, addend=addend, need_dx="raw" if j > 0 else "none")
+            if j == 0 and x_split_late:
+                self._cur.extend(self._x_split_call)
+            S_next = self.bwd_layer(l, din, S, addend=addend, need_dx="raw" if j > 0 else "none",
+                                    dz_planes=self.dYp if (j == 0 and self.pl_enc) else None,
+                                    inp_planes=self.xp if (j == 0 and self.pl_enc) else None)
             din, S = None, S_next
             if early and j == self.n_expert_enc:  # the last VAE layer is done: what remains is the expert's encoder
                 self._begin_exchange(self.opt_vae)
@@ -1238,12 +1408,18 @@ class _Plan:
             calls = self._take(start)
             self._fork()  # the branch depends on the chain up to here; its kernels are enqueued behind the GEMM
             layout, M, N, Kk, A, lda, Bm, ldb, Cm, ldc = dw
+            dwp = getattr(self, "_deferred_dw_planes", None)
+            if dwp is not None and self._x_split_ev is not None:
+                self._wait_event(self._x_split_ev)  # the planes of x come from the side stream
             if not self._fuse_sqnorm(layout, M, N, Kk, 1.0, A, lda, Bm, ldb, Cm, ldc, None, 0, side_cap=eng.side_dw2,
-                                     on_side=False):
-                self.gemm(*dw, side=True)
+                                     on_side=False, planes=dwp):
+                self.gemm(*dw, side=True, planes=dwp)
             self._branch(eng.side_stream, calls)
         elif dw is not None:
-            self.gemm(*dw, side=True)
+            dwp = getattr(self, "_deferred_dw_planes", None)
+            if dwp is not None and self._x_split_ev is not None:
+                self._wait_event(self._x_split_ev)
+            self.gemm(*dw, side=True, planes=dwp)
         if early:  # the expert's exchange + update leave the main stream: its norm is logged from the comm stream
             emit_log_copy()
         # in-order program: the log copy rides on the expert's Adam launch (its words -- losses, both norms -- are final

@@ -143,6 +143,89 @@ def gemm_sq(layout: int, a: torch.Tensor, b: torch.Tensor, *, out: Optional[torc
     return out, partials
 
 
+class Planes:
+    """The exact three-way bf16 split of an fp32 matrix [rows, cols] (include/mmvae_hip.h, "Pre-split operands"):
+    `data` is int16 [3, rows + slack_rows, ld]; the slack rows stay zero (a weight-gradient GEMM pads its K to 32)."""
+
+    def __init__(self, rows: int, cols: int, device, slack_rows: int = 32):
+        if cols % 8:
+            raise ValueError("Planes: cols must be a multiple of 8")
+        self.rows, self.cols, self.ld = rows, cols, cols
+        self.data = torch.zeros((3, rows + slack_rows, self.ld), dtype=torch.int16, device=device)
+        self.plane_stride = (rows + slack_rows) * self.ld
+
+    def ptr(self):
+        return self.data.data_ptr()
+
+    def to_float(self) -> torch.Tensor:
+        """p0 + p1 + p2 as fp32 (exactly the matrix that was split; tests)."""
+        planes = (self.data[:, : self.rows].to(torch.int32) << 16).view(torch.float32)
+        return (planes[0] + planes[1]) + planes[2]
+
+
+def split_planes(src: torch.Tensor, out: Optional[Planes] = None) -> Planes:
+    """mmvae_split_planes_f32: write the three bf16 planes of `src` [rows, cols] (cols % 8 == 0)."""
+    lib = _lib.load()
+    _chk(src, "src")
+    rows, cols, ld = _mat(src, "src")
+    if out is None:
+        out = Planes(rows, cols, src.device)
+    if (out.rows, out.cols) != (rows, cols):
+        raise ValueError("split_planes: shape mismatch")
+    _lib.check(lib.mmvae_split_planes_f32(rows, cols, _ptr(src), ld, out.ptr(), out.ld, out.plane_stride, _stream()),
+               "mmvae_split_planes_f32")
+    return out
+
+
+def gemm_planes(layout: int, a: Optional[torch.Tensor], b: Optional[torch.Tensor], *, a_planes: Optional[Planes] = None,
+                b_planes: Optional[Planes] = None, K: Optional[int] = None, out: Optional[torch.Tensor] = None,
+                accumulate: bool = False, splitk: int = 0, raw_slabs: bool = False, want_sq: bool = False):
+    """mmvae_gemm_planes_f32: gemm() / gemm_slabs() / gemm_sq() with optional pre-split operands (a / b may be None
+    when the planes are given).  K overrides the reduction length of a TN product (padded over the zero slack rows)."""
+    lib = _lib.load()
+
+    def dims(t, pl):
+        return (t.shape[0], t.shape[1]) if t is not None else (pl.rows, pl.cols)
+
+    (ar, ac), (br, bc) = dims(a, a_planes), dims(b, b_planes)
+    if layout == GEMM_NT:
+        M, Kk, N = ar, ac, br
+    elif layout == GEMM_NN:
+        M, Kk, N = ar, ac, bc
+    else:
+        Kk, M, N = ar, ac, bc
+    if K is not None:
+        Kk = K
+    dev = (a if a is not None else a_planes.data).device
+    if splitk == 0 and not want_sq:
+        _, splitk = gemm_plan(layout, M, N, Kk)
+    flags = (GEMM_ACCUMULATE if accumulate else 0) | (GEMM_RAW_SLABS if raw_slabs else 0)
+    if raw_slabs:
+        out = torch.empty((splitk, M, N), dtype=torch.float32, device=dev)
+        ldc, ws, nbytes = N, None, 0
+    else:
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=dev)
+        ldc = _mat(out, "out")[2]
+        nbytes = 0 if want_sq else lib.mmvae_gemm_workspace_bytes(layout, M, N, Kk, splitk)
+        ws = workspace(nbytes, dev) if nbytes else None
+    partials, n = None, 0
+    if want_sq:
+        n = lib.mmvae_gemm_sq_partials(layout, M, N, Kk, 0)
+        if n <= 0:
+            raise ValueError("gemm_planes: this shape is planned as a split-K launch")
+        partials = torch.empty(n, dtype=torch.float32, device=dev)
+    rc = lib.mmvae_gemm_planes_f32(
+        layout, M, N, Kk, 1.0,
+        _ptr(a), a.stride(0) if a is not None else 0, a_planes.ptr() if a_planes else None,
+        a_planes.ld if a_planes else 0, a_planes.plane_stride if a_planes else 0,
+        _ptr(b), b.stride(0) if b is not None else 0, b_planes.ptr() if b_planes else None,
+        b_planes.ld if b_planes else 0, b_planes.plane_stride if b_planes else 0,
+        _ptr(out), ldc, None, flags, splitk, _ptr(ws), nbytes, _ptr(partials), n, _stream())
+    _lib.check(rc, "mmvae_gemm_planes_f32")
+    return (out, partials) if want_sq else out
+
+
 def gemm_slabs(layout: int, a: torch.Tensor, b: torch.Tensor, splitk: int = 0) -> torch.Tensor:
     """Raw split-K partial products [S, M, N] (no epilogue), to be summed by fc_epilogue_fwd / _bwd."""
     lib = _lib.load()
@@ -185,8 +268,11 @@ def decoder_recon(
     dP: Optional[torch.Tensor] = None,
     se_part: Optional[torch.Tensor] = None,
     col_part: Optional[torch.Tensor] = None,
+    h_planes: Optional["Planes"] = None,
+    dP_planes: Optional["Planes"] = None,
 ):
     """Fused last decoder layer + squared error.  h [R,H] (R = K*B rows), W [G,H], x [B,G].
+    h_planes: the pre-split h (mmvae_decoder_recon_planes_f32; h stays the fallback).
     Returns (xhat [R,G] | None, dP [R,G] | None, se_part [tiles, R]).  col_part [recon_row_tiles(R), G] (optional):
     receives the column sums of dP per row tile (their sum over the tiles is the bias gradient when K = 1)."""
     lib = _lib.load()
@@ -207,6 +293,16 @@ def decoder_recon(
     lddp = _mat(dP, "dP")[2] if dP is not None else 0
     if col_part is not None and (tuple(col_part.shape) != (lib.mmvae_recon_row_tiles(R), G) or not col_part.is_contiguous()):
         raise ValueError(f"decoder_recon: col_part must be a contiguous [{lib.mmvae_recon_row_tiles(R)}, {G}] tensor")
+    if h_planes is not None or dP_planes is not None:
+        hp, dpp = h_planes, dP_planes
+        rc = lib.mmvae_decoder_recon_planes_f32(
+            R, B, G, H, _ptr(h), ldh, hp.ptr() if hp else None, hp.ld if hp else 0, hp.plane_stride if hp else 0,
+            _ptr(W), ldw, _ptr(bias), _ptr(x), ldx, _ptr(xhat), ldxh, _ptr(dP), lddp,
+            dpp.ptr() if dpp else None, dpp.ld if dpp else 0, dpp.plane_stride if dpp else 0,
+            _ptr(se_part), _ptr(col_part), _stream(),
+        )
+        _lib.check(rc, "mmvae_decoder_recon_planes_f32")
+        return xhat, dP, se_part
     rc = lib.mmvae_decoder_recon_rows_colsum_f32(
         R, B, G, H, _ptr(h), ldh, _ptr(W), ldw, _ptr(bias), _ptr(x), ldx, _ptr(xhat), ldxh, _ptr(dP), lddp,
         _ptr(se_part), _ptr(col_part), _stream(),
