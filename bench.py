@@ -44,6 +44,8 @@ def parse():
                                                    "step: that many workgroups holding that much LDS each spin on a side "
                                                    "stream for that long, started with every step (DESIGN.md section 7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity block (one step of the timed program "
+                                                             "against the oracle, ~2 s, outside the timed region)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline sample (all thread counts)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                     help="cpu: rehearsal of the launch / exchange / timing logic on the gloo backend with CPU plumbing "
@@ -89,26 +91,47 @@ def spawn_ranks(argv, n: int) -> int:
     return code
 
 
-# /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks (no sparsity)
+# /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks (no sparsity), HBM3E peak
 BF16_DENSE_TFLOPS = 2500.0
-PMC_FETCH_KIB, PMC_WRITE_KIB = 60332.6, 32768.0  # rocprofv3 --pmc passes of tools/roofline_kernel.py (see below)
 F32_MFMA_TFLOPS = 157.3
-# HBM bytes per launch of the roofline kernel, from the separate rocprofv3 --pmc passes summarised in
-# profiles/r2_pmc_roofline_kernel.csv: 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, in KiB.
-# Algorithmic bytes of the launch: 4 (B*G + 1024*G + B*1024) = 125.0 MB (operands once, the layer's output once); the
-# kernel writes 16 split-K slabs of that output (33.5 MB) for the layer tail to sum.
-HBM_TRAFFIC_PMC_BYTES = int((2 * PMC_FETCH_KIB + PMC_WRITE_KIB) * 1024)
+HBM_PEAK_TBS = 8.0
+# The dominant kernel family of the step: its five G-wide GEMMs (2 B G 1024 FLOP each, ~half of the critical path), by
+# the engine's probe tag; the substring identifies the kernel's row in profiles/*_pmc_family.csv (rocprofv3 --pmc passes
+# of tools/roofline_kernel.py, one counter group per run, summarised by tools/pmc_summary.py).
+FAMILY = [
+    ("enc_l1_fwd", "forward GEMM of the G-wide expert encoder layer (NT, split-K 16 raw slabs)", "gemm_x3w_kernel<0, 0, 256, 128"),
+    ("dec_l2_recon", "expert decoder's last layer + reconstruction loss epilogue (NT)", "gemm_x3_kernel<0, 0, 128, 160"),
+    ("dec_l2_dx", "input gradient of the decoder's last layer (NN, split-K 16 raw slabs)", "gemm_x3w_kernel<0, 1, 256, 128"),
+    ("dec_l2_dw", "weight gradient of the decoder's last layer (TN)", "gemm_x3w_kernel<1, 1, 160, 256"),
+    ("enc_l1_dw", "weight gradient of the encoder's first layer (TN)", "gemm_x3w_kernel<1, 1, 256, 160"),
+]
+PMC_FAMILY_FILE = os.path.join(ROOT, "profiles", "r3_pmc_family.csv")
 
 
-def time_dominant_kernel(model, step, first, steps=8):
-    """Roofline leg: the dominant kernel family of the step is its five G-wide GEMMs (2 B G 1024 FLOP each, half of the
-    step's critical path).  Measured on the first of them, the expert encoder's forward GEMM Y[B, 1024] = X[B, G] .
-    W^T (NT layout, fp32 in / fp32 out, 6 bf16 MFMAs per product, split-K 16 into raw slabs:
-    gemm_x3w_kernel<NT, 256x128>), INSIDE the step: `steps` more training steps are run eagerly (same launches in the
-    same order, not replayed from the graph) with a HIP event pair around that launch on its launch stream
-    (engine probe hook).  Launched alone the same kernel takes 115-127 us (cold clocks and caches,
-    tools/debug/leg_probe.py) against ~103 us where it actually runs.  Returns (median seconds per launch, algorithmic
-    FLOPs per launch = 2 M N K)."""
+def pmc_traffic():
+    """HBM bytes per launch of the family's kernels from the tracked PMC summary: 2 x FETCH_SIZE (gfx950 tallies 128-B
+    read requests at 64 B) + WRITE_SIZE, KiB -> bytes.  {kernel substring: bytes} ({} when the file is absent)."""
+    import csv
+
+    if not os.path.exists(PMC_FAMILY_FILE):
+        return {}
+    per = {}
+    with open(PMC_FAMILY_FILE) as f:
+        for row in csv.DictReader(f):
+            for _, _, sub in FAMILY:
+                if sub in row["kernel"] and row["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    per.setdefault(sub, {})[row["counter"]] = float(row["value_per_launch"])
+    return {sub: int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024) for sub, v in per.items() if len(v) == 2}
+
+
+def time_step_kernels(model, step, first, steps=8):
+    """Roofline leg: every G-wide GEMM of the step and the expert's Adam pass, measured INSIDE the step: `steps` more
+    training steps are run eagerly (same launches in the same order, not replayed from the graph) with a HIP event pair
+    around each probed launch on the stream it is launched on (engine probe hook, _Plan._probed; the pair includes one
+    event marker, 2-8 us on a busy stream -- reported as measured, so a figure never over-states its kernel).  A GEMM
+    whose grid the engine caps to share the chip with a branch (`cus`) is timed as it runs there.  Launched alone the
+    same kernels are slower (cold clocks and caches, tools/debug/leg_probe.py).  Returns {tag: (median seconds,
+    work per launch, meta)}."""
     eng = model._engine
     prev = os.environ.get("MMVAE_NO_GRAPH")
     os.environ["MMVAE_NO_GRAPH"] = "1"
@@ -126,14 +149,40 @@ def time_dominant_kernel(model, step, first, steps=8):
             os.environ.pop("MMVAE_NO_GRAPH", None)
         else:
             os.environ["MMVAE_NO_GRAPH"] = prev
-    pairs = probe.get("enc_l1_fwd", [])[2:]  # (event, event, flops, event) per launch; the first two steps warm up
-    if not pairs:
-        raise RuntimeError("roofline leg: the engine did not run the probed GEMM")
-    # e0 -> e1 brackets the launch and one event marker (e1 -> e2, an empty pair, shows what the marker costs: 2-8 us on
-    # a busy stream).  Reported as measured, marker included: the figure never over-states the kernel (subtracting the
-    # empty pair landed below the kernel's minimum in the rocprofv3 trace of the same run).
-    ts = sorted(e0.elapsed_time(e1) for e0, e1, _, e2 in pairs)
-    return ts[len(ts) // 2] * 1e-3, pairs[0][2]
+    meta = {}
+    for p in eng._plans.values():
+        meta.update(p.probe_meta)
+    out = {}
+    for tag, pairs in probe.items():
+        pairs = pairs[2:]  # (event, event, work, event) per launch; the first two steps warm up
+        if not pairs:
+            continue
+        ts = sorted(e0.elapsed_time(e1) for e0, e1, _, e2 in pairs)
+        out[tag] = (ts[len(ts) // 2] * 1e-3, pairs[0][2], meta.get(tag, {}))
+    if "enc_l1_fwd" not in out:
+        raise RuntimeError("roofline leg: the engine did not run the probed GEMMs")
+    return out
+
+
+def parity_block(model, step_args):
+    """One more step of the timed program (replayed graph, Philox noise, branches) against the oracle -- the checker,
+    outside the timed region (oracle/program_check.py; tests/test_bench_program_gpu.py holds 12 such steps to the same
+    tolerances)."""
+    from oracle import program_check as PC
+
+    x, meta, eid, i = step_args
+    t0 = time.perf_counter()
+    r = PC.check_step(model, eid, x, meta, i, strict=False)
+    tol = PC.TOL
+    ok = (max(r["loss"], r["recon_loss"], r["kl_loss"]) <= tol["loss"]
+          and max(r["grad_norm_vae"], r["grad_norm_expert"]) <= tol["grad_norm"] and r["grad"] <= tol["grad"]
+          and r["param"] <= (tol["param_cold"] if r["cold"] else tol["param"]))
+    return {"checked": "one step of the timed program (replayed hipGraph, device Philox noise, side branches) against "
+                       "oracle.train_step from the snapshotted pre-step state, at the noise and ReLU slopes the step took",
+            "pass": bool(ok), "tolerance": tol, "rel_err": {k: r[k] for k in ("loss", "recon_loss", "kl_loss", "grad_norm_vae",
+                                                                              "grad_norm_expert", "grad", "param")},
+            "relu_kinks": r["kinks"], "replayed_graph": r["replayed"], "forked_branches": r["forked"],
+            "seconds": round(time.perf_counter() - t0, 2)}
 
 
 def cpu_baseline(cfg, seconds):
@@ -350,11 +399,18 @@ def main():
         el = float(t)
     leg = None
     if on_gpu and a.mode == "train" and feed is None and getattr(model, "_engine", None) and not a.no_engine:
-        leg = time_dominant_kernel(model, step, n_setup + a.warmup + a.steps)  # every rank: the steps exchange gradients
+        leg = time_step_kernels(model, step, n_setup + a.warmup + a.steps)  # every rank: the steps exchange gradients
     if getattr(model, "_engine", None):
         model._flush_engine()
     loss = {k: float(v.detach() if torch.is_tensor(v) else v) for k, v in model.logged.items()
             if k.startswith(("loss/", "recon_loss/", "kl_loss/"))}
+    parity = None
+    if (leg is not None and world == 1 and rank == 0 and a.config == "c2" and a.input == "dense" and not a.genes
+            and not a.no_parity):
+        i_par = n_setup + a.warmup + a.steps + 8
+        eid_par = eids[i_par % len(eids)]
+        x_par, m_par = data[eid_par][(i_par // len(eids)) % n_res]
+        parity = parity_block(model, (x_par, m_par, eid_par, i_par))
 
     if rank == 0:
         G = max(cfg["experts"].values())
@@ -387,26 +443,54 @@ def main():
         if leg is not None:
             from mmvae_amd import _lib
 
-            tk, fl = leg
             x3 = _lib.load().mmvae_gemm_get_precision() == _lib.GEMM_PRECISION_BF16X3
             # bf16x3: every fp32 product costs 6 bf16 MFMA products, so the matrix-core ceiling for ALGORITHMIC fp32
             # flops is the dense bf16 peak / 6; the exact-f32 mode is bounded by the fp32 MFMA peak.
             peak = BF16_DENSE_TFLOPS / 6.0 if x3 else F32_MFMA_TFLOPS
-            out["roofline"] = {"bound": "mfma",
-                               "kernel": (("gemm_x3w_kernel<NT,256x128> (bf16x3 MFMA, 4 multiplier + 4 stager waves per CU)"
-                                           if os.environ.get("MMVAE_X3W", "1") != "0" else  # off under a gradient exchange
-                                           "gemm_x3_kernel<NT,128x128> (bf16x3 MFMA, 2 x 4 waves per CU)")
-                                          if x3 else "gemm_f32_kernel<NT> (f32 MFMA)")
-                                         + ": forward GEMM of the G-wide expert encoder layer, split-K 16",
-                               "achieved": fl / tk / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl / tk / (peak * 1e12),
-                               "traffic": HBM_TRAFFIC_PMC_BYTES, "algorithmic_bytes": 4 * (cfg["batch"] * 1024 + (cfg["batch"] + 1024)
-                                                                                               * max(cfg["experts"].values())),
-                               "us_per_launch": tk * 1e6, "flops_per_launch": fl,
-                               "measured": "median over 6 eagerly launched training steps behind the timed region of the HIP "
-                                           "event pair around this launch on its launch stream (one event marker included)",
-                               "peak_note": "dense bf16 MFMA peak 2500 / 6 MFMA products per fp32 product" if x3
-                                            else "dense fp32 MFMA peak",
-                               "frac_of_f32_mfma_peak": fl / tk / (F32_MFMA_TFLOPS * 1e12)}
+            traffic = pmc_traffic()
+            kernels, fl_sum, t_sum, tr_sum, tr_n = [], 0.0, 0.0, 0, 0
+            for tag, what, sub in FAMILY:
+                if tag not in leg:
+                    continue
+                tk, fl, meta = leg[tag]
+                fl_sum += fl
+                t_sum += tk
+                tr = traffic.get(sub)
+                if tr is not None:
+                    tr_sum += tr
+                    tr_n += 1
+                kernels.append({"name": tag, "what": what, "shape": meta.get("shape"), "us": tk * 1e6,
+                                "tflops": fl / tk / 1e12, "frac": fl / tk / (peak * 1e12),
+                                "cus": meta.get("cus") or 256, "operands": "pre-split bf16 planes (LDS-DMA)" if meta.get("planes")
+                                else "fp32, split in the kernel", "traffic": tr})
+            if "adam_expert" in leg:
+                tk, by, meta = leg["adam_expert"]
+                kernels.append({"name": "adam_expert", "what": "fused clip + Adam over the active expert's flat arenas",
+                                "shape": meta.get("shape"), "us": tk * 1e6, "bound": "hbm", "tb_per_s": by / tk / 1e12,
+                                "frac": by / tk / (HBM_PEAK_TBS * 1e12), "cus": 256})
+            step_tf = synthetic.flops_per_cell(G, K) * cells_per_s / world / 1e12
+            out["roofline"] = {
+                "bound": "mfma",
+                "kernel": ("the five G-wide GEMMs of the step, time-weighted (bf16x3 MFMA: 6 bf16 products per fp32 product)"
+                           if x3 else "the five G-wide GEMMs of the step, time-weighted (f32 MFMA)"),
+                "achieved": fl_sum / t_sum / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl_sum / t_sum / (peak * 1e12),
+                "traffic": int(tr_sum / tr_n) if tr_n else None,
+                "traffic_note": (f"mean HBM bytes per launch over {tr_n} of the family's kernels, 2 x FETCH_SIZE + WRITE_SIZE "
+                                 f"from {os.path.relpath(PMC_FAMILY_FILE, ROOT)} (separate rocprofv3 --pmc passes)"
+                                 if tr_n else "no tracked PMC summary found"),
+                "algorithmic_bytes": 4 * (cfg["batch"] * 1024 + (cfg["batch"] + 1024) * max(cfg["experts"].values())),
+                "us_per_launch": t_sum / max(len([k for k in kernels if k["name"] != "adam_expert"]), 1) * 1e6,
+                "flops_per_launch": leg["enc_l1_fwd"][1],
+                "kernels": kernels,
+                "whole_step": {"tflops": step_tf, "frac": step_tf / peak,
+                               "note": "algorithmic FLOPs of the whole step / step time against the same ceiling"},
+                "measured": "per kernel: median over 6 eagerly launched training steps behind the timed region of the HIP "
+                            "event pair around its launch on its launch stream (one event marker included); `cus` < 256: "
+                            "the grid is capped to share the chip with a branch of the program, timed as it runs there",
+                "peak_note": "dense bf16 MFMA peak 2500 / 6 MFMA products per fp32 product" if x3 else "dense fp32 MFMA peak",
+                "frac_of_f32_mfma_peak": fl_sum / t_sum / (F32_MFMA_TFLOPS * 1e12)}
+            if parity is not None:
+                out["parity"] = parity
         elif not on_gpu:
             out["rehearsal"] = "CPU plumbing over gloo: launch / exchange / timing logic only, not a measurement"
         if world == 1 and not a.no_cpu_baseline:

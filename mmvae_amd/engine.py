@@ -525,6 +525,7 @@ class _Plan:
         self.use_side = False           # this plan forks work onto the engine's side stream (set in _build)
         self._probe_next = None         # tag for the next emitted GEMM (measurement hook, see _emit_gemm)
         self.probe = None               # dict tag -> [(event, event, flops)] while an eager run is being measured
+        self.probe_meta: Dict[str, dict] = {}  # tag -> {work, kernel, cus, bound} of the probed launches (_probed)
         self._forked = False            # the program has branches on other streams
         self._events: List = []         # the fork / join events of the program (kept alive: see _edge)
         self._runs = 0
@@ -540,7 +541,8 @@ class _Plan:
         self._build()
 
     # ------------------------------------------------------------------------------------------- program building
-    def _emit(self, fn, *args):
+    def _emit(self, fn, *args, probe=None):
+        """probe: (tag, work) -- see _probed."""
         lib_fn = fn
 
         def call():
@@ -548,7 +550,31 @@ class _Plan:
             if rc != 0:
                 raise _lib.HipLibraryError(f"{lib_fn.__name__} failed with code {rc}")
 
-        self._cur.append(call)
+        self._cur.append(self._probed(probe[0], probe[1], call) if probe else call)
+
+    def _probed(self, tag, work, call, **meta):
+        """Measurement hook (bench.py's roofline leg): in an EAGER run with plan.probe set, `call` is bracketed by a
+        timing event pair on the stream it launches on (e0 -> e1; e1 -> e2 is an empty pair: what one event marker costs
+        there); never active under capture.  `work`: algorithmic FLOPs (or bytes) of the launch; `meta` (kernel name,
+        workgroup cap, bound) is kept in plan.probe_meta[tag]."""
+        if tag is None:
+            return call
+        plan = self
+        self.probe_meta[tag] = dict(meta, work=work)
+
+        def wrapped():
+            pr = plan.probe
+            if pr is None:
+                return call()
+            st = torch.cuda.current_stream()
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record(st)
+            call()
+            e1.record(st)
+            e2.record(st)
+            pr.setdefault(tag, []).append((e0, e1, work, e2))
+
+        return wrapped
 
     def _cut(self, marker):
         self._join()  # a captured segment may not end with work outstanding on the side branch
@@ -606,8 +632,9 @@ class _Plan:
         plan = self
 
         ap, bp = (planes[0].args() if planes and planes[0] else _NOPL), (planes[1].args() if planes and planes[1] else _NOPL)
+        tag, self._probe_next = self._probe_next, None
 
-        def launch():
+        def launch_gemm():
             if planes:
                 rc = plan.lib.mmvae_gemm_planes_f32(layout, M, N, K, alpha, _p(A), lda, *ap, _p(Bm), ldb, *bp, _p(Cm), ldc,
                                                     _p(bias), flags | SLACK, 1, None, 0, buf.data_ptr() + 4 * base, n_part,
@@ -617,6 +644,9 @@ class _Plan:
                                                 flags | SLACK, buf.data_ptr() + 4 * base, n_part, _s())
             if rc != 0:
                 raise _lib.HipLibraryError(f"mmvae_gemm_f32_sq failed with code {rc} (layout {layout}, {M}x{N}x{K})")
+
+        launch = self._probed(tag, 2.0 * M * N * K, launch_gemm, bound="mfma", cus=side_cap, planes=bool(planes),
+                              shape=f"{('NT', 'NN', 'TN')[layout]} {M}x{N}x{K}")
 
         if side_cap:  # persistent grid capped to `side_cap` workgroups: the CUs left over serve another branch
             side = eng.side_stream if on_side else None
@@ -834,20 +864,6 @@ class _Plan:
         tag, self._probe_next = self._probe_next, None
         ap, bp = (planes[0].args() if planes and planes[0] else _NOPL), (planes[1].args() if planes and planes[1] else _NOPL)
 
-        def launch():
-            # measurement hook (bench.py's roofline leg): in an EAGER run with plan.probe set, the tagged GEMM is
-            # bracketed by a timing event pair on its launch stream; never active under capture
-            pr = plan.probe
-            if tag is not None and pr is not None:
-                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-                e0.record(torch.cuda.current_stream())
-                launch_gemm()
-                e1.record(torch.cuda.current_stream())
-                e2.record(torch.cuda.current_stream())  # e1 -> e2: what one event marker itself costs on this stream
-                pr.setdefault(tag, []).append((e0, e1, 2.0 * M * N * K, e2))
-            else:
-                launch_gemm()
-
         def launch_gemm():
             ws = plan.ws_side if use_ws == "side" else plan.ws
             c_ptr = _p(Cm) if Cm is not None else plan.slab.data_ptr()
@@ -861,6 +877,9 @@ class _Plan:
                                              ws.numel() * 4 if use_ws else 0, _s())
             if rc != 0:
                 raise _lib.HipLibraryError(f"mmvae_gemm_f32 failed with code {rc} (layout {layout}, {M}x{N}x{K})")
+
+        launch = self._probed(tag, 2.0 * M * N * K, launch_gemm, bound="mfma", cus=0, planes=bool(planes),
+                              shape=f"{('NT', 'NN', 'TN')[layout]} {M}x{N}x{K}" + (f" split-K {sk}" if sk > 1 else ""))
 
         if use_ws == "side":
             side = self.eng.side_stream
@@ -967,7 +986,10 @@ class _Plan:
             self._deferred_dw_planes = dw_planes
             self._defer_next_dw = False
         else:
+            big_first = l is self.enc_layers[0] and 2.0 * l.n_out * l.n_in * k_rows >= 5e9
+            self._probe_next = "enc_l1_dw" if big_first else None
             self.gemm(TN, l.n_out, l.n_in, k_rows, l.dz, l.n_out, l.inp, l.ld_inp, l.gW, l.n_in, side=True, planes=dw_planes)
+            self._probe_next = None
         if need_dx == "raw":
             return self.gemm_raw(NN, rows, l.n_in, l.n_out, l.dz, l.n_out, l.W, l.n_in)
         if need_dx == "full":
@@ -1077,13 +1099,16 @@ class _Plan:
                 self._emit(self.lib.mmvae_grad_sqnorm, n, a.grad.data_ptr() + 4 * o, buf.data_ptr() + 4 * slot)
                 slot += k
             self._emit(self.lib.mmvae_adam_prepare, npart, _p(buf), max_norm, gs, b1, b2, _p(opt.state_dev), flags)
+        pr = ("adam_expert", 28.0 * a.numel) if opt is self.opt_exp else None  # bytes: p, g, m, v read; p, m, v written
         if step and tail_copy is not None:  # (n, src, dst): the step's logged scalars ride on this launch
             self._emit(self.lib.mmvae_adam_step_copy, a.numel, _p(a.data), _p(a.grad), _p(a.exp_avg), _p(a.exp_avg_sq),
                        _p(opt.state_dev), g["lr"], b1, b2, g["eps"], g["weight_decay"], gs, tail_copy[0],
-                       _p(tail_copy[1]), _p(tail_copy[2]))
+                       _p(tail_copy[1]), _p(tail_copy[2]), probe=pr)
         elif step:
             self._emit(self.lib.mmvae_adam_step, a.numel, _p(a.data), _p(a.grad), _p(a.exp_avg), _p(a.exp_avg_sq),
-                       _p(opt.state_dev), g["lr"], b1, b2, g["eps"], g["weight_decay"], gs)
+                       _p(opt.state_dev), g["lr"], b1, b2, g["eps"], g["weight_decay"], gs, probe=pr)
+        if step and pr:
+            self.probe_meta["adam_expert"].update(bound="hbm", cus=0, shape=f"{a.numel} parameters, 28 B each")
 
     def _begin_exchange(self, opt: HipAdam):
         """All gradients of `opt` are final here: start their all-reduce on the small-message stream."""
@@ -1185,7 +1210,7 @@ class _Plan:
         # ---- forward, encoder side
         cur, ld = x, ldx
         for i, l in enumerate(self.enc_layers):
-            self._probe_next = "enc_l1_fwd" if i == 0 else None
+            self._probe_next = "enc_l1_fwd" if (i == 0 and big) else None
             cur = self.fwd_layer(f"{self.eid}.enc{i}" if i < self.n_expert_enc else f"vae.enc{i}", l, cur, ld, B,
                                  training=train, mask_stream=i, after_gemm=x_split_hook if i == 0 else None,
                                  inp_planes=self.xp if (i == 0 and getattr(self, "_x_head", False)) else None,
@@ -1245,10 +1270,13 @@ class _Plan:
             keep_dp = os.environ.get("MMVAE_PLANES_KEEP_DP", "0") != "0"
             self._emit(lib.mmvae_decoder_recon_planes_f32, R, B, G, last.n_in, _p(cur), ld, None, 0, 0, _p(last.W),
                        last.n_in, _p(last.b), _p(x), ldx, None, 0, _p(self.dP) if keep_dp else None, G, *self.dPp.args(),
-                       _p(self.se_part), _p(self.dp_colpart))
+                       _p(self.se_part), _p(self.dp_colpart), probe=("dec_l2_recon", 2.0 * R * G * last.n_in))
         else:
             self._emit(lib.mmvae_decoder_recon_rows_colsum_f32, R, B, G, last.n_in, _p(cur), ld, _p(last.W), last.n_in,
-                       _p(last.b), _p(x), ldx, None, 0, _p(self.dP), G, _p(self.se_part), _p(self.dp_colpart))
+                       _p(last.b), _p(x), ldx, None, 0, _p(self.dP), G, _p(self.se_part), _p(self.dp_colpart),
+                       probe=("dec_l2_recon", 2.0 * R * G * last.n_in))
+        self.probe_meta["dec_l2_recon"].update(bound="mfma", cus=0, planes=bool(self.pl_dec),
+                                               shape=f"NT {R}x{G}x{last.n_in} + reconstruction epilogue")
         self.recon_row = eng.buf("recon_row", (B,))
         if self.iwae:
             self.rows3 = eng.buf("iwae.rows3", (3, B))
@@ -1295,6 +1323,7 @@ class _Plan:
         dx_pl = (self.dPp, None) if self.pl_dec else None
         dw_pl = (self.dPp, self.hp) if self.pl_dec else None
         if side_dw:  # input gradient first (the chain waits for it), then the weight gradient on the side branch
+            self._probe_next = "dec_l2_dx"
             S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in, planes=dx_pl)
             xs = getattr(self, "_x_split_side", None)
             if xs:
@@ -1302,17 +1331,22 @@ class _Plan:
                 self._branch(eng.side_stream, xs)
                 self._x_split_ev = self._record_event(eng.side_stream)
                 self._x_split_side = None
+            self._probe_next = "dec_l2_dw"
             if not self._fuse_sqnorm(TN, G, last.n_in, self.kpad(R), 1.0, self.dP, G, last.inp, last.ld_inp, last.gW,
                                      last.n_in, None, 0, side_cap=side_dw, planes=dw_pl):
                 self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True,
                           planes=dw_pl)
+            self._probe_next = None
             if early_branch:  # behind the weight gradient on its stream: one branch, in order (probe: DESIGN.md 5)
                 self._fork()  # (the weight gradient may have stayed on the main stream)
                 self._branch(eng.side_stream, early_calls)
         else:
+            self._probe_next = "dec_l2_dw" if big else None
             self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True,
                       planes=dw_pl)
+            self._probe_next = "dec_l2_dx" if big else None
             S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in, planes=dx_pl)
+            self._probe_next = None
         rest = self.dec_layers[:-1]
         for j in range(len(rest) - 1, -1, -1):
             l = rest[j]
@@ -1411,15 +1445,19 @@ class _Plan:
             dwp = getattr(self, "_deferred_dw_planes", None)
             if dwp is not None and self._x_split_ev is not None:
                 self._wait_event(self._x_split_ev)  # the planes of x come from the side stream
+            self._probe_next = "enc_l1_dw"
             if not self._fuse_sqnorm(layout, M, N, Kk, 1.0, A, lda, Bm, ldb, Cm, ldc, None, 0, side_cap=eng.side_dw2,
                                      on_side=False, planes=dwp):
                 self.gemm(*dw, side=True, planes=dwp)
+            self._probe_next = None
             self._branch(eng.side_stream, calls)
         elif dw is not None:
             dwp = getattr(self, "_deferred_dw_planes", None)
             if dwp is not None and self._x_split_ev is not None:
                 self._wait_event(self._x_split_ev)
+            self._probe_next = "enc_l1_dw" if big else None
             self.gemm(*dw, side=True, planes=dwp)
+            self._probe_next = None
         if early:  # the expert's exchange + update leave the main stream: its norm is logged from the comm stream
             emit_log_copy()
         # in-order program: the log copy rides on the expert's Adam launch (its words -- losses, both norms -- are final

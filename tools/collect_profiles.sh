@@ -15,11 +15,11 @@ db=$(find gpurun_out/prof_${tag}_db -name "*.db" | head -1)
 python3 tools/timeline.py $db > gpurun_out/${tag}_step_timeline.txt
 python3 tools/kernel_rooflines.py $db $steps > gpurun_out/${tag}_kernel_rooflines.csv
 rm -rf gpurun_out/prof_${tag}_db
-for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_LDS"; do
   name=$(echo $pmc | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d gpurun_out/pmc_${tag}_$name -o p -- python3 tools/roofline_kernel.py > /dev/null 2>> gpurun_out/${tag}_bench.err || exit 1
 done
-python3 tools/pmc_summary.py $tag > gpurun_out/${tag}_pmc_roofline_kernel.csv
+python3 tools/pmc_summary.py $tag > gpurun_out/${tag}_pmc_family.csv
 cut -c1-300 gpurun_out/${tag}_bench_line.json
 tail -3 gpurun_out/${tag}_step_timeline.txt
-cat gpurun_out/${tag}_pmc_roofline_kernel.csv
+cat gpurun_out/${tag}_pmc_family.csv

@@ -13,6 +13,9 @@ notes = {
     "WRITE_SIZE": "KiB; exact for 16-B/lane stores",
     "SQ_VALU_MFMA_BUSY_CYCLES": "cycles summed over the SIMDs that report; / (GRBM_GUI_ACTIVE x 4 SIMD x 256 CU) = MFMA busy fraction",
     "GRBM_GUI_ACTIVE": "GPU clock cycles of the launch",
+    "SQ_INSTS_VALU": "vector ALU instructions (wave-level) of the launch",
+    "SQ_INSTS_LDS": "LDS instructions (wave-level) of the launch",
+    "SQ_INSTS_VMEM_RD": "vector memory read instructions (wave-level) of the launch",
 }
 for d in sorted(glob.glob(f"gpurun_out/pmc_{tag}_*")):
     files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
@@ -26,6 +29,6 @@ for d in sorted(glob.glob(f"gpurun_out/pmc_{tag}_*")):
         gemm = {k: v for k, v in kernels.items() if "gemm_x3" in k or "gemm_f32" in k}
         if not gemm:
             continue
-        k = max(gemm, key=lambda n: len(gemm[n]))
-        v = gemm[k]
-        print(f'{d.split("/")[-1]},"{k}",{counter},{len(v)},{sum(v) / len(v):.1f},"{notes.get(counter, "")}"')
+        for k in sorted(gemm, key=lambda n: -len(gemm[n])):  # every GEMM kernel of the pass (the family of five)
+            v = gemm[k]
+            print(f'{d.split("/")[-1]},"{k}",{counter},{len(v)},{sum(v) / len(v):.1f},"{notes.get(counter, "")}"')

@@ -1,11 +1,12 @@
-"""Launches the roofline kernel of bench.py (the forward GEMM of the G-wide expert encoder layer; `dw`: the TN
-weight-gradient GEMM) a few times, for
-rocprofv3 --pmc passes:   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out -- python3 tools/roofline_kernel.py"""
+"""Launches the five G-wide GEMMs of the C2 step in the operand forms the engine uses (the expert encoder's first
+layer: forward, weight gradient from pre-split planes; the decoder's last layer: fused forward + reconstruction, input
+gradient, weight gradient) a few times each, for rocprofv3 --pmc passes (one counter group per run):
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out -o p -- python3 tools/roofline_kernel.py
+usage: roofline_kernel.py [family | fwd | dw | dw_planes]"""
+import os
 import sys
 
 import torch
-
-import os
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mmvae_amd import ops, synthetic  # noqa: E402
@@ -14,15 +15,33 @@ cfg = synthetic.CONFIGS["c2"]
 B, G, H1 = cfg["batch"], max(cfg["experts"].values()), 1024
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(1)
-X = torch.randn(B, G, device=dev, generator=g)
-W = torch.randn(H1, G, device=dev, generator=g)
-dY = torch.randn(B, H1, device=dev, generator=g)
-dW = torch.empty(H1, G, device=dev)
-which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+r = lambda *s: torch.randn(*s, device=dev, generator=g)
+
+
+def padded(t):  # engine-style buffer: 32 zero slack rows behind the matrix
+    full = torch.zeros(t.shape[0] + 32, t.shape[1], device=dev)
+    full[: t.shape[0]] = t
+    return full[: t.shape[0]]
+
+
+X = padded(synthetic.synthetic_counts(B, G, seed=1234, device=dev))  # the bench's input distribution (~90 % zeros)
+W1, W4, b4 = r(H1, G) * 0.03, r(G, H1) * 0.03, r(G) * 0.1
+dY, h = padded(r(B, H1)), padded(torch.relu(r(B, H1)))
+dP = padded(r(B, G) * (torch.rand(B, G, device=dev, generator=g) < 0.5))
+dW1, dW4 = torch.empty(H1, G, device=dev), torch.empty(G, H1, device=dev)
+sep = torch.empty(ops.recon_tiles(G), B, device=dev)
+Xp, dYp = ops.split_planes(X), ops.split_planes(dY)
+which = sys.argv[1] if len(sys.argv) > 1 else "family"
 for _ in range(8):
-    if which == "fwd":   # bench.py's roofline kernel: Y[B, 1024] = X . W^T as 16 raw split-K slabs
-        ops.gemm_slabs(ops.GEMM_NT, X, W)
-    else:                # the weight gradient dW[1024, G] = dY^T . X (round 1's roofline kernel)
-        ops.gemm(ops.GEMM_TN, dY, X, out=dW, splitk=1)
+    if which in ("family", "fwd"):  # Y[B, 1024] = X . W1^T as 16 raw split-K slabs
+        ops.gemm_slabs(ops.GEMM_NT, X, W1)
+    if which == "family":
+        ops.decoder_recon(h, W4, b4, X, want_xhat=False, dP=dP.clone(), se_part=sep)  # fused last layer + recon
+        ops.gemm_slabs(ops.GEMM_NN, dP, W4)  # dX[B, 1024] = dP . W4
+        ops.gemm_planes(ops.GEMM_TN, dP, h, out=dW4, want_sq=True)  # dW4[G, 1024] = dP^T . h  (fp32 operands)
+    if which in ("family", "dw_planes"):  # dW1[1024, G] = dY^T . X from pre-split planes (LDS-DMA stagers)
+        ops.gemm_planes(ops.GEMM_TN, None, None, a_planes=dYp, b_planes=Xp, out=dW1, want_sq=True)
+    if which == "dw":  # the same product with the in-kernel split (round 2's form)
+        ops.gemm_planes(ops.GEMM_TN, dY, X, out=dW1, want_sq=True)
 torch.cuda.synchronize()
-print("algorithmic bytes per launch:", 4 * (B * H1 + B * G + H1 * G))
+print("algorithmic bytes per launch (forward GEMM):", 4 * (B * H1 + B * G + H1 * G))
