@@ -87,6 +87,11 @@ int mmvae_gemm_set_precision(int mode);
  * CUs to kernels of another stream: the engine runs a weight-gradient GEMM that way beside the latency-bound backward
  * chain of the core layers.  Results do not depend on the cap. */
 int mmvae_gemm_set_workgroup_cap(int max_workgroups);
+/* Kernel selection for the chip-filling bf16x3 GEMMs: 1 = the wave-specialised persistent kernel (one 512-thread
+ * workgroup per CU), 0 = the 2 x 4-wave kernels, -1 = follow the environment (MMVAE_X3W, default on).  Process-wide
+ * launch state like the precision switch; results do not depend on it.  mmvae_gemm_get_x3w: what a launch would take. */
+int mmvae_gemm_set_x3w(int mode);
+int mmvae_gemm_get_x3w(void);
 int mmvae_gemm_get_precision(void);
 
 /* Library heuristic: picks the block tile (128 or 64; the bf16x3 path may widen a 128 tile to 128x160 / 160x128 at

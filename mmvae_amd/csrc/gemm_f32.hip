@@ -681,9 +681,13 @@ int launch_gemm_x3(int tile_id, const GemmArgs& g0, int nwork, hipStream_t s) {
     return MMVAE_OK;
 }
 
-// The wave-specialised kernel is taken where its tiles fill the chip; MMVAE_X3W=0 keeps the 2 x 4-wave kernel (read at
-// every launch: tests and A/B runs toggle it).  Interleaved A/B of the C2 step on one box: 1.130 against 1.150 ms.
+// The wave-specialised kernel is taken where its tiles fill the chip.  Host-side launch state like the precision switch:
+// -1 = follow the environment (MMVAE_X3W=0 keeps the 2 x 4-wave kernel; read at every launch: tests and A/B runs toggle
+// it), 0 / 1 = set by mmvae_gemm_set_x3w (the engine switches it off under a gradient exchange).  Interleaved A/B of the
+// C2 step on one box: 1.130 against 1.150 ms.
+int g_x3w = -1;
 bool x3w_enabled() {
+    if (g_x3w >= 0) return g_x3w != 0;
     const char* e = getenv("MMVAE_X3W");
     return !(e && e[0] == '0');
 }
@@ -1187,6 +1191,14 @@ extern "C" int mmvae_gemm_set_precision(int mode) {
 }
 
 extern "C" int mmvae_gemm_get_precision(void) { return g_precision; }
+
+extern "C" int mmvae_gemm_set_x3w(int mode) {
+    if (mode < -1 || mode > 1) return MMVAE_ERR_ARG;
+    g_x3w = mode;
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_gemm_get_x3w(void) { return x3w_enabled() ? 1 : 0; }
 
 extern "C" int mmvae_gemm_set_workgroup_cap(int max_workgroups) {
     if (max_workgroups < 0) return MMVAE_ERR_ARG;

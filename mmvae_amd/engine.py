@@ -211,6 +211,7 @@ class StepEngine:
         # VAE optimiser) on a second branch stream
         self.side_dw2 = int(os.environ.get("MMVAE_SIDE_DW2", "185"))
         self.side_branches = os.environ.get("MMVAE_SIDE_BRANCHES", "1") != "0"
+        self.side_dw_any = os.environ.get("MMVAE_SIDE_DW_ANY", "0") != "0"  # fork outside the measured geometry too
         self.side_max_rows = int(os.environ.get("MMVAE_SIDE_MAX_ROWS", "640"))  # see _Plan._build
         if self.side_dw:
             side_stream = True
@@ -250,8 +251,10 @@ class StepEngine:
         # collective's workgroups holding CUs beside it (the previous step's all-reduce under data parallelism) would
         # delay whole workgroups by a round.  Under a gradient exchange the 2 x 4-wave kernel (measured sensitivity:
         # DESIGN.md section 7) is kept unless the caller chose explicitly.
-        if mdist.collectives_active() and "MMVAE_X3W" not in os.environ:
-            os.environ["MMVAE_X3W"] = "0"
+        # (library launch state, set and restored here -- not the process environment: a later single-rank engine of
+        # the same process gets the persistent kernel back)
+        if "MMVAE_X3W" not in os.environ:
+            self.lib.mmvae_gemm_set_x3w(0 if mdist.collectives_active() else -1)
         if self.overlap and self.comm_stream is None:
             self.comm_stream = torch.cuda.Stream(device=self.device)
             self.small_stream = torch.cuda.Stream(device=self.device)
@@ -271,6 +274,16 @@ class StepEngine:
     def _check_signature(self) -> None:
         sig = self._signature()
         if sig != self._sig:
+            # A captured program freezes the optimiser's hyper-parameters: a per-step schedule (learning-rate warm-up)
+            # rebuilds and re-captures every step -- correct, but milliseconds instead of one replay.  Say so once.
+            self._sig_changes = getattr(self, "_sig_changes", 0) + 1
+            if self._sig_changes == 3 and not getattr(self, "_sig_warned", False):
+                import warnings
+
+                self._sig_warned = True
+                warnings.warn("mmvae_amd.engine: optimiser settings changed on several training steps; every change drops "
+                              "the captured step programs and re-captures them (a learning-rate schedule stepping per "
+                              "batch costs milliseconds per step) -- change them per epoch, or set use_engine=False")
             self.flush()
             torch.cuda.synchronize(self.device)
             for k, p in self._plans.items():
@@ -1146,11 +1159,21 @@ class _Plan:
         # dependent; only ever seen with the tests' toy shapes, whose whole step is ~100 us -- tools/debug/seg_hunt.sh).
         # A G-wide weight gradient of >= 5 GFLOP puts the first fork hundreds of microseconds into the replay.
         big = 2.0 * G * self.dec_layers[-1].n_in * R >= 5e9
+        # The forked program is the default only for the geometry its caps were measured on (C2: a G-wide weight
+        # gradient of ~21 GFLOP, 512 rows: within +-25 %), where it has run > 10^4 replays without a fault; any other
+        # shape stays on one stream unless MMVAE_SIDE_DW_ANY=1 asks for it (the hipGraphLaunch hazard has no
+        # root cause yet, and a crashed replay cannot be recovered in-process).
+        dw_flops = 2.0 * G * self.dec_layers[-1].n_in * R
+        measured = 0.75 * 2.1e10 <= dw_flops <= 1.25 * 2.1e10
         side_dw = eng.side_dw if (train and eng.side_stream is not None and not eng.overlap and eng.world == 1
-                                  and K == 1 and R <= eng.side_max_rows and not self.has_adv and big) else 0
+                                  and K == 1 and R <= eng.side_max_rows and not self.has_adv and big
+                                  and (measured or eng.side_dw_any)) else 0
         early_branch = bool(side_dw and K == 1 and not self.iwae and eng.batch_finish and eng.merge_launches
                             and eng.side_branches)
-        self.use_side = bool(side_dw) or (eng.side_stream_asked and eng.side_stream is not None)
+        # (MMVAE_SIDE_STREAM=1, the diagnostic that forks the small weight-gradient GEMMs: big shapes only -- toy-sized
+        # forked graphs are where hipGraphLaunch faulted; MMVAE_SIDE_STREAM=force lifts that for the crash hunt)
+        self.use_side = bool(side_dw) or (eng.side_stream_asked and eng.side_stream is not None
+                                          and (big or os.environ.get("MMVAE_SIDE_STREAM") == "force"))
         loss_aside, early_calls = False, []
         # ---- pre-split operands of the G-wide GEMMs (K = 1 training programs on the wave-specialised kernels): the
         # decoder side (dP from the reconstruction epilogue, the last hidden activations from their layer tail) feeds

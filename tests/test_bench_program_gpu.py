@@ -69,3 +69,91 @@ def test_bench_program_matches_oracle():
             f.write(json.dumps(r) + "\n")
         f.write(json.dumps({"worst_of_12_replayed_steps": worst, "kinks": sum(r["kinks"] for r in rows)}) + "\n")
     model._engine.close()
+
+
+def _run_c2(steps, env):
+    """`steps` training steps of the C2 model under `env`; returns the final parameters and whether the plan forked."""
+    import bench
+    from mmvae_amd import synthetic
+
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        a = argparse.Namespace(config="c2", genes="", no_engine=False)
+        cfg = dict(synthetic.CONFIGS["c2"])
+        device = torch.device("cuda", 0)
+        model = bench.build_model(a, cfg, device).to(device)
+        model.train()
+        model.trainer.set_stage("training")
+        model.optimizers()
+        from mmvae_amd import rng
+
+        rng.state(device)
+        rng.reseed(1234)  # the same Philox stream for every variant
+        B = cfg["batch"]
+        eids = list(cfg["experts"].keys())
+        data = {eid: (synthetic.synthetic_counts(B, G, seed=77 + i, device=device), synthetic.synthetic_metadata(B, seed=5))
+                for i, (eid, G) in enumerate(cfg["experts"].items())}
+        for i in range(steps):
+            eid = eids[i % len(eids)]
+            model.training_step((*data[eid], eid), i)
+        model._flush_engine()
+        torch.cuda.synchronize()
+        forked = bool(model._engine.last_plan._forked)
+        sd = {k: v.detach().cpu().clone() for k, v in model.module.state_dict().items()}
+        model._engine.close()
+        del model
+        return sd, forked
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_forked_program_is_bit_identical_to_the_single_stream_one():
+    """the multi-stream captured program (default at the C2 geometry) against the same steps on ONE stream
+    (MMVAE_SIDE_DW=0) and without the small branches (MMVAE_SIDE_BRANCHES=0): identical parameters after 8 steps (the
+    same kernels, the same summation orders; a cap only changes how many workgroups a persistent grid has), with the
+    pre-split operand path on and off."""
+    import gc
+
+    ref, forked = _run_c2(8, {})
+    assert forked, "the C2 program forks by default"
+    for env in ({"MMVAE_SIDE_DW": "0"}, {"MMVAE_SIDE_BRANCHES": "0"}, {"MMVAE_PLANES": "0"},
+                {"MMVAE_PLANES": "0", "MMVAE_SIDE_DW": "0"}):
+        gc.collect()
+        torch.cuda.empty_cache()
+        got, f = _run_c2(8, env)
+        assert f == (env.get("MMVAE_SIDE_DW") != "0")
+        bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+        assert not bad, f"{env}: {len(bad)} tensors differ, e.g. {bad[:3]}"
+
+
+def test_fork_is_gated_to_the_measured_geometry():
+    """Shapes away from C2's (here: 8 000 genes, 512 rows: a 8.4 GFLOP weight gradient) stay on one stream unless asked."""
+    from mmvae_amd import synthetic
+
+    def build(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            model = synthetic.build_model({"human": 8000, "mouse": 8000}, adversarial=False, n_samples=1, use_engine=True,
+                                          seed=0).to("cuda")
+            model.train()
+            model.trainer.set_stage("training")
+            model.optimizers()
+            x = synthetic.synthetic_counts(512, 8000, seed=3, device="cuda")
+            for i in range(2):
+                model.training_step((x, synthetic.synthetic_metadata(512, seed=5), "human"), i)
+            torch.cuda.synchronize()
+            f = bool(model._engine.last_plan._forked)
+            model._engine.close()
+            return f
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+    assert build({}) is False
+    assert build({"MMVAE_SIDE_DW_ANY": "1"}) is True
