@@ -299,6 +299,9 @@ int mmvae_sum_rows_f32(int H, int64_t n, const float* v, int64_t ld, float* out_
  *                      grad_scale multiplies the gradients first (DDP averaging: 1/world_size).
  * mmvae_adam_step:     g = clip*grad_scale*grad + wd*p ; m += (1-b1)(g-m) ; v = b2 v + (1-b2) g^2 ;
  *                      p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)            (torch.optim.Adam, amsgrad=False)
+ *                      state[5] = cv > 0 (written by the caller; mmvae_adam_prepare never touches it): clip BY VALUE --
+ *                      GradientClipConfig(algorithm="value"), config.py:8, Lightning clip_gradients ->
+ *                      clip_grad_value_ -- g = clamp(clip*grad_scale*grad, -cv, cv) + wd*p (pass max_norm = 0: clip = 1).
  * ------------------------------------------------------------------------------------------------------------ */
 #define MMVAE_ADAM_STATE_FLOATS 8
 #define MMVAE_PREPARE_NORM 1u

@@ -566,9 +566,13 @@ __global__ __launch_bounds__(256) void sqnorm_ranges_prepare_kernel(SqRanges r, 
 #ifndef MMVAE_ADAM_NT
 #define MMVAE_ADAM_NT 1  // 1: nontemporal loads of g, m, v and stores of m, v (2: p as well); 0: plain accesses
 #endif
+// cv > 0: gradient_clip_algorithm "value" (config.py:8; Lightning clip_gradients -> clip_grad_value_): every element
+// of the (averaged) gradient is clamped to [-cv, cv] ahead of the weight decay; the norm coefficient is 1 then.
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float gmul, float wd, float b1, float b2,
-                                         float step_size, float inv_bc2_sqrt, float eps) {
+                                         float step_size, float inv_bc2_sqrt, float eps, float cv = 0.f) {
+    const float gc = fminf(fmaxf(g * gmul, -cv), cv) + wd * p;
     g = g * gmul + wd * p;
+    if (cv > 0.f) g = gc;
     m = m + (1.f - b1) * (g - m);
     v = b2 * v + (1.f - b2) * g * g;
     const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
@@ -587,6 +591,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(int64_t n, float* __rest
     const float gmul = state[2] * grad_scale;
     const float step_size = lr / state[3];
     const float inv_bc2_sqrt = 1.f / sqrtf(state[4]);
+    const float cv = state[5];  // clip-by-value bound (0: off), mmvae_adam_set_clip_value
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (vec) {
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(int64_t n, float* __rest
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float pe = pp[e], me = mm[e], ve = vw[e];
-                adam_one(pe, gg[e], me, ve, gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+                adam_one(pe, gg[e], me, ve, gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps, cv);
                 pp[e] = pe;
                 mm[e] = me;
                 vw[e] = ve;
@@ -627,10 +632,10 @@ __global__ __launch_bounds__(256) void adam_step_kernel(int64_t n, float* __rest
 #endif
         }
         for (int64_t i = nv * 4 + tid0; i < n; i += stride)
-            adam_one(p[i], g[i], m[i], v[i], gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+            adam_one(p[i], g[i], m[i], v[i], gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps, cv);
     } else {
         for (int64_t i = tid0; i < n; i += stride)
-            adam_one(p[i], g[i], m[i], v[i], gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+            adam_one(p[i], g[i], m[i], v[i], gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps, cv);
     }
 }
 
@@ -648,6 +653,7 @@ __global__ __launch_bounds__(256) void adam_step_jobs_kernel(const mmvae_adam_jo
     const float gmul = state[2] * grad_scale;
     const float step_size = lr / job.bc1;
     const float inv_bc2_sqrt = 1.f / sqrtf(job.bc2);
+    const float cv = state[5];
     const int64_t o = job.offset;
     const int n = job.len;
     if ((o & 3) == 0) {  // arena tensors start on 16-byte boundaries: 16-byte accesses, scalar tail
@@ -661,7 +667,7 @@ __global__ __launch_bounds__(256) void adam_step_jobs_kernel(const mmvae_adam_jo
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float pe = pp[e], me = mm[e], ve = vw[e];
-                adam_one(pe, gg[e], me, ve, gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+                adam_one(pe, gg[e], me, ve, gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps, cv);
                 pp[e] = pe;
                 mm[e] = me;
                 vw[e] = ve;
@@ -671,10 +677,10 @@ __global__ __launch_bounds__(256) void adam_step_jobs_kernel(const mmvae_adam_jo
             vv[i] = vw;
         }
         for (int i = 4 * nv + threadIdx.x; i < n; i += 256)
-            adam_one(p[o + i], g[o + i], m[o + i], v[o + i], gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+            adam_one(p[o + i], g[o + i], m[o + i], v[o + i], gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps, cv);
     } else {
         for (int i = threadIdx.x; i < n; i += 256)
-            adam_one(p[o + i], g[o + i], m[o + i], v[o + i], gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+            adam_one(p[o + i], g[o + i], m[o + i], v[o + i], gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps, cv);
     }
 }
 

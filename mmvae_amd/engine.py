@@ -265,7 +265,7 @@ class StepEngine:
         after the first step, a new learning rate through param_groups or HipAdam.load_state_dict, an edited
         autograd_config) drops the plans and their graphs, which are then rebuilt with the current values."""
         ac = self.model.autograd_config
-        clip = lambda c: float(c.val) if (c and c.val) else 0.0  # noqa: E731
+        clip = lambda c: (float(c.val), c.algorithm or "norm") if (c and c.val) else (0.0, "norm")  # noqa: E731
         per_opt = tuple((g["lr"], g["eps"], g["weight_decay"], tuple(g["betas"]), o.reducer is not None, o.grad_scale)
                         for o in self.model.optimizers() for g in o.param_groups[:1])
         return (per_opt, clip(ac.vae_gradient_clip), clip(ac.expert_gradient_clip), clip(ac.adversarial_gradient_clip),
@@ -515,10 +515,22 @@ class _Plan:
         self.opt_exp = eng.opts["experts"][eid]
         self.opt_adv = list(eng.opts.get("adversarials", {}).values()) if self.has_adv else []
         ac = model.autograd_config
-        self.clip_vae = float(ac.vae_gradient_clip.val) if ac.vae_gradient_clip and ac.vae_gradient_clip.val else 0.0
-        self.clip_exp = float(ac.expert_gradient_clip.val) if ac.expert_gradient_clip and ac.expert_gradient_clip.val else 0.0
-        self.clip_adv = (float(ac.adversarial_gradient_clip.val)
-                         if ac.adversarial_gradient_clip and ac.adversarial_gradient_clip.val else 0.0)
+        def clip_rule(c):
+            """GradientClipConfig -> (max_norm for the fused clip, clamp bound for clip-by-value); config.py:4-26"""
+            val = float(c.val) if (c and c.val) else 0.0
+            if val and (c.algorithm or "norm") == "value":
+                return 0.0, val
+            if val and (c.algorithm or "norm") != "norm":
+                raise _lib.HipLibraryError(f"engine: gradient_clip_algorithm {c.algorithm!r} (config.py:8 allows 'norm' / 'value')")
+            return val, 0.0
+
+        (self.clip_vae, cv_vae), (self.clip_exp, cv_exp), (self.clip_adv, cv_adv) = (
+            clip_rule(ac.vae_gradient_clip), clip_rule(ac.expert_gradient_clip), clip_rule(ac.adversarial_gradient_clip))
+        # clip-by-value: the bound is state word 5 of each optimiser (read by the Adam kernels; 0 = off)
+        for opt, cv in [(self.opt_vae, cv_vae), (self.opt_exp, cv_exp)] + [(o, cv_adv) for o in self.opt_adv]:
+            opt.set_clip_value(cv or None)
+            if not cv:
+                opt.state_dev[5] = 0.0
         self.conditions = list(Adversarial.labels.keys()) if self.has_adv else []
         self.metric_slots: Dict[str, int] = {}
         self.segments: List = []  # list of closure lists, separated by ("allreduce", opt) markers

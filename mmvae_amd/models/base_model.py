@@ -106,13 +106,20 @@ class BaseModel(_Base):
         def clip_gradients(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm=None):
             if gradient_clip_val is None:
                 return
-            if (gradient_clip_algorithm or "norm") != "norm":
-                raise NotImplementedError("only gradient_clip_algorithm='norm' is on the HIP path")
-            if hasattr(optimizer, "set_clip"):
-                optimizer.set_clip(float(gradient_clip_val))  # fused into HipAdam.step()
+            algorithm = gradient_clip_algorithm or "norm"
+            if algorithm not in ("norm", "value"):
+                raise ValueError(f"gradient_clip_algorithm {algorithm!r}: 'norm' or 'value' (config.py:8)")
+            if hasattr(optimizer, "set_clip"):  # fused into HipAdam.step()
+                if algorithm == "norm":
+                    optimizer.set_clip(float(gradient_clip_val))
+                else:
+                    optimizer.set_clip_value(float(gradient_clip_val))
             else:
                 params = [p for g in optimizer.param_groups for p in g["params"]]
-                torch.nn.utils.clip_grad_norm_(params, float(gradient_clip_val))
+                if algorithm == "norm":
+                    torch.nn.utils.clip_grad_norm_(params, float(gradient_clip_val))
+                else:
+                    torch.nn.utils.clip_grad_value_(params, float(gradient_clip_val))
 
         @property
         def device(self):

@@ -153,6 +153,16 @@ class HipAdam(torch.optim.Optimizer):
     # ---- Lightning-style clipping hook: remembered, applied inside step()
     def set_clip(self, max_norm: Optional[float]) -> None:
         self.max_grad_norm = max_norm
+        if getattr(self, "clip_value", None):
+            self.set_clip_value(None)
+
+    def set_clip_value(self, bound: Optional[float]) -> None:
+        """gradient_clip_algorithm "value" (config.py:8): every gradient element clamped to [-bound, bound] inside the
+        fused update (state word 5; include/mmvae_hip.h); None / 0 switches it off.  Replaces the norm clip."""
+        self.clip_value = float(bound) if bound else None
+        if self.clip_value:
+            self.max_grad_norm = None
+        self.state_dev[5] = self.clip_value or 0.0
 
     @property
     def grad_norm(self) -> torch.Tensor:
@@ -351,7 +361,10 @@ class HipAdam(torch.optim.Optimizer):
         self.state_dev[0] += 1
         t = float(self.state_dev[0])
         self.state_dev[1], self.state_dev[2] = norm, clip
-        grad = grad * clip + g["weight_decay"] * a.data
+        grad = grad * clip
+        if getattr(self, "clip_value", None):
+            grad = grad.clamp(-self.clip_value, self.clip_value)
+        grad = grad + g["weight_decay"] * a.data
         a.exp_avg.lerp_(grad, 1 - b1)
         a.exp_avg_sq.mul_(b2).addcmul_(grad, grad, value=1 - b2)
         bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t

@@ -94,6 +94,7 @@ class ModelSpec:
     latent_dim: int
     var_eps: float = 1e-4  # components.py:704
     hidden_z: bool = False  # components.py:803-804
+    softmax_z: bool = False  # Encoder(distribution="ln"): z = softmax(rsample) (components.py:740-741,801)
     adversarials: List[AdvSpec] = field(default_factory=list)
     conditionals: Optional[CondSpec] = None  # clvae.py:42-49
 
@@ -114,6 +115,7 @@ class HParams:
     bn_momentum: float = 0.01  # components.py:279
     bn_eps: float = 1e-3
     world_size: int = 1  # DDP gradient averaging (Lightning DDP semantics): grads are divided by world_size
+    clip_algorithm: str = "norm"  # "value": GradientClipConfig(algorithm="value"), config.py:8 -> clip_grad_value_
     elbo_mode: str = "analytic"  # "iwae": the opt-in full-IWAE objective of the K-sample extension (elbo_iwae)
 
 
@@ -314,6 +316,8 @@ def model_forward(spec: ModelSpec, sd, x, expert_id: str, eps, training: bool, m
     var = torch.exp(F.linear(q, sd["vae.encoder.var_encoder.weight"], sd["vae.encoder.var_encoder.bias"])) + spec.var_eps
     std = var.sqrt()  # :798 Normal(q_m, q_v.sqrt())
     z = mu + std * eps  # :801 rsample == loc + eps * scale ; broadcasts over K
+    if spec.softmax_z:  # :801 z_transformation (nn.Softmax(dim=-1) for distribution "ln", :740-741)
+        z = torch.softmax(z, dim=-1)
     if spec.hidden_z:  # :803-804 (K = 1 sample)
         hidden = hidden + [z if z.dim() == 2 else z[0]]
     if spec.conditionals is not None:  # vae.py:100 after_reparameterize -> clvae.py:107-111; the returned z is its output
@@ -406,7 +410,9 @@ def clip_and_adam(names, sd, grads, opt_state, group: str, clip: Optional[float]
     gl = [grads[n] / hp.world_size for n in names]
     norm = grad_norm(gl)
     coef = 1.0
-    if clip is not None:
+    if clip is not None and hp.clip_algorithm == "value":  # Lightning clip_gradients(..., "value") = clip_grad_value_
+        gl = [g.clamp(-float(clip), float(clip)) for g in gl]
+    elif clip is not None:
         coef = min(1.0, float(clip) / (float(norm) + 1e-6))
     st = opt_state.setdefault(group, {"steps": {}, "exp_avg": {}, "exp_avg_sq": {}})
     new = {}

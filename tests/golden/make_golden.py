@@ -113,6 +113,7 @@ def build_reference(case, tmpdir):
                                   dropout=case.get("vae_dropout", 0.0)),
             decoder_config=fc_cfg(base, [case["Z"]] + case["vae_hidden"][::-1] + [case["expert_hidden"][-1]]),
             hidden_z=case["hidden_z"], **cond_kwargs,
+            **({"distribution": case["distribution"]} if case.get("distribution") else {}),
         )
     advs = None
     if case.get("adversarials"):
@@ -296,8 +297,12 @@ def run_case(case):
                         out[f"step{t}/grad/vae.{n_}"] = p.grad.numpy().copy()
                 for n_, p in list(module.experts[eid].named_parameters()):
                     out[f"step{t}/grad/experts.{eid}.{n_}"] = p.grad.numpy().copy()
-                torch.nn.utils.clip_grad_norm_(list(module.vae.parameters()), 10.0)  # :203-204
-                torch.nn.utils.clip_grad_norm_(list(module.experts[eid].parameters()), 10.0)  # :206-209
+                if case.get("clip_value"):  # GradientClipConfig(val, "value") (config.py:4-26) -> clip_grad_value_
+                    torch.nn.utils.clip_grad_value_(list(module.vae.parameters()), case["clip_value"])
+                    torch.nn.utils.clip_grad_value_(list(module.experts[eid].parameters()), case["clip_value"])
+                else:
+                    torch.nn.utils.clip_grad_norm_(list(module.vae.parameters()), 10.0)  # :203-204
+                    torch.nn.utils.clip_grad_norm_(list(module.experts[eid].parameters()), 10.0)  # :206-209
                 optims["vae"].step()  # :212-213
                 optims[f"expert_{eid}"].step()
                 for k, v in res.items():
@@ -414,6 +419,18 @@ CASES = {
                      cond=dict(keys=["assay", "donor_id", "species", "sex"], shared={"assay": 4, "sex": 2},
                                species_specific={"donor_id": {"human": 5, "mouse": 3}}, layer_norm=True,
                                parallel=False)),
+    # Encoder(distribution="ln"): softmax over the latent sample (components.py:740-741,801)
+    "ln_dist": dict(seed=29, experts={"human": 96, "mouse": 72}, expert_hidden=[64, 32], vae_hidden=[24], Z=12, B=20,
+                    dropout=0.1, hidden_z=True, distribution="ln", schedule=["human", "mouse", "human"],
+                    kl_weights=[1.0, 1.0, 0.5],
+                    # the softmax damps the encoder's gradients to rounding level in places, and a cold Adam step is
+                    # sign-like (+-lr whatever the magnitude): post-step parameters are held to 5e-4 instead of 1e-4
+                    # (gradients themselves to 1e-4 as everywhere)
+                    param_tol=5e-4),
+    # GradientClipConfig(algorithm="value") (config.py:8): Lightning clip_gradients(..., "value") = clip_grad_value_
+    "clip_value": dict(seed=31, experts={"human": 96, "mouse": 72}, expert_hidden=[64, 32], vae_hidden=[24], Z=12, B=20,
+                       dropout=0.1, hidden_z=False, clip_value=0.05, schedule=["human", "mouse", "human"],
+                       kl_weights=[1.0, 1.0, 1.0]),
     # ---- full-size ("regen") cases: the kernels the benchmark times, pinned to the reference.  Initial parameters and
     # inputs are regenerated from the seeds (tests/helpers.regen_initial_state / RegenStream); the fixture keeps
     # checksums and sampled entries.  lam_scale 1.0 = the benchmark's count distribution (~10 % non-zeros).

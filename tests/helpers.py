@@ -8,7 +8,7 @@ import torch
 from oracle import mmvae_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["c1_small", "two_mod_odd", "adversarial", "adv_dropout"]
+CASES = ["c1_small", "two_mod_odd", "adversarial", "adv_dropout", "ln_dist", "clip_value"]
 # conditional layers after the reparameterisation; cond_adv: + two adversaries
 COND_CASES = ["cond_seq", "cond_par", "cond_adv"]
 
@@ -49,7 +49,7 @@ def spec_from_case(case) -> O.ModelSpec:
         vae_encoder=O.FCSpec.make([eh[-1]] + vh, use_batch_norm=True, relu=True, return_hidden=True,
                                   dropout_rate=case.get("vae_dropout", 0.0)),
         vae_decoder=O.FCSpec.make(dec_layers, relu=True),
-        latent_dim=Z,
+        latent_dim=Z, softmax_z=case.get("distribution") == "ln",
         hidden_z=case["hidden_z"],
         adversarials=advs,
         conditionals=conds,
@@ -93,7 +93,11 @@ def cond_order(case, t):
 
 
 def hparams_from_case(case) -> O.HParams:
-    return O.HParams(adv_weight=float(case.get("adv_weight") or 1.0))
+    hp = O.HParams(adv_weight=float(case.get("adv_weight") or 1.0))
+    if case.get("clip_value"):
+        v = float(case["clip_value"])
+        hp.clip_algorithm, hp.vae_clip, hp.expert_clip, hp.adversarial_clip = "value", v, v, v
+    return hp
 
 
 def sd_from(z, prefix):

@@ -21,6 +21,11 @@ def test_engine_path_matches_reference(name):
     case, z, results = MU.replay_training(name, "cuda", use_engine=True)
     MU.check_against_golden(case, z, results)
     engine = MU.replay_training.last_engine
+    if case.get("distribution") == "ln":
+        # Encoder(distribution="ln") (softmax over the latent sample, components.py:740-741): the captured engine
+        # declines it; the step ran -- and matched -- on the module path (HIP kernels sequenced by autograd)
+        assert not engine
+        return
     assert engine, "the captured engine must have taken this configuration"
     if name in H.COND_CASES:  # conditional layers ran inside the captured program, not on the module path
         assert all(p.cond is not None for p in engine._plans.values())
