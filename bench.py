@@ -400,6 +400,29 @@ def main():
     leg = None
     if on_gpu and a.mode == "train" and feed is None and getattr(model, "_engine", None) and not a.no_engine:
         leg = time_step_kernels(model, step, n_setup + a.warmup + a.steps)  # every rank: the steps exchange gradients
+    # N > 1: the same loop once more with the gradient all-reduces skipped (mmvae_amd.dist.DRY_RUN) -- what the step
+    # costs without the transfers; `ms_per_step` minus this is the exchange the overlapped program did NOT hide
+    dp_diag = None
+    if world > 1 and a.mode == "train" and feed is None:
+        n_dry = max(min(a.steps, 20), 2 * len(eids))
+        base = n_setup + a.warmup + a.steps + 16
+        mdist.DRY_RUN = True
+        try:
+            for i in range(2 * len(eids)):
+                step(base + i)
+            sync()
+            t1 = time.perf_counter()
+            for i in range(n_dry):
+                step(base + 2 * len(eids) + i)
+            sync()
+            dry = time.perf_counter() - t1
+        finally:
+            mdist.DRY_RUN = False
+        t = torch.tensor([dry], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dp_diag = {"ms_per_step_without_transfers": float(t) / n_dry * 1e3, "steps": n_dry,
+                   "note": "the same data-parallel program with the all-reduce calls skipped (max over ranks), run behind "
+                           "the timed region; ms_per_step minus this = exchange time the program did not hide"}
     if getattr(model, "_engine", None):
         model._flush_engine()
     loss = {k: float(v.detach() if torch.is_tensor(v) else v) for k, v in model.logged.items()
@@ -493,6 +516,9 @@ def main():
                 out["parity"] = parity
         elif not on_gpu:
             out["rehearsal"] = "CPU plumbing over gloo: launch / exchange / timing logic only, not a measurement"
+        if dp_diag is not None:
+            dp_diag["ms_exposed_exchange"] = el / a.steps * 1e3 - dp_diag["ms_per_step_without_transfers"]
+            out["data_parallel"] = dp_diag
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -17,6 +17,11 @@ import torch
 import torch.distributed as dist
 
 BUCKET_BYTES = 64 << 20  # xGMI ring all-reduce is per-link bound: few, large messages
+# Diagnostics (bench.py --gpus N > 1, behind its timed region): skip the gradient all-reduces while everything else of
+# the data-parallel program (streams, events, the norm of the "reduced" arena, the deferred update) runs unchanged --
+# the step time without the transfers; the difference to the timed figure is the exchange that was NOT hidden.  The
+# replicas drift apart from there on: only ever set at the end of a measurement process.
+DRY_RUN = False
 
 
 def init_from_env(backend: Optional[str] = None) -> int:
@@ -69,7 +74,7 @@ def all_reduce_flat(flat: torch.Tensor, group=None, bucket_bytes: int = BUCKET_B
     """Sum-all-reduce a flat tensor in place, in contiguous buckets, ordered after the CURRENT stream (the process
     group's communication stream waits for the current stream and the current stream waits for the collective, both
     as stream dependencies: the host never blocks)."""
-    if not collectives_active():
+    if not collectives_active() or DRY_RUN:
         return
     for r in bucket_ranges(flat.numel(), bucket_bytes):
         dist.all_reduce(flat[r.start:r.stop], op=dist.ReduceOp.SUM, group=group)
@@ -97,7 +102,7 @@ class GradAllReducer:
 
     def launch(self, flat_grad: torch.Tensor) -> None:
         """Enqueue the all-reduce of `flat_grad` (in place).  Returns immediately; call wait() before reading it."""
-        if not collectives_active():
+        if not collectives_active() or DRY_RUN:
             return
         if self.stream is not None and flat_grad.is_cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
