@@ -1245,7 +1245,7 @@ class _Plan:
         # ---- forward, encoder side
         cur, ld = x, ldx
         for i, l in enumerate(self.enc_layers):
-            self._probe_next = "enc_l1_fwd" if (i == 0 and big) else None
+            self._probe_next = "enc_l1_fwd" if i == 0 else None
             cur = self.fwd_layer(f"{self.eid}.enc{i}" if i < self.n_expert_enc else f"vae.enc{i}", l, cur, ld, B,
                                  training=train, mask_stream=i, after_gemm=x_split_hook if i == 0 else None,
                                  inp_planes=self.xp if (i == 0 and getattr(self, "_x_head", False)) else None,

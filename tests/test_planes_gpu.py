@@ -48,15 +48,17 @@ def test_split_is_exact(ops, rows, cols):
 
 CASES = [
     # (layout, M, N, K, pre-split operands, raw split-K slabs)
-    (TN, 1024, 2560, 512, "ab", False),   # tiles of the three shapes are all exercised through M, N below
-    (TN, 2560, 1024, 512, "ab", False),
+    # (the planes kernels are the wave-specialised ones: a shape needs >= 160 work items to be taken)
+    (TN, 2048, 5120, 512, "ab", False),   # 256x160 tiles
+    (TN, 5120, 2048, 512, "ab", False),   # 160x256 tiles
+    (TN, 4096, 4096, 256, "ab", False),   # 256x128 tiles
     (TN, 1024, 20000, 512, "ab", False),  # dW of the expert encoder's first layer at C2
     (TN, 20000, 1024, 512, "ab", False),  # dW of the expert decoder's last layer
-    (TN, 1000, 2504, 480, "ab", False),   # ragged tiles (extents % 8 == 0 only), K padded to 512 over the slack rows
+    (TN, 2000, 5008, 480, "ab", False),   # ragged tiles (extents % 8 == 0 only), K padded to 512 over the slack rows
     (NT, 512, 1024, 20000, "a", True),    # forward of the first layer: x pre-split, W fp32
     (NN, 512, 1024, 20000, "a", True),    # dX of the last layer: dP pre-split, W fp32
-    (NT, 500, 1024, 4096, "a", True),
-    (NN, 768, 1280, 4096, "a", True),
+    (NT, 500, 1024, 8192, "a", True),
+    (NN, 768, 1280, 8192, "a", True),
 ]
 
 
@@ -65,14 +67,13 @@ def test_gemm_planes_bitwise_and_fp64(ops, layout, M, N, K, pre, slabs):
     Kp = (K + 31) // 32 * 32
     if layout == TN:
         a, b = padded(rnd(K, M, seed=1)), padded(rnd(K, N, seed=2))
-        ref = a.double().t() @ b.double()
     elif layout == NT:
         a, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.02)
-        ref = a.double() @ b.double().t()
     else:
         a, b = rnd(M, K, seed=1), rnd(K, N, seed=2, scale=0.02)
-        ref = a.double() @ b.double()
     a[:, ::3] = 0  # count-like sparsity
+    ref = (a.double().t() @ b.double() if layout == TN else a.double() @ b.double().t() if layout == NT
+           else a.double() @ b.double())
     ap = ops.split_planes(a)
     bp = ops.split_planes(b) if "b" in pre else None
     kw = dict(K=Kp if layout == TN else None, raw_slabs=slabs, want_sq=(layout == TN))
