@@ -60,6 +60,9 @@ namespace {
 #ifndef MMVAE_X3_STAMPS
 #define MMVAE_X3_STAMPS 0  // diagnostic build: per-phase cycle sums of the bf16x3 loop (block 0, one lane per wave)
 #endif
+#ifndef MMVAE_SLAB_STORE_NT
+#define MMVAE_SLAB_STORE_NT 0  // 1: raw split-K slabs stored non-temporally (measured r3: 1.036 against 1.033 ms per C2 step -- no gain)
+#endif
 #ifndef MMVAE_GEMM_PRELOAD
 #define MMVAE_GEMM_PRELOAD 0
 #endif
@@ -249,6 +252,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
 #pragma unroll
                                     for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                                 }
+#if MMVAE_SLAB_STORE_NT
+                                // raw split-K slabs (16 x 2 MB for the G-wide K reductions) are read exactly once, by the
+                                // next launch: stored non-temporally they do not sit dirty in L2 at the kernel boundary
+                                if (raw)
+                                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(cp));
+                                else
+#endif
                                 *reinterpret_cast<f32x4*>(cp) = v;
                                 sq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                             } else {

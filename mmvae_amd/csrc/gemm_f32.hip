@@ -186,6 +186,129 @@ __global__ __launch_bounds__(NT) void gemm_f32_batch_kernel(const mmvae_gemm_job
         gemm_f32_item<FORM_RC, FORM_RC, 64, 64, 32, 2, 2, true, EPI_STD>(g, l, lds);
 }
 
+// ---- bf16x3 twin of gemm_f32_item for the 64x64 tiles of the core layers (r3).  These launches are latency-bound, but
+// a quarter to a half of a workgroup's life was its MFMA chain: 16 x v_mfma_f32_32x32x2_f32 (64 cycles each) per k-tile
+// and wave, with 2-4 workgroups sharing a CU's matrix cores.  The same products as six bf16 MFMAs per 16 k (the split
+// done once per element on the way to LDS, 88 VALU instructions per thread and k-tile): 384 cycles instead of 1 024.
+// One LDS image (three bf16 planes per operand, 80-byte rows), next tile's loads in flight during the MFMAs, two
+// barriers per k-tile; fp32-GEMM accuracy as in the chip-filling kernels (MMVAE_GEMM_PRECISION_F32 keeps the exact path).
+constexpr int X3S_LDS_BYTES = 3 * (64 + 64) * X3_LD;
+template <int AFORM, int BFORM, bool VEC, int EPI>
+__device__ __forceinline__ void gemm_x3s_item(const GemmArgs& g, int L, char* lds) {
+    constexpr int BM = 64, BN = 64, WGN = 2;
+    constexpr int PA = BM * X3_LD, PB = BN * X3_LD;
+    char* As = lds;
+    char* Bs = lds + 3 * PA;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int tiles = g.mt * g.nt;
+    const int z = L / tiles;
+    const int t = L - z * tiles;
+    const int bm = t % g.mt, bn = t / g.mt;
+    const int kt_beg = z * g.ktiles_per_split;
+    int kt_end = kt_beg + g.ktiles_per_split;
+    if (kt_end > g.ktiles) kt_end = g.ktiles;
+    const int nkt = kt_end - kt_beg;
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.f;
+    constexpr int NVA = X3Regs<AFORM, BM>::NV, NVB = X3Regs<BFORM, BN>::NV;
+    f32x4 ra[NVA], rb[NVB];
+    unsigned va[NVA], vb[NVB];
+    auto load_ab = [&](int kt) {
+        const int k0 = kt * X3_BK;
+        if constexpr (AFORM == FORM_KC)
+            load_tile<FORM_KC, BM, X3_BK, VEC>(ra, va, g.A, g.lda, bm * BM, g.M, k0, g.K, tid);
+        else
+            x3_load_rc<BM, VEC>(ra, va, g.A, g.lda, bm * BM, g.M, k0, g.K, tid);
+        if constexpr (BFORM == FORM_KC)
+            load_tile<FORM_KC, BN, X3_BK, VEC>(rb, vb, g.B, g.ldb, bn * BN, g.N, k0, g.K, tid);
+        else
+            x3_load_rc<BN, VEC>(rb, vb, g.B, g.ldb, bn * BN, g.N, k0, g.K, tid);
+    };
+    if (nkt > 0) {
+        load_ab(kt_beg);
+        x3_store<AFORM, BM, VEC>(As, ra, va, tid, bm * BM, g.M, kt_beg * X3_BK, g.K);
+        x3_store<BFORM, BN, VEC>(Bs, rb, vb, tid, bn * BN, g.N, kt_beg * X3_BK, g.K);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const bool more = kt + 1 < nkt;
+            if (more) load_ab(kt_beg + kt + 1);  // in flight during this k-tile's MFMAs
+            f32x16 c = acc[0][0];
+#pragma unroll
+            for (int ks = 0; ks < X3_BK / 16; ++ks) {
+                bf16x8 fa[3], fb[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    fa[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(
+                                                           As + p * PA + (wm * 32 + l31) * X3_LD + ks * 32 + half * 16));
+                    fb[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(
+                                                           Bs + p * PB + (wn * 32 + l31) * X3_LD + ks * 32 + half * 16));
+                }
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], c, 0, 0, 0);  // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], c, 0, 0, 0);
+            }
+            acc[0][0] = c;
+            __syncthreads();
+            if (more) {
+                const int k0 = (kt_beg + kt + 1) * X3_BK;
+                x3_store<AFORM, BM, VEC>(As, ra, va, tid, bm * BM, g.M, k0, g.K);
+                x3_store<BFORM, BN, VEC>(Bs, rb, vb, tid, bn * BN, g.N, k0, g.K);
+            }
+            __syncthreads();
+        }
+    }
+    gemm_epilogue<BM, BN, 2, 2, EPI>(acc, g, bm, bn, z, reinterpret_cast<float*>(lds));
+}
+
+template <int AFORM, int BFORM, bool VEC, int EPI>
+__global__ __launch_bounds__(NT) void gemm_x3s_kernel(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) char lds[X3S_LDS_BYTES];
+    gemm_x3s_item<AFORM, BFORM, VEC, EPI>(g, xcd_remap(blockIdx.x, gridDim.x), lds);
+}
+
+// gemm_f32_batch_kernel on the bf16x3 item
+__global__ __launch_bounds__(NT) void gemm_x3s_batch_kernel(const mmvae_gemm_job* __restrict__ jobs, int n_jobs) {
+    __shared__ __attribute__((aligned(16))) char lds[X3S_LDS_BYTES];
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    int j = 0;
+    while (j + 1 < n_jobs && L >= jobs[j + 1].first_block) ++j;  // wave-uniform
+    const mmvae_gemm_job& job = jobs[j];
+    GemmArgs g = {};
+    g.A = job.A;
+    g.B = job.B;
+    g.C = job.C;
+    g.bias = job.bias;
+    g.lda = job.lda;
+    g.ldb = job.ldb;
+    g.ldc = job.ldc;
+    g.M = job.M;
+    g.N = job.N;
+    g.K = job.K;
+    g.mt = (job.M + 63) / 64;
+    g.nt = (job.N + 63) / 64;
+    g.ktiles = (job.K + 31) / 32;
+    g.ktiles_per_split = g.ktiles;
+    g.alpha = job.alpha;
+    g.flags = job.flags;
+    g.aligned = 2;
+    g.c_vec = 1;
+    g.x_rows = 1;
+    const int l = L - job.first_block;
+    if (job.layout == MMVAE_GEMM_NT)
+        gemm_x3s_item<FORM_KC, FORM_KC, true, EPI_STD>(g, l, lds);
+    else if (job.layout == MMVAE_GEMM_NN)
+        gemm_x3s_item<FORM_KC, FORM_RC, true, EPI_STD>(g, l, lds);
+    else
+        gemm_x3s_item<FORM_RC, FORM_RC, true, EPI_STD>(g, l, lds);
+}
+
 template <int AFORM, int BFORM, int BM, int BN, int WGM, int WGN, bool VEC, int EPI>
 __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
     static_assert(WGM * WGN == 4, "4 wavefronts per workgroup");
@@ -619,6 +742,15 @@ TileShape tile_shape(int layout, int id) {
     return {64, 64, 4};
 }
 
+extern int g_precision;
+// 64x64-tile launches on the bf16 matrix cores: opt-in (MMVAE_X3S=1, bf16x3 mode).  Measured r3 at C2, interleaved on
+// one box: 0.984 / 0.984 ms per step with it against 0.989 / 0.985 with the exact-f32 MFMA kernel -- these launches are
+// bound by their launch / prologue / epilogue latency, not by the MFMA chain, so the default stays the exact kernel.
+bool x3s_enabled() {
+    const char* e = getenv("MMVAE_X3S");
+    return g_precision == MMVAE_GEMM_PRECISION_BF16X3 && e && e[0] == '1';
+}
+
 template <int AFORM, int BFORM, bool VEC, int EPI>
 int launch_gemm_vec(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) {
     if (tile_id == 0)
@@ -634,6 +766,8 @@ int launch_gemm_vec(int tile_id, const GemmArgs& g, int nblocks, hipStream_t s) 
         else
             return MMVAE_ERR_ARG;
     }
+    else if (x3s_enabled() && EPI == EPI_STD)
+        MMVAE_LAUNCH((gemm_x3s_kernel<AFORM, BFORM, VEC, EPI_STD>), dim3(nblocks), dim3(NT), 0, s, g);
     else
         MMVAE_LAUNCH((gemm_f32_kernel<AFORM, BFORM, 64, 64, 32, 2, 2, VEC, EPI>), dim3(nblocks), dim3(NT), 0, s,
                            g);
@@ -1163,7 +1297,10 @@ extern "C" int mmvae_gemm_batch_prepare(int n_jobs, mmvae_gemm_job* jobs, int* t
 extern "C" int mmvae_gemm_batch_f32(int n_jobs, const mmvae_gemm_job* jobs_dev, int total_blocks,
                                     mmvae_stream_t stream) {
     if (n_jobs <= 0 || !jobs_dev || total_blocks <= 0) return MMVAE_ERR_ARG;
-    MMVAE_LAUNCH(gemm_f32_batch_kernel, dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, jobs_dev, n_jobs);
+    if (x3s_enabled())
+        MMVAE_LAUNCH(gemm_x3s_batch_kernel, dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, jobs_dev, n_jobs);
+    else
+        MMVAE_LAUNCH(gemm_f32_batch_kernel, dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, jobs_dev, n_jobs);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
 }
