@@ -120,6 +120,25 @@ class GradAllReducer:
         self._pending.clear()
 
 
+_HOST_GROUP = None
+
+
+def host_group():
+    """A process group for small HOST-side exchanges (metadata-derived flags): gloo, created at first use -- a collective
+    call, every rank must reach it at the same point of its program.  With a gloo default group it is that group."""
+    global _HOST_GROUP
+    if _HOST_GROUP is None:
+        _HOST_GROUP = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+    return _HOST_GROUP
+
+
+def host_all_reduce_max(flags):
+    """MAX all-reduce of a small numpy int32 array over the host group, in place; no device work, no stream sync."""
+    t = torch.from_numpy(flags)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=host_group())
+    return flags
+
+
 def attach(model, reducer: Optional[GradAllReducer] = None) -> GradAllReducer:
     """Make every HipAdam of `model` average its gradients over the default process group.  Collective call: every
     rank must call it (a second communicator for the small arenas is created here)."""

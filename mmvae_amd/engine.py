@@ -1962,7 +1962,13 @@ class _CondProgram:
         self.n_exchange, self.exchange_floats, self.staging = 0, 0, None
         if mdist.collectives_active() and train:
             # gradient exchange over the union's segments only: staging for every job of a full table
-            self.staging = eng.buf("cond.exchange", (self.max_jobs * 16384,))
+            # (sized by what a full table can hold, in the 128-float units of mmvae_jobs_pack: the dense parameters and
+            # one weight + bias per block that can step -- not 64 KB per job: 4 644 donor blocks at world 8 would have
+            # reserved gigabytes)
+            pad128 = lambda v: (int(v) + 127) // 128 * 128  # noqa: E731
+            n_blocks = (self.max_jobs - n_dense_jobs) // jpb
+            dense_floats = sum(pad128(a.params[i].numel()) for i in self.dense) + 128 * n_dense_jobs
+            self.staging = eng.buf("cond.exchange", (dense_floats + n_blocks * (pad128(Z * Z) + 128 * jpb + pad128(Z)),))
         if mdist.collectives_active():
             self.max_jobs += self.max_jobs - n_dense_jobs  # + the segments retired from the previous step's union
         # ---- static device tables, filled by load(): one padded cond_tables set per position
@@ -2087,12 +2093,13 @@ class _CondProgram:
                 # zeros; DDP's semantics for unused parameters, HipAdam._allreduce on the module path).  One MAX
                 # all-reduce of presence flags per step, on the host path ahead of the replay; every rank then builds
                 # the same job table, and marks the segments it did not write itself for zeroing.
+                # (on the HOST -- the flags come from host metadata; a device all-reduce + read-back was a
+                # full host-device synchronisation ahead of every replay)
                 n = len(self.opt.arena.params)
-                present = torch.zeros(n, dtype=torch.int32, device=self.eng.device)
-                present[torch.as_tensor(act, dtype=torch.long, device=self.eng.device)] = 1
-                torch.distributed.all_reduce(present, op=torch.distributed.ReduceOp.MAX,
-                                             group=self.opt.reducer.small_group if self.opt.reducer is not None else None)
-                union = np.flatnonzero(present.cpu().numpy()).astype(np.int64)
+                present = np.zeros(n, dtype=np.int32)
+                present[act] = 1
+                mdist.host_all_reduce_max(present)
+                union = np.flatnonzero(present).astype(np.int64)
                 absent_here = np.setdiff1d(union, act, assume_unique=False)
                 act = union
             jobs, owner = self.opt.job_table(act, b1, b2, with_owner=True)

@@ -198,3 +198,22 @@ def test_layer_tail_with_piggybacked_split(ops):
     got = xp.to_float()
     assert torch.equal(got[r0:r0 + nrows], x[r0:r0 + nrows])
     assert float(got[:r0].abs().max()) == 0 and float(got[r0 + nrows:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("layout", [NT, NN, TN])
+@pytest.mark.parametrize("M,N,K,splitk", [(512, 512, 1024, 0), (512, 256, 512, 1), (96, 257, 300, 1), (130, 70, 1000, 5),
+                                          (33, 47, 19, 1), (64, 48, 33, 0)])
+def test_small_tile_bf16x3_kernel(ops, monkeypatch, layout, M, N, K, splitk):
+    """MMVAE_X3S=1: the 64x64-tile GEMMs of the core layers on the bf16 matrix cores (opt-in: measured level with the
+    exact-f32 MFMA kernel inside the step).  fp32-GEMM accuracy, exact on integer-valued operands."""
+    monkeypatch.setenv("MMVAE_X3S", "1")
+    a, b = rnd(M, K, seed=31), rnd(K, N, seed=32)
+    ref = a.double() @ b.double()
+    A = a if layout != TN else a.t().contiguous()
+    Bm = b.t().contiguous() if layout == NT else b
+    out = ops.gemm(layout, A, Bm, splitk=splitk)
+    assert rel_l2(out.double(), ref) <= 2e-6
+    ai, bi = torch.round(a * 4), torch.round(b * 4) + 1
+    Ai = ai if layout != TN else ai.t().contiguous()
+    Bi = bi.t().contiguous() if layout == NT else bi
+    assert torch.equal(ops.gemm(layout, Ai, Bi, splitk=splitk).double(), ai.double() @ bi.double())
