@@ -310,6 +310,13 @@ int64_t mmvae_sqnorm_partials(int64_t n);
 int mmvae_grad_sqnorm(int64_t n, const float* grad, float* partials, mmvae_stream_t stream);
 int mmvae_adam_prepare(int64_t n_partials, const float* partials, float max_norm, float grad_scale, float beta1,
                        float beta2, float* state, unsigned flags, mmvae_stream_t stream);
+/* Host-side launch state (like mmvae_gemm_set_workgroup_cap): workgroups > 0 confines mmvae_adam_step /
+ * mmvae_adam_step_copy to that many compute units (1024-thread workgroups, one per CU) for callers that run the update
+ * beside a kernel of another stream whose grid is capped to the remaining units; 0 = the chip-filling grid.
+ * Elementwise work: results do not depend on it.  Replaces nothing in the reference (torch.optim.Adam.step,
+ * cmmvae_model.py:203-213, is stream-ordered behind backward). */
+int mmvae_adam_set_workgroups(int workgroups);
+int mmvae_adam_get_workgroups(void);
 /* mmvae_adam_step with a rider: workgroup 0 also copies copy_n floats copy_src -> copy_dst (both must not overlap the
  * arenas) -- the step's logged scalars into a log buffer without a launch of their own.  copy_n = 0: mmvae_adam_step. */
 int mmvae_adam_step_copy(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,

@@ -54,6 +54,8 @@ PROTOTYPES = {
     "mmvae_build_arch": (C.c_char_p, []),
     "mmvae_gemm_set_precision": (_i, [_i]),
     "mmvae_gemm_set_workgroup_cap": (_i, [_i]),
+    "mmvae_adam_set_workgroups": (_i, [_i]),
+    "mmvae_adam_get_workgroups": (_i, []),
     "mmvae_gemm_set_x3w": (_i, [_i]),
     "mmvae_gemm_get_x3w": (_i, []),
     "mmvae_gemm_get_precision": (_i, []),

@@ -579,11 +579,11 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p = p - step_size * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void adam_step_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
-                                                        float* __restrict__ m, float* __restrict__ v,
-                                                        const float* __restrict__ state, float lr, float b1, float b2,
-                                                        float eps, float wd, float grad_scale, int vec, int copy_n,
-                                                        const float* copy_src, float* copy_dst) {
+__device__ __forceinline__ void adam_step_body(int64_t n, float* __restrict__ p, const float* __restrict__ g,
+                                               float* __restrict__ m, float* __restrict__ v,
+                                               const float* __restrict__ state, float lr, float b1, float b2, float eps,
+                                               float wd, float grad_scale, int vec, int copy_n, const float* copy_src,
+                                               float* copy_dst) {
     // optional rider: a small device-to-device copy (the step's logged scalars into the plan's log buffer) done by
     // workgroup 0 -- instead of a launch of its own behind the longest kernel of the step
     if (copy_n > 0 && blockIdx.x == 0)
@@ -637,6 +637,58 @@ __global__ __launch_bounds__(256) void adam_step_kernel(int64_t n, float* __rest
         for (int64_t i = tid0; i < n; i += stride)
             adam_one(p[i], g[i], m[i], v[i], gmul, wd, b1, b2, step_size, inv_bc2_sqrt, eps, cv);
     }
+}
+
+__global__ __launch_bounds__(256) void adam_step_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        const float* __restrict__ state, float lr, float b1, float b2,
+                                                        float eps, float wd, float grad_scale, int vec, int copy_n,
+                                                        const float* copy_src, float* copy_dst) {
+    adam_step_body(n, p, g, m, v, state, lr, b1, b2, eps, wd, grad_scale, vec, copy_n, copy_src, copy_dst);
+}
+
+// The same pass confined to a chosen number of compute units (mmvae_adam_set_workgroups): that many workgroups of 1024
+// threads, each holding enough LDS that a compute unit takes exactly one -- for callers that run the update beside
+// another kernel whose grid is capped to the remaining units (the engine's deferred expert update).  Elementwise work:
+// identical results for any grid.
+constexpr int ADAM_WIDE_LDS = 84 * 1024;
+__global__ __launch_bounds__(1024) void adam_step_wide_kernel(int64_t n, float* __restrict__ p,
+                                                              const float* __restrict__ g, float* __restrict__ m,
+                                                              float* __restrict__ v, const float* __restrict__ state,
+                                                              float lr, float b1, float b2, float eps, float wd,
+                                                              float grad_scale, int vec, int copy_n,
+                                                              const float* copy_src, float* copy_dst) {
+    adam_step_body(n, p, g, m, v, state, lr, b1, b2, eps, wd, grad_scale, vec, copy_n, copy_src, copy_dst);
+}
+
+inline int grid_for(int64_t n, int per_block, int cap);
+static int g_adam_workgroups = 0;  // 0: the chip-filling grid of 256-thread workgroups
+
+extern "C" int mmvae_adam_set_workgroups(int workgroups) {
+    if (workgroups < 0 || workgroups > 256) return MMVAE_ERR_ARG;
+    g_adam_workgroups = workgroups;
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_adam_get_workgroups(void) { return g_adam_workgroups; }
+
+template <typename... Args>
+static int launch_adam_step(int64_t n, hipStream_t stream, Args... args) {
+    if (g_adam_workgroups > 0) {
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(adam_step_wide_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, ADAM_WIDE_LDS) != hipSuccess)
+                return MMVAE_ERR_LAUNCH;
+            attr = true;
+        }
+        MMVAE_LAUNCH(adam_step_wide_kernel, dim3(g_adam_workgroups), dim3(1024), (size_t)ADAM_WIDE_LDS, stream, n,
+                     args...);
+    } else {
+        MMVAE_LAUNCH(adam_step_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, stream, n, args...);
+    }
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
 }
 
 // Adam over a LIST of arena segments, one workgroup per job (a job = at most ADAM_JOB_ELEMS consecutive elements of
@@ -1142,11 +1194,8 @@ extern "C" int mmvae_adam_step(int64_t n, float* param, const float* grad, float
                                float grad_scale, mmvae_stream_t stream) {
     if (n <= 0 || !param || !grad || !exp_avg || !exp_avg_sq || !state) return MMVAE_ERR_ARG;
     const int vec = aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq);
-    MMVAE_LAUNCH(adam_step_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream, n, param,
-                       grad, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps, weight_decay, grad_scale, vec, 0,
-                       (const float*)nullptr, (float*)nullptr);
-    MMVAE_LAUNCH_CHECK();
-    return MMVAE_OK;
+    return launch_adam_step(n, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps,
+                            weight_decay, grad_scale, vec, 0, (const float*)nullptr, (float*)nullptr);
 }
 
 extern "C" int mmvae_adam_step_copy(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
@@ -1156,11 +1205,8 @@ extern "C" int mmvae_adam_step_copy(int64_t n, float* param, const float* grad, 
     if (n <= 0 || !param || !grad || !exp_avg || !exp_avg_sq || !state) return MMVAE_ERR_ARG;
     if (copy_n < 0 || copy_n > 65536 || (copy_n > 0 && (!copy_src || !copy_dst))) return MMVAE_ERR_ARG;
     const int vec = aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq);
-    MMVAE_LAUNCH(adam_step_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream, n, param,
-                       grad, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps, weight_decay, grad_scale, vec, copy_n,
-                       copy_src, copy_dst);
-    MMVAE_LAUNCH_CHECK();
-    return MMVAE_OK;
+    return launch_adam_step(n, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps,
+                            weight_decay, grad_scale, vec, copy_n, copy_src, copy_dst);
 }
 
 extern "C" int mmvae_adam_step_jobs(int n_jobs, const mmvae_adam_job* jobs_dev, float* param, const float* grad,

@@ -191,9 +191,13 @@ __device__ __forceinline__ void x3_pack4_lean(f32x2 lo, f32x2 hi, uint2 (&pk)[3]
 
 // Epilogue shared by the fp32-MFMA and the bf16x3-MFMA kernels (the C/D register layout of the 32x32 MFMAs is
 // dtype-independent): col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
-template <int BM, int BN, int WGM, int WGN, int EPI, int TM, int TN>
+// MF16 (standard epilogue only): a 32x32 block was accumulated as 2 x 2 sub-blocks by v_mfma_f32_16x16x32 -- element
+// e = 4 (2 si + sj) + j of the block's 16 registers is row 16 si + 4 (lane >> 4) + j, col 16 sj + (lane & 15).  Either
+// way a lane holds 4 consecutive rows of one column per register group, so the quad transposes below are common.
+template <int BM, int BN, int WGM, int WGN, int EPI, int TM, int TN, bool MF16 = false>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& g, int bm, int bn, int z,
                                               float* lds) {
+    static_assert(!MF16 || EPI == EPI_STD, "the 16x16 accumulator layout has the standard epilogue only");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -218,18 +222,28 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int n = 0; n < TN; ++n) {
-                    const int col = bn * BN + wn * WTN + n * 32 + (l31 & ~3);
-                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                    const bool whole = col + 3 < g.N;  // N % 4 != 0: the group straddling the edge goes element-wise
-                    if (!raw && g.bias && col < g.N) {
-                        if (whole) {
-                            bv = *reinterpret_cast<const f32x4*>(g.bias + col);
-                        } else {
-                            for (int j = 0; j < g.N - col; ++j) bv[j] = g.bias[col + j];
+                    // (MF16: the two 16-column halves of the block have a column group each)
+                    int cols[MF16 ? 2 : 1];
+                    f32x4 bvs[MF16 ? 2 : 1];
+#pragma unroll
+                    for (int h = 0; h < (MF16 ? 2 : 1); ++h) {
+                        const int col = bn * BN + wn * WTN + n * 32 + (MF16 ? 16 * h + (lane & 12) : (l31 & ~3));
+                        cols[h] = col;
+                        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                        if (!raw && g.bias && col < g.N) {
+                            if (col + 3 < g.N) {
+                                bv = *reinterpret_cast<const f32x4*>(g.bias + col);
+                            } else {
+                                for (int j = 0; j < g.N - col; ++j) bv[j] = g.bias[col + j];
+                            }
                         }
+                        bvs[h] = bv;
                     }
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
+                        const int col = cols[MF16 ? (gq & 1) : 0];
+                        const f32x4 bv = bvs[MF16 ? (gq & 1) : 0];
+                        const bool whole = col + 3 < g.N;  // N % 4 != 0: the group straddling the edge goes element-wise
                         float a0 = acc[i][n][4 * gq], a1 = acc[i][n][4 * gq + 1], a2 = acc[i][n][4 * gq + 2],
                               a3 = acc[i][n][4 * gq + 3];
                         // stage 1: exchange with lane ^ 1
@@ -242,7 +256,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
                         v[1] = hi ? t1 : c1;
                         v[2] = hi ? c2 : t0;
                         v[3] = hi ? c3 : t1;
-                        const int row = bm * BM + wm * WTM + i * 32 + 8 * gq + 4 * half + q;
+                        const int row = bm * BM + wm * WTM + i * 32 +
+                                        (MF16 ? 16 * (gq >> 1) + 4 * (lane >> 4) + q : 8 * gq + 4 * half + q);
                         if (row < g.M && col < g.N) {
                             float* cp = C + (int64_t)row * g.ldc + col;
                             v = v * alpha + bv;
@@ -280,12 +295,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int n = 0; n < TN; ++n) {
-                const int col = bn * BN + wn * WTN + n * 32 + l31;
-                if (col >= g.N) continue;
-                const float bv = (!raw && g.bias) ? g.bias[col] : 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int row = bm * BM + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    const int col = bn * BN + wn * WTN + n * 32 + (MF16 ? 16 * ((e >> 2) & 1) + (lane & 15) : l31);
+                    if (col >= g.N) continue;
+                    const float bv = (!raw && g.bias) ? g.bias[col] : 0.f;
+                    const int row = bm * BM + wm * WTM + i * 32 +
+                                    (MF16 ? 16 * (e >> 3) + 4 * (lane >> 4) + (e & 3) : (e & 3) + 8 * (e >> 2) + 4 * half);
                     if (row >= g.M) continue;
                     float* cp = C + (int64_t)row * g.ldc + col;
                     float v = acc[i][n][e] * alpha + bv;
@@ -1027,6 +1043,9 @@ struct XwCursor {
 //       The four k-rows of a transposed read must fall on different 64-byte bank slots: rows of 512 B / 256 B (R = 256 /
 //       128) XOR the slot index with k & 3; rows of 320 B (R = 160) already do.
 enum { SRC_F32 = 0, SRC_PLANES = 1 };
+#ifndef MMVAE_MFMA16
+#define MMVAE_MFMA16 1  // multipliers of the standard-epilogue kernels: v_mfma_f32_16x16x32_bf16 (0: 32x32x16)
+#endif
 #ifndef MMVAE_XW_INTERLEAVE
 #define MMVAE_XW_INTERLEAVE 1  // multipliers: one fragment read pinned behind each MFMA (0: compiler-scheduled reads)
 #endif
@@ -1038,7 +1057,11 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 // stager waits for its pieces itself before the k-tile's barrier.  M0 is written in the statement that reads it.
 __device__ __forceinline__ void xw_glds16(const char* base, unsigned off, unsigned lds_addr) {
     unsigned keep;
-    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);  // (wave-uniform by construction; the "s" operand needs it provable)
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);  // (wave-uniform by construction; the "s" operands need it provable)
+    const unsigned long long b64 = reinterpret_cast<unsigned long long>(base);
+    base = reinterpret_cast<const char*>(
+        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
+        (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64));
     asm volatile(
         "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
         : "=&s"(keep)
@@ -1111,6 +1134,17 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
     constexpr bool A_PL = ASRC == SRC_PLANES, B_PL = BSRC == SRC_PLANES;
     constexpr bool ANY_F32 = !A_PL || !B_PL, ANY_PL = A_PL || B_PL;
     constexpr bool A_TR = A_PL && AFORM == FORM_RC, B_TR = B_PL && BFORM == FORM_RC;  // transposed-read images
+    // 16x16x32 MFMAs: the same flops with a quarter of the accumulator registers per instruction -- the chip is
+    // power-limited under this kernel and holds a ~10 % higher rate with them (profiles/r3_mfma_shape.txt, measured in
+    // this kernel: forward 103 -> 91 us).  The fused reconstruction epilogue keeps the 32x32 layout.
+    // Not for TN.  With fp32 operands that kernel is bound by its stagers (in-kernel split + transposing store) and the
+    // short MFMAs take twice the issue slots of the SIMD the stager wave shares (160x256: 127 -> 137 us).  With planes
+    // operands the 16-row fragments come out of the DMA'd k-major image by transposed reads whose four 16-lane groups
+    // address the same 16 operand rows at k-rows 8 apart -- the same banks: 108 -> 128 us; trading the two 32-byte
+    // halves of a slot in every other k-octet to separate them made it 320 us (profiles/r3_mfma16.txt).
+    constexpr bool IS_TN = AFORM == FORM_RC && BFORM == FORM_RC;
+    constexpr bool MF16 = MMVAE_MFMA16 && MMVAE_XW_INTERLEAVE && EPI == EPI_STD && !IS_TN;
+    static_assert(!MF16 || TK >= 2, "the in-place reload of the kept fragments needs two kept blocks");
     static_assert(2 * IMG + XW_SCRATCH <= 160 * 1024, "two images + scratch must fit the CU's LDS");
     __shared__ __attribute__((aligned(16))) char lds[2 * IMG + XW_SCRATCH];
 
@@ -1360,7 +1394,53 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
         else
             return frag(img + 3 * PA + b_row0 + p * PB, block, ks);
     };
+    // 16x16x32 fragments: row l15 of a 16-row sub-block, k = 8 grp .. 8 grp + 7 = chunk grp of the row's 64 bytes; the
+    // transposed reads address k-row 8 grp + q, the sub-block's half of the 64-byte slot
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int coff16 = l15 * XW_ROWB + ((grp ^ ((l15 >> 2) & 3)) << 4);
+    auto tr_lane_off16 = [&](int R, int bg) {  // first transposed read of sub-block 0 of block bg
+        const int slot = (R == 160) ? bg : (bg ^ tq);
+        return (8 * grp + tq) * (2 * R) + slot * 64 + 8 * (lane & 3);
+    };
+    constexpr int tr_odd = 32;  // from sub-block 0 to sub-block 1 of a block
+    int tro16A[(MF16 && A_TR) ? TM : 1], tro16B[(MF16 && B_TR) ? TN : 1];
+    if constexpr (MF16 && A_TR) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) tro16A[i] = tr_lane_off16(BM, wm * TM + i);
+    }
+    if constexpr (MF16 && B_TR) {
+#pragma unroll
+        for (int n = 0; n < TN; ++n) tro16B[n] = tr_lane_off16(BN, wn * TN + n);
+    }
+    auto frag16 = [&](const char* plane_base, int sb) {
+        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(plane_base + sb * (16 * XW_ROWB) + coff16));
+    };
+    auto frag16A = [&](const char* img, int p, int sb) {  // sub-block sb (16 rows) of this wave's A rows, plane p
+        if constexpr (A_TR)
+            return tr_frag(img + p * PA + tro16A[sb >> 1] + ((sb & 1) ? tr_odd : 0), 4 * 2 * BM);
+        else
+            return frag16(img + a_row0 + p * PA, sb);
+    };
+    auto frag16B = [&](const char* img, int p, int sb) {
+        if constexpr (B_TR)
+            return tr_frag(img + 3 * PA + p * PB + tro16B[sb >> 1] + ((sb & 1) ? tr_odd : 0), 4 * 2 * BN);
+        else
+            return frag16(img + 3 * PA + b_row0 + p * PB, sb);
+    };
+    auto frag16K = [&](const char* img, int p, int sb) {  // kept operand
+        if constexpr (KEEP_A)
+            return frag16A(img, p, sb);
+        else
+            return frag16B(img, p, sb);
+    };
+    auto frag16S = [&](const char* img, int p, int sb) {  // streamed operand
+        if constexpr (KEEP_A)
+            return frag16B(img, p, sb);
+        else
+            return frag16A(img, p, sb);
+    };
     // kept side: all TK blocks x 3 planes of a k-step; streamed side: one block x 3 planes, double buffered
+    // (MF16: fk[0] / fk[1] hold the even / odd 16-row sub-blocks of the kept blocks for the whole k-tile)
     bf16x8 fk[2][3][TK], fs[2][3];
     auto load_kept = [&](int set, const char* img, int ks) {
 #pragma unroll
@@ -1395,8 +1475,17 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
 #endif
     if (MMVAE_XW_PRIO) __builtin_amdgcn_s_setprio(MMVAE_XW_PRIO);
     __syncthreads();  // image 0 holds element 0
-    load_kept(0, lds, 0);
-    load_stream(0, lds, 0, 0);
+    if constexpr (MF16) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int sb = 0; sb < 2 * TK; ++sb) fk[sb & 1][p][sb >> 1] = frag16K(lds, p, sb);
+            fs[0][p] = frag16S(lds, p, 0);
+        }
+    } else {
+        load_kept(0, lds, 0);
+        load_stream(0, lds, 0, 0);
+    }
 #if MMVAE_X3_STAMPS
     long long mst[4] = {0, 0, 0, 0};  // before the barrier, in the barrier, behind it, k-tiles
     long long tq_ = clock64();
@@ -1421,6 +1510,79 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
             // sched_barrier -- left to itself the compiler gathers the reads of several blocks into bursts of ~20 and
             // the MFMAs behind a burst wait for it (37.8 cycles per MFMA, stamps of r3).  Same reads, same MFMAs, same
             // accumulation order per accumulator: identical results.
+            if constexpr (MF16) {
+                // One k-step of 32 per k-tile; blocks of 16 streamed rows x all kept blocks, 2 x 6 MFMAs of 16 cycles per
+                // kept block.  Reads behind the MFMAs: the next block's streamed fragments behind the first three; the
+                // kept fragments are reloaded in place -- block kb - 1 behind the first MFMAs of block kb in the last
+                // streamed block (behind the k-tile's barrier, from the next image), the last kept block at the start
+                // of the next k-tile's first streamed block.
+#pragma unroll
+                for (int l16 = 0; l16 < 2 * TL; ++l16) {
+                    const int cur = l16 & 1;
+                    const bool last = l16 == 2 * TL - 1;
+                    const char* s_img = last ? nxt : img;
+                    const int s_sb = last ? 0 : l16 + 1;
+                    if (last) {
+#if MMVAE_X3_STAMPS
+                        {
+                            const long long tn_ = clock64();
+                            mst[0] += tn_ - tq_;
+                            tq_ = tn_;
+                        }
+#endif
+                        __syncthreads();
+#if MMVAE_X3_STAMPS
+                        {
+                            const long long tn_ = clock64();
+                            mst[1] += tn_ - tq_;
+                            tq_ = tn_;
+                            mst[3] += 1;
+                        }
+#endif
+                    }
+                    X3_SB();
+#pragma unroll
+                    for (int kb = 0; kb < TK; ++kb) {
+                        // the two 16-row sub-blocks of kept block kb against this streamed sub-block: two independent
+                        // accumulator chains, their MFMAs alternating
+                        const int lb = l16 >> 1, lsub = l16 & 1;
+                        f32x16& blk = KEEP_A ? acc[kb][lb] : acc[lb][kb];
+                        const int gq0 = KEEP_A ? lsub : 2 * lsub, gq1 = KEEP_A ? 2 + lsub : 2 * lsub + 1;
+                        f32x4 c0 = {blk[4 * gq0], blk[4 * gq0 + 1], blk[4 * gq0 + 2], blk[4 * gq0 + 3]};
+                        f32x4 c1 = {blk[4 * gq1], blk[4 * gq1 + 1], blk[4 * gq1 + 2], blk[4 * gq1 + 3]};
+#pragma unroll
+                        for (int m = 0; m < 6; ++m) {
+                            const int pk = (m == 0) ? 2 : (m == 1 || m == 3) ? 1 : 0;               // plane of A
+                            const int ps = (m == 0 || m == 3 || m == 5) ? 0 : (m == 1 || m == 4) ? 1 : 2;  // plane of B
+#pragma unroll
+                            for (int ksub = 0; ksub < 2; ++ksub) {
+                                const bf16x8 am = KEEP_A ? fk[ksub][pk][kb] : fs[cur][pk];
+                                const bf16x8 bq = KEEP_A ? fs[cur][ps] : fk[ksub][ps][kb];
+                                if (ksub == 0)  // smallest terms first
+                                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bq, c0, 0, 0, 0);
+                                else
+                                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bq, c1, 0, 0, 0);
+                                const int u = 2 * m + ksub;  // read unit behind this MFMA
+                                if (kb == 0) {
+                                    if (u < 3) {
+                                        fs[cur ^ 1][u] = frag16S(s_img, u, s_sb);
+                                    } else if (l16 == 0 && u - 3 < 6) {
+                                        // the last kept block's fragments of THIS k-tile (its image is the current one now)
+                                        const int sb = 2 * (TK - 1) + (u - 3) / 3;
+                                        fk[sb & 1][(u - 3) % 3][TK - 1] = frag16K(img, (u - 3) % 3, sb);
+                                    }
+                                } else if (last && u < 6) {  // kept block kb - 1 is done with: the next k-tile's
+                                    const int sb = 2 * (kb - 1) + u / 3;
+                                    fk[sb & 1][u % 3][kb - 1] = frag16K(nxt, u % 3, sb);
+                                }
+                                X3_SB();
+                            }
+                        }
+                        blk[4 * gq0] = c0[0], blk[4 * gq0 + 1] = c0[1], blk[4 * gq0 + 2] = c0[2], blk[4 * gq0 + 3] = c0[3];
+                        blk[4 * gq1] = c1[0], blk[4 * gq1 + 1] = c1[1], blk[4 * gq1 + 2] = c1[2], blk[4 * gq1 + 3] = c1[3];
+                    }
+                }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -1489,6 +1651,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
                     }
                 }
             }
+            }  // (32x32x16 path)
 #else
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -1558,7 +1721,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
 #if MMVAE_X3_STAMPS
         if (tid == 0 && bid < 4096) g_x3_trace[bid * 4 + 2] = wall_clock64();
 #endif
-        gemm_epilogue<BM, BN, WGM, WGN, EPI>(acc, g, bm, bn, z, scratch);
+        gemm_epilogue<BM, BN, WGM, WGN, EPI, TM, TN, MF16>(acc, g, bm, bn, z, scratch);
         if (EPI == EPI_RECON) __syncthreads();
 #if MMVAE_X3_STAMPS
         tq_ = clock64();

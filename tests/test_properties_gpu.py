@@ -105,7 +105,12 @@ def test_full_size_properties_config2():
     assert H.rel_l2(xhat, xh2) < 1e-6
     se_row, d2 = ops.mse_sum_fwd_bwd(xh2, x)
     assert H.rel_l2(se_part.sum(0), se_row) < 1e-5
-    assert H.rel_l2(dP, d2 * (xh2 > 0)) < 1e-5
+    # (the fused kernel and the stand-alone GEMM accumulate in different orders: a pre-activation within rounding of
+    # zero may land on either side; dP follows the fused kernel's own slope)
+    kink = (xhat > 0) != (xh2 > 0)
+    assert int(kink.sum()) <= 1e-5 * kink.numel()
+    assert float(torch.maximum(xhat, xh2)[kink].max()) < 1e-5 if bool(kink.any()) else True
+    assert H.rel_l2(dP, d2 * (xhat > 0)) < 1e-5
     out, _ = ops.elbo_finalize(se_part, None, None, B=B, K=1)
     assert abs(float(out[1]) - float(se_row.double().sum())) <= 1e-5 * float(se_row.double().sum())
     # weight gradient through a probe: u^T (dP^T h) v == (dP u)^T (h v), evaluated in fp64 on the host
