@@ -389,6 +389,8 @@ def main():
         step(n_setup + a.warmup + i)
         if marks:
             marks[i + 1].record()
+    if a.mode == "train" and hasattr(model, "_flush_engine"):
+        model._flush_engine()  # the last step's deferred expert update belongs to the timed work (engine.defer_tail)
     sync()
     el = time.perf_counter() - t0
     if feed is not None:

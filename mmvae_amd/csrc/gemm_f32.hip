@@ -469,52 +469,55 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(const GemmArgs g) {
                 using I3 = std::integral_constant<int, 3>;
                 using I4 = std::integral_constant<int, 4>;
                 using I5 = std::integral_constant<int, 5>;
+// (two 16x16x32 MFMAs in place of each of these, as in the wave-specialised kernel, bought this loop 4 %: its MFMAs
+// share their wave's issue slots with the in-kernel split -- not worth a second reconstruction epilogue)
+#define X3_MFMA(C, A, B) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
 #define X3_GROUP_FS(C, A2, A1, A0, B0, B1, B2, U, RD, FS)                  \
-    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B0, C, 0, 0, 0);       \
+    X3_MFMA(C, A2, B0);       \
     chunk(U, I0{});                                                        \
     FS(0);                                                                 \
     X3_SB();                                                               \
-    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, C, 0, 0, 0);       \
+    X3_MFMA(C, A1, B1);       \
     chunk(U, I1{});                                                        \
     X3_SB();                                                               \
-    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B2, C, 0, 0, 0);       \
+    X3_MFMA(C, A0, B2);       \
     chunk(U, I2{});                                                        \
     FS(2);                                                                 \
     X3_SB();                                                               \
-    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, C, 0, 0, 0);       \
+    X3_MFMA(C, A1, B0);       \
     chunk(U, I3{});                                                        \
     RD(0);                                                                 \
     FS(3);                                                                 \
     X3_SB();                                                               \
-    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B1, C, 0, 0, 0);       \
+    X3_MFMA(C, A0, B1);       \
     chunk(U, I4{});                                                        \
     RD(1);                                                                 \
     FS(4);                                                                 \
     X3_SB();                                                               \
-    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, C, 0, 0, 0);       \
+    X3_MFMA(C, A0, B0);       \
     chunk(U, I5{});                                                        \
     RD(2);                                                                 \
     FS(5);                                                                 \
     X3_SB();
 #define X3_GROUP(C, A2, A1, A0, B0, B1, B2, U, RD)                        \
-    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B0, C, 0, 0, 0);       \
+    X3_MFMA(C, A2, B0);       \
     chunk(U, I0{});                                                        \
     X3_SB();                                                               \
-    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, C, 0, 0, 0);       \
+    X3_MFMA(C, A1, B1);       \
     chunk(U, I1{});                                                        \
     X3_SB();                                                               \
-    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B2, C, 0, 0, 0);       \
+    X3_MFMA(C, A0, B2);       \
     chunk(U, I2{});                                                        \
     X3_SB();                                                               \
-    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, C, 0, 0, 0);       \
+    X3_MFMA(C, A1, B0);       \
     chunk(U, I3{});                                                        \
     RD(0);                                                                 \
     X3_SB();                                                               \
-    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B1, C, 0, 0, 0);       \
+    X3_MFMA(C, A0, B1);       \
     chunk(U, I4{});                                                        \
     RD(1);                                                                 \
     X3_SB();                                                               \
-    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, C, 0, 0, 0);       \
+    X3_MFMA(C, A0, B0);       \
     chunk(U, I5{});                                                        \
     RD(2);                                                                 \
     X3_SB();
