@@ -40,6 +40,8 @@ def parse():
                          "feed and PCIe transfer inside the timed region)")
     ap.add_argument("--genes", default="", help="diagnostics: comma-separated gene counts replacing the config's (one per "
                                                 "modality), e.g. 60530,52437 = the reference's human / mouse widths")
+    ap.add_argument("--hidden", type=int, default=0, help="diagnostics: width of the experts' hidden layer next to the "
+                    "genes (1024 in every BASELINE config; e.g. 1000 = not a multiple of the 32-wide k-tile)")
     ap.add_argument("--sim-comm", default="", help="diagnostics: CUS,LDS_KB,MICROS -- a stand-in for a collective beside the "
                                                    "step: that many workgroups holding that much LDS each spin on a side "
                                                    "stream for that long, started with every step (DESIGN.md section 7)")
@@ -244,9 +246,9 @@ def build_model(a, cfg, device):
     from mmvae_amd import instantiate, synthetic
 
     torch.manual_seed(0)
-    if a.genes:
+    if a.genes or a.hidden:
         return synthetic.build_model(cfg["experts"], adversarial=cfg["adversarial"], n_samples=cfg["K"],
-                                     use_engine=not a.no_engine, seed=0)
+                                     use_engine=not a.no_engine, seed=0, **({"h1": a.hidden} if a.hidden else {}))
     if cfg["adversarial"]:  # unique_expression_<condition>.csv files with the reference's class counts
         import tempfile
 
@@ -431,7 +433,7 @@ def main():
             if k.startswith(("loss/", "recon_loss/", "kl_loss/"))}
     parity = None
     if (leg is not None and world == 1 and rank == 0 and a.config == "c2" and a.input == "dense" and not a.genes
-            and not a.no_parity):
+            and not a.hidden and not a.no_parity):
         i_par = n_setup + a.warmup + a.steps + 8
         eid_par = eids[i_par % len(eids)]
         x_par, m_par = data[eid_par][(i_par // len(eids)) % n_res]
@@ -461,8 +463,8 @@ def main():
                        "path": "module" if (a.no_engine or not model._engine) else "engine(hipGraph)"},
             "rccl_ranks": torch.distributed.get_world_size() if backend_name == "nccl" else 0,
             "dist_backend": backend_name,
-            "step_flops_per_cell": synthetic.flops_per_cell(G, K),
-            "step_tflops": synthetic.flops_per_cell(G, K) * cells_per_s / world / 1e12,
+            "step_flops_per_cell": synthetic.flops_per_cell(G, K, **({"h1": a.hidden} if a.hidden else {})),
+            "step_tflops": synthetic.flops_per_cell(G, K, **({"h1": a.hidden} if a.hidden else {})) * cells_per_s / world / 1e12,
             "last_losses": loss, "setup_steps": n_setup,
         }
         if leg is not None:
@@ -493,7 +495,7 @@ def main():
                 kernels.append({"name": "adam_expert", "what": "fused clip + Adam over the active expert's flat arenas",
                                 "shape": meta.get("shape"), "us": tk * 1e6, "bound": "hbm", "tb_per_s": by / tk / 1e12,
                                 "frac": by / tk / (HBM_PEAK_TBS * 1e12), "cus": 256})
-            step_tf = synthetic.flops_per_cell(G, K) * cells_per_s / world / 1e12
+            step_tf = synthetic.flops_per_cell(G, K, **({"h1": a.hidden} if a.hidden else {})) * cells_per_s / world / 1e12
             out["roofline"] = {
                 "bound": "mfma",
                 "kernel": ("the five G-wide GEMMs of the step, time-weighted (bf16x3 MFMA: 6 bf16 products per fp32 product)"

@@ -127,6 +127,12 @@ int mmvae_decoder_recon_f32(int B, int G, int H, const float* h, int64_t ldh, co
 int mmvae_decoder_recon_rows_f32(int rows, int x_rows, int G, int H, const float* h, int64_t ldh, const float* W,
                                  int64_t ldw, const float* bias, const float* x, int64_t ldx, float* xhat,
                                  int64_t ldxhat, float* dP, int64_t lddp, float* se_part, mmvae_stream_t stream);
+/* Launch state for the fused decoder / reconstruction entry points (host side, read when a launch is enqueued): on = the
+ * caller vouches that h has ZERO columns from H up to the next multiple of 32 inside its leading dimension and that
+ * every row of W may be read that far (the next row; 32 readable floats behind the last one).  A hidden width that is
+ * not a multiple of the 32-wide k-tile (e.g. 1000) then takes the pipelined kernels over the padded K instead of the
+ * guarded loop (2 x slower).  Results: the products beyond H are exact zeros. */
+int mmvae_recon_set_h_kpad(int on);
 /* The same launch, also leaving the column sums of dP (= the gradient of the layer's bias when the rows are not
  * re-weighted afterwards, K = 1) as per-row-tile partials: col_part [mmvae_recon_row_tiles(rows)][G], to be summed over
  * the row tiles in order (mmvae_sum_parts_batch).  col_part = NULL: exactly mmvae_decoder_recon_rows_f32.  Saves the

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "mmvae_gemm_set_precision": (_i, [_i]),
     "mmvae_gemm_set_workgroup_cap": (_i, [_i]),
     "mmvae_adam_set_workgroups": (_i, [_i]),
+    "mmvae_recon_set_h_kpad": (_i, [_i]),
     "mmvae_adam_get_workgroups": (_i, []),
     "mmvae_gemm_set_x3w": (_i, [_i]),
     "mmvae_gemm_get_x3w": (_i, []),

@@ -1264,31 +1264,40 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
             if constexpr (!B_PL) ob.template stage_and_reload<S_>(Bs, st, x3p_base<BFORM>(g.B, g.ldb, ld_c.bn * BN, ld_c.kt), nothing);
             bump(ld_c);
         };
-        // mixed kernels (A pre-split, B fp32): the DMA pieces of A are dealt out behind the split of B's units -- a piece
+        // mixed kernels (one operand pre-split, the other fp32): the DMA pieces are dealt out behind the split of the fp32
+        // operand's units -- a piece
         // costs ~125 cycles of VMEM issue while every CU streams (stamps of r3: 12 pieces back to back held the wave for
         // 1 450 cycles before its split work even began) -- and ahead of the re-loads that follow each unit, so that
         // only TRAIL compiler-visible loads are younger than the last piece: the wait before the barrier is counted.
         auto step_mixed = [&](auto SET, int img) {
             constexpr int S_ = decltype(SET)::value;
-            static_assert(!ANY_F32 || !ANY_PL || (A_PL && !B_PL), "mixed kernels: A pre-split, B fp32");
-            if constexpr (A_PL && !B_PL) {
-                using XB = XwOperand<BFORM, BN>;
-                constexpr int NPA = XwPlanes<AFORM, BM>::NP;
-                constexpr int PPU = (NPA + XB::NU - 1) / XB::NU;  // pieces per unit of B
+            if constexpr (A_PL != B_PL) {
+                // F = the fp32 operand (split here), P = the pre-split one (DMA)
+                using XF = std::conditional_t<A_PL, XwOperand<BFORM, BN>, XwOperand<AFORM, BM>>;
+                constexpr int NPP = std::conditional_t<A_PL, XwPlanes<AFORM, BM>, XwPlanes<BFORM, BN>>::NP;
+                constexpr int PPU = (NPP + XF::NU - 1) / XF::NU;  // pieces per unit of the fp32 operand
                 if (dm_c.w != dma_w) {
-                    oa.offsets(g.ldap, g.a_pstride, dm_c.bm * BM, g.M, dlane, wv);
+                    if constexpr (A_PL) oa.offsets(g.ldap, g.a_pstride, dm_c.bm * BM, g.M, dlane, wv);
+                    if constexpr (B_PL) ob.offsets(g.ldbp, g.b_pstride, dm_c.bn * BN, g.N, dlane, wv);
                     dma_w = dm_c.w;
                 }
-                const unsigned ia = lds0 + img * IMG;
-                const char* abase = xwp_base<AFORM>(g.Ap, g.ldap, dm_c.kt);
+                const unsigned ip = lds0 + img * IMG + (A_PL ? 0 : 3 * PA);
                 refresh_offsets();
-                ob.template stage_and_reload<S_>(lds + img * IMG + 3 * PA, st,
-                                                 x3p_base<BFORM>(g.B, g.ldb, ld_c.bn * BN, ld_c.kt),
-                                                 [&](int u) { oa.issue_range(abase, ia, wv, u * PPU, (u + 1) * PPU); });
+                if constexpr (A_PL) {
+                    const char* pbase = xwp_base<AFORM>(g.Ap, g.ldap, dm_c.kt);
+                    ob.template stage_and_reload<S_>(lds + img * IMG + 3 * PA, st,
+                                                     x3p_base<BFORM>(g.B, g.ldb, ld_c.bn * BN, ld_c.kt),
+                                                     [&](int u) { oa.issue_range(pbase, ip, wv, u * PPU, (u + 1) * PPU); });
+                } else {
+                    const char* pbase = xwp_base<BFORM>(g.Bp, g.ldbp, dm_c.kt);
+                    oa.template stage_and_reload<S_>(lds + img * IMG, st,
+                                                     x3p_base<AFORM>(g.A, g.lda, ld_c.bm * BM, ld_c.kt),
+                                                     [&](int u) { ob.issue_range(pbase, ip, wv, u * PPU, (u + 1) * PPU); });
+                }
                 bump(ld_c);
                 bump(dm_c);
-                if (XB::TRAIL == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // every piece has landed
-                if (XB::TRAIL == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                if (XF::TRAIL == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // every piece has landed
+                if (XF::TRAIL == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             }
         };
         // one k-tile of the stream into image `img`

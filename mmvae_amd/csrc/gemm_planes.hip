@@ -66,7 +66,9 @@ namespace mmvae_detail {
 // dP^T . h -- both operands are activations / gradients whose producers can write planes), NT and NN with a pre-split A
 // (x, dP) against the fp32 weights (split in the kernel: the optimiser rewrites them every step).
 bool x3w_planes_combo(int layout, bool a_pl, bool b_pl) {
-    if (layout == MMVAE_GEMM_TN) return a_pl && b_pl;
+    // (TN with only B pre-split: dW = dP^T h with the small operand h from its layer tail -- on the 160x256 tile B is
+    // 256 of the 416 rows the stagers would otherwise split per k-tile)
+    if (layout == MMVAE_GEMM_TN) return b_pl;
     return a_pl && !b_pl;
 }
 
@@ -98,8 +100,10 @@ int launch_x3w_planes(int layout, int tile_id, bool a_pl, bool b_pl, int epi, co
         else                                                                                                            \
             MMVAE_LAUNCH((gemm_x3w_kernel<AF, BF, 256, 128, 2, 2, EPI_STD, AS, BS>), dim3(nblocks), dim3(512), 0, s, g); \
     } while (0)
-    if (layout == MMVAE_GEMM_TN)
+    if (layout == MMVAE_GEMM_TN && a_pl)
         XWP(FORM_RC, FORM_RC, SRC_PLANES, SRC_PLANES);
+    else if (layout == MMVAE_GEMM_TN)
+        XWP(FORM_RC, FORM_RC, SRC_F32, SRC_PLANES);
     else if (layout == MMVAE_GEMM_NT)
         XWP(FORM_KC, FORM_KC, SRC_PLANES, SRC_F32);
     else

@@ -196,6 +196,7 @@ class StepEngine:
         self.planes = os.environ.get("MMVAE_PLANES", "1") != "0"
         self.planes_enc = os.environ.get("MMVAE_PLANES_ENC", "1") != "0"  # x, dY -> the first layer's weight gradient
         self.planes_dec = os.environ.get("MMVAE_PLANES_DEC", "0") != "0"  # dP, h -> the last layer's dW and dX
+        self.planes_dec_h = os.environ.get("MMVAE_PLANES_DEC_H", "1") != "0"  # h alone -> B of the last layer's dW
         if os.environ.get("MMVAE_SIDE_STREAM", "0") != "0":
             side_stream = True
         self.side_stream_asked = bool(side_stream)  # the caller / environment asked for it (not only the dW branch)
@@ -1201,7 +1202,12 @@ class _Plan:
                            and lib.mmvae_gemm_planes_supported(TN, l0.n_out, l0.n_in, self.kpad(B), 1, 1, 1))
         self.xp = _PlaneBuf(eng, f"xp.{l0.n_in}", B, l0.n_in) if self.pl_enc else None
         self.dYp = _PlaneBuf(eng, f"dYp.{l0.n_out}", B, l0.n_out) if self.pl_enc else None
-        self.hp = _PlaneBuf(eng, f"hp.{lastl.n_in}", R, lastl.n_in) if self.pl_dec else None
+        # the last hidden activations alone (3 MB of planes from their layer tail): B of dW = dP^T h, the wider operand of
+        # that product's tile -- its stagers then split dP only
+        self.pl_dec_h = bool(pl_on and eng.planes_dec_h and not self.pl_dec and lastl.n_in % 8 == 0
+                             and len(self.dec_layers) >= 2
+                             and lib.mmvae_gemm_planes_supported(TN, G, lastl.n_in, self.kpad(R), 1, 0, 1))
+        self.hp = _PlaneBuf(eng, f"hp.{lastl.n_in}", R, lastl.n_in) if (self.pl_dec or self.pl_dec_h) else None
         self.dPp = _PlaneBuf(eng, f"dPp.{G}", R, G) if self.pl_dec else None
         self._x_split_ev = None
         x_split_late = False
@@ -1278,8 +1284,8 @@ class _Plan:
         for i, l in enumerate(self.dec_layers[:-1]):
             cur = self.fwd_layer(f"{self.eid}.dec{i}.K{K}", l, cur, ld, R, training=train,
                                  mask_stream=len(self.enc_layers) + i,
-                                 planes_out=self.hp if (self.pl_dec and i == len(self.dec_layers) - 2) else None,
-                                 split_job=None if (self.pl_dec and i == len(self.dec_layers) - 2)
+                                 planes_out=self.hp if (self.hp is not None and i == len(self.dec_layers) - 2) else None,
+                                 split_job=None if (self.hp is not None and i == len(self.dec_layers) - 2)
                                  else self._next_x_split_job(l, R))
             ld = l.n_out
         for job in getattr(self, "_x_split_jobs", []):  # tails the chain did not have: passes of their own
@@ -1307,9 +1313,31 @@ class _Plan:
                        last.n_in, _p(last.b), _p(x), ldx, None, 0, _p(self.dP) if keep_dp else None, G, *self.dPp.args(),
                        _p(self.se_part), _p(self.dp_colpart), probe=("dec_l2_recon", 2.0 * R * G * last.n_in))
         else:
-            self._emit(lib.mmvae_decoder_recon_rows_colsum_f32, R, B, G, last.n_in, _p(cur), ld, _p(last.W), last.n_in,
+            h_in, ld_h, kpad = cur, ld, False
+            if last.n_in % 32 != 0 and lib.mmvae_gemm_get_precision() == 1:
+                # a hidden width off the 32-wide k-tile (1000): the fused kernel's pipelined loop needs whole k-tiles --
+                # it gets a copy of h in a buffer padded with zero columns (a 2 MB pass: ~4 us) and runs over the padded
+                # K; the weights' rows are read on into the next row / the arena's slack, against those zeros
+                # (mmvae_recon_set_h_kpad; the guarded loop it replaces: 242 against 123 us at C2's sizes)
+                Kp = (last.n_in + 31) // 32 * 32
+                hpad = eng.buf(f"hpad.{R}.{last.n_in}", (R, Kp))
+                self._defer_sum(cur, 1, 0, R, last.n_in, ld, hpad, Kp)
+                self._flush_sums()
+                h_in, ld_h, kpad = hpad, Kp, True
+            self._emit(lib.mmvae_decoder_recon_rows_colsum_f32, R, B, G, last.n_in, _p(h_in), ld_h, _p(last.W), last.n_in,
                        _p(last.b), _p(x), ldx, None, 0, _p(self.dP), G, _p(self.se_part), _p(self.dp_colpart),
                        probe=("dec_l2_recon", 2.0 * R * G * last.n_in))
+            if kpad:  # the launch state brackets the launch
+                launch = self._cur.pop()
+
+                def recon_kpad(launch=launch):
+                    lib.mmvae_recon_set_h_kpad(1)
+                    try:
+                        launch()
+                    finally:
+                        lib.mmvae_recon_set_h_kpad(0)
+
+                self._cur.append(recon_kpad)
         self.probe_meta["dec_l2_recon"].update(bound="mfma", cus=0, planes=bool(self.pl_dec),
                                                shape=f"NT {R}x{G}x{last.n_in} + reconstruction epilogue")
         self.recon_row = eng.buf("recon_row", (B,))
@@ -1356,7 +1384,7 @@ class _Plan:
             if early_branch:  # the bias gradient (a pass over dP) is needed by the optimiser only
                 early_calls += self._take(start)
         dx_pl = (self.dPp, None) if self.pl_dec else None
-        dw_pl = (self.dPp, self.hp) if self.pl_dec else None
+        dw_pl = (self.dPp, self.hp) if self.pl_dec else ((None, self.hp) if self.pl_dec_h else None)
         if side_dw:  # input gradient first (the chain waits for it), then the weight gradient on the side branch
             self._probe_next = "dec_l2_dx"
             S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in, planes=dx_pl)

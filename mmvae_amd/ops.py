@@ -270,8 +270,11 @@ def decoder_recon(
     col_part: Optional[torch.Tensor] = None,
     h_planes: Optional["Planes"] = None,
     dP_planes: Optional["Planes"] = None,
+    h_kpad: bool = False,
 ):
     """Fused last decoder layer + squared error.  h [R,H] (R = K*B rows), W [G,H], x [B,G].
+    h_kpad: h is a view of a buffer whose columns H .. round_up(H, 32) - 1 are ZERO and W's rows may be read that far
+    (mmvae_recon_set_h_kpad): a hidden width that is not a multiple of 32 then takes the pipelined kernels.
     h_planes: the pre-split h (mmvae_decoder_recon_planes_f32; h stays the fallback).
     Returns (xhat [R,G] | None, dP [R,G] | None, se_part [tiles, R]).  col_part [recon_row_tiles(R), G] (optional):
     receives the column sums of dP per row tile (their sum over the tiles is the bias gradient when K = 1)."""
@@ -303,10 +306,16 @@ def decoder_recon(
         )
         _lib.check(rc, "mmvae_decoder_recon_planes_f32")
         return xhat, dP, se_part
-    rc = lib.mmvae_decoder_recon_rows_colsum_f32(
-        R, B, G, H, _ptr(h), ldh, _ptr(W), ldw, _ptr(bias), _ptr(x), ldx, _ptr(xhat), ldxh, _ptr(dP), lddp,
-        _ptr(se_part), _ptr(col_part), _stream(),
-    )
+    if h_kpad and ldh < (H + 31) // 32 * 32:
+        raise ValueError("decoder_recon: h_kpad needs h's leading dimension to cover the padded width")
+    lib.mmvae_recon_set_h_kpad(1 if h_kpad else 0)
+    try:
+        rc = lib.mmvae_decoder_recon_rows_colsum_f32(
+            R, B, G, H, _ptr(h), ldh, _ptr(W), ldw, _ptr(bias), _ptr(x), ldx, _ptr(xhat), ldxh, _ptr(dP), lddp,
+            _ptr(se_part), _ptr(col_part), _stream(),
+        )
+    finally:
+        lib.mmvae_recon_set_h_kpad(0)
     _lib.check(rc, "mmvae_decoder_recon_rows_colsum_f32")
     return xhat, dP, se_part
 

@@ -65,10 +65,11 @@ class ParamArena:
                 n = _pad4(n)
         self.offsets: List[int] = [placed[id(p)] for p in self.params]
         self.numel = n
-        # 16 spare elements behind each arena: its tensors may be read as rows-contiguous GEMM operands in 16-byte groups
-        # up to 12 bytes past their end (MMVAE_GEMM_OPERAND_SLACK)
-        self.data = torch.zeros(n + 16, dtype=torch.float32, device=dev)[:n]
-        self.grad = torch.zeros(n + 16, dtype=torch.float32, device=dev)[:n]
+        # 32 spare elements behind each arena: its tensors may be read as rows-contiguous GEMM operands in 16-byte groups
+        # up to 12 bytes past their end (MMVAE_GEMM_OPERAND_SLACK), a weight matrix row up to the next multiple of 32
+        # columns (mmvae_recon_set_h_kpad)
+        self.data = torch.zeros(n + 32, dtype=torch.float32, device=dev)[:n]
+        self.grad = torch.zeros(n + 32, dtype=torch.float32, device=dev)[:n]
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         for p, off in zip(self.params, self.offsets):

@@ -212,6 +212,34 @@ def test_decoder_recon(ops, R, B, G, H):
     assert torch.equal(se3, se_part)
 
 
+@pytest.mark.parametrize("R,B,G,H", [(512, 512, 20000, 1000), (512, 512, 20000, 1016), (256, 128, 5008, 72)])
+def test_decoder_recon_hidden_width_off_the_k_tile(ops, R, B, G, H):
+    """A hidden width that is not a multiple of 32 on the pipelined kernels (mmvae_recon_set_h_kpad): h in a buffer padded
+    with zero columns, W's rows read on into the next row (the last one into readable slack) -- same results as the
+    guarded loop (to rounding) and as fp64."""
+    h, bias = rnd(R, H, seed=1), rnd(G, seed=3, scale=0.1)
+    x = rnd(B, G, seed=4).abs()
+    Hp = (H + 31) // 32 * 32
+    Wbuf = torch.zeros(G * H + 32)                      # an arena: 32 readable floats behind the last row
+    Wbuf[:G * H] = rnd(G, H, seed=2, scale=0.2).reshape(-1)
+    Wbuf[G * H:] = 3.0                                  # (finite garbage there must not reach the result)
+    Wd = dev(Wbuf)[:G * H].view(G, H)
+    hpad = torch.zeros(R, Hp, device="cuda")
+    hpad[:, :H] = dev(h)
+    P = h.double() @ Wbuf[:G * H].view(G, H).double().t() + bias.double()
+    xh = P.clamp_min(0)
+    d = xh - x.double().repeat(R // B, 1)
+    col_part = torch.zeros(ops.recon_row_tiles(R), G, device="cuda")
+    xhat, dP, se_part = ops.decoder_recon(hpad[:, :H], Wd, dev(bias), dev(x), col_part=col_part, h_kpad=True)
+    assert rel_l2(xhat, xh) < 2e-6
+    assert rel_l2(se_part.sum(0), (d * d).sum(1)) < 1e-5
+    clear = P.abs() > 1e-4
+    assert rel_l2(dP.cpu().double()[clear], (2 * d * (P > 0))[clear]) < 1e-5
+    assert rel_l2(col_part.sum(0), dP.double().sum(0)) < 1e-6
+    xhat_g, _, se_g = ops.decoder_recon(dev(h), Wd, dev(bias), dev(x))  # the guarded loop
+    assert rel_l2(xhat, xhat_g) < 2e-6 and rel_l2(se_part.sum(0), se_g.sum(0)) < 1e-5
+
+
 # --------------------------------------------------------------------------------------------------- FC epilogues
 @pytest.mark.parametrize("B,N,S", [(8, 48, 1), (33, 72, 3), (512, 1024, 4), (128, 100, 1)])
 @pytest.mark.parametrize("has_bn", [True, False])

@@ -55,6 +55,8 @@ CASES = [
     (TN, 1024, 20000, 512, "ab", False),  # dW of the expert encoder's first layer at C2
     (TN, 20000, 1024, 512, "ab", False),  # dW of the expert decoder's last layer
     (TN, 2000, 5008, 480, "ab", False),   # ragged tiles (extents % 8 == 0 only), K padded to 512 over the slack rows
+    (TN, 20000, 1024, 512, "b", False),   # the same product with only h pre-split (A = dP split in the kernel)
+    (TN, 2000, 5008, 480, "b", False),
     (NT, 512, 1024, 20000, "a", True),    # forward of the first layer: x pre-split, W fp32
     (NN, 512, 1024, 20000, "a", True),    # dX of the last layer: dP pre-split, W fp32
     (NT, 500, 1024, 8192, "a", True),
@@ -74,13 +76,14 @@ def test_gemm_planes_bitwise_and_fp64(ops, layout, M, N, K, pre, slabs):
     a[:, ::3] = 0  # count-like sparsity
     ref = (a.double().t() @ b.double() if layout == TN else a.double() @ b.double().t() if layout == NT
            else a.double() @ b.double())
-    ap = ops.split_planes(a)
+    ap = ops.split_planes(a) if "a" in pre else None
     bp = ops.split_planes(b) if "b" in pre else None
     kw = dict(K=Kp if layout == TN else None, raw_slabs=slabs, want_sq=(layout == TN))
     lib = __import__("mmvae_amd._lib", fromlist=["load"]).load()
-    assert lib.mmvae_gemm_planes_supported(layout, M, N, Kp if layout == TN else K, 0 if slabs else 1, 1, int("b" in pre)) == 1
+    assert lib.mmvae_gemm_planes_supported(layout, M, N, Kp if layout == TN else K, 0 if slabs else 1, int("a" in pre),
+                                           int("b" in pre)) == 1
     f32 = ops.gemm_planes(layout, a, b, **kw)
-    pl = ops.gemm_planes(layout, None, b if bp is None else None, a_planes=ap, b_planes=bp, **kw)
+    pl = ops.gemm_planes(layout, a if ap is None else None, b if bp is None else None, a_planes=ap, b_planes=bp, **kw)
     if layout == TN:
         (f32, sq0), (pl, sq1) = f32, pl
         assert torch.equal(sq0, sq1)
