@@ -246,9 +246,9 @@ def build_model(a, cfg, device):
     from mmvae_amd import instantiate, synthetic
 
     torch.manual_seed(0)
-    if a.genes or a.hidden:
+    if a.genes or getattr(a, "hidden", 0):
         return synthetic.build_model(cfg["experts"], adversarial=cfg["adversarial"], n_samples=cfg["K"],
-                                     use_engine=not a.no_engine, seed=0, **({"h1": a.hidden} if a.hidden else {}))
+                                     use_engine=not a.no_engine, seed=0, **({"h1": a.hidden} if getattr(a, "hidden", 0) else {}))
     if cfg["adversarial"]:  # unique_expression_<condition>.csv files with the reference's class counts
         import tempfile
 

@@ -1321,8 +1321,11 @@ class _Plan:
                 # (mmvae_recon_set_h_kpad; the guarded loop it replaces: 242 against 123 us at C2's sizes)
                 Kp = (last.n_in + 31) // 32 * 32
                 hpad = eng.buf(f"hpad.{R}.{last.n_in}", (R, Kp))
+                # (reductions / grouped GEMMs queued so far wait for their own flush)
+                pending, self._sum_jobs, pending_g, self._gemm_jobs = self._sum_jobs, [], self._gemm_jobs, []
                 self._defer_sum(cur, 1, 0, R, last.n_in, ld, hpad, Kp)
                 self._flush_sums()
+                self._sum_jobs, self._gemm_jobs = pending, pending_g
                 h_in, ld_h, kpad = hpad, Kp, True
             self._emit(lib.mmvae_decoder_recon_rows_colsum_f32, R, B, G, last.n_in, _p(h_in), ld_h, _p(last.W), last.n_in,
                        _p(last.b), _p(x), ldx, None, 0, _p(self.dP), G, _p(self.se_part), _p(self.dp_colpart),

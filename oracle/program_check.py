@@ -135,9 +135,9 @@ def check_step(model, eid: str, x: torch.Tensor, meta, step_index: int, strict: 
         keep = masks.get(name + ".dr")
         if keep is not None:  # a dropped unit's slope never reaches a gradient
             diff &= keep.reshape(y.shape)
-        if name == last:  # dP is also zero where xhat == x exactly
+        if name == last:  # dP is also zero where xhat == x exactly (the step's xhat: within rounding of the oracle's)
             xr = x.detach().cpu()
-            diff &= ~((y > 0) & ~slope.reshape(y.shape) & (torch.relu(y) == xr))
+            diff &= ~((y > 0) & ~slope.reshape(y.shape) & torch.isclose(torch.relu(y), xr, rtol=1e-5, atol=1e-6))
         n = int(diff.sum())
         if n:
             rms = float(y.double().pow(2).mean().sqrt())
