@@ -488,8 +488,11 @@ def main():
                     tr_n += 1
                 kernels.append({"name": tag, "what": what, "shape": meta.get("shape"), "us": tk * 1e6,
                                 "tflops": fl / tk / 1e12, "frac": fl / tk / (peak * 1e12),
-                                "cus": meta.get("cus") or 256, "operands": "pre-split bf16 planes (LDS-DMA)" if meta.get("planes")
-                                else "fp32, split in the kernel", "traffic": tr})
+                                "cus": meta.get("cus") or 256, "operands": {"": "fp32, split in the kernel", "A+B": "pre-split bf16 planes (LDS-DMA)",
+                                             "A": "A pre-split bf16 planes (LDS-DMA), B fp32 split in the kernel",
+                                             "B": "A fp32 split in the kernel, B pre-split bf16 planes (LDS-DMA)"
+                                             }.get(meta.get("planes") or "", "fp32, split in the kernel"),
+                                "traffic": tr})
             if "adam_expert" in leg:
                 tk, by, meta = leg["adam_expert"]
                 kernels.append({"name": "adam_expert", "what": "fused clip + Adam over the active expert's flat arenas",

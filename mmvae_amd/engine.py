@@ -484,6 +484,13 @@ class StepEngine:
         plan.log(model, expert_id)
 
 
+def _planes_desc(planes) -> str:
+    """Which operands of a launch are pre-split planes ("", "A", "B", "A+B"): probe metadata."""
+    if not planes:
+        return ""
+    return "+".join(n for n, p in zip("AB", planes) if p is not None)
+
+
 class _Plan:
     def __init__(self, eng: StepEngine, eid: str, B: int, K: int, explicit: bool, x: torch.Tensor, mode: str = "train",
                  iwae: bool = False):
@@ -671,7 +678,7 @@ class _Plan:
             if rc != 0:
                 raise _lib.HipLibraryError(f"mmvae_gemm_f32_sq failed with code {rc} (layout {layout}, {M}x{N}x{K})")
 
-        launch = self._probed(tag, 2.0 * M * N * K, launch_gemm, bound="mfma", cus=side_cap, planes=bool(planes),
+        launch = self._probed(tag, 2.0 * M * N * K, launch_gemm, bound="mfma", cus=side_cap, planes=_planes_desc(planes),
                               shape=f"{('NT', 'NN', 'TN')[layout]} {M}x{N}x{K}")
 
         if side_cap:  # persistent grid capped to `side_cap` workgroups: the CUs left over serve another branch
@@ -904,7 +911,7 @@ class _Plan:
             if rc != 0:
                 raise _lib.HipLibraryError(f"mmvae_gemm_f32 failed with code {rc} (layout {layout}, {M}x{N}x{K})")
 
-        launch = self._probed(tag, 2.0 * M * N * K, launch_gemm, bound="mfma", cus=0, planes=bool(planes),
+        launch = self._probed(tag, 2.0 * M * N * K, launch_gemm, bound="mfma", cus=0, planes=_planes_desc(planes),
                               shape=f"{('NT', 'NN', 'TN')[layout]} {M}x{N}x{K}" + (f" split-K {sk}" if sk > 1 else ""))
 
         if use_ws == "side":
@@ -1341,7 +1348,7 @@ class _Plan:
                         lib.mmvae_recon_set_h_kpad(0)
 
                 self._cur.append(recon_kpad)
-        self.probe_meta["dec_l2_recon"].update(bound="mfma", cus=0, planes=bool(self.pl_dec),
+        self.probe_meta["dec_l2_recon"].update(bound="mfma", cus=0, planes="",
                                                shape=f"NT {R}x{G}x{last.n_in} + reconstruction epilogue")
         self.recon_row = eng.buf("recon_row", (B,))
         if self.iwae:

@@ -1,6 +1,6 @@
 """Launches the five G-wide GEMMs of the C2 step in the operand forms the engine uses (the expert encoder's first
 layer: forward, weight gradient from pre-split planes; the decoder's last layer: fused forward + reconstruction, input
-gradient, weight gradient) a few times each, for rocprofv3 --pmc passes (one counter group per run):
+gradient, weight gradient with h pre-split) a few times each, for rocprofv3 --pmc passes (one counter group per run):
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out -o p -- python3 tools/roofline_kernel.py
 usage: roofline_kernel.py [family | fwd | dw | dw_planes]"""
 import os
@@ -30,7 +30,7 @@ dY, h = padded(r(B, H1)), padded(torch.relu(r(B, H1)))
 dP = padded(r(B, G) * (torch.rand(B, G, device=dev, generator=g) < 0.5))
 dW1, dW4 = torch.empty(H1, G, device=dev), torch.empty(G, H1, device=dev)
 sep = torch.empty(ops.recon_tiles(G), B, device=dev)
-Xp, dYp = ops.split_planes(X), ops.split_planes(dY)
+Xp, dYp, hp = ops.split_planes(X), ops.split_planes(dY), ops.split_planes(h)
 which = sys.argv[1] if len(sys.argv) > 1 else "family"
 for _ in range(8):
     if which in ("family", "fwd"):  # Y[B, 1024] = X . W1^T as 16 raw split-K slabs
@@ -38,7 +38,7 @@ for _ in range(8):
     if which == "family":
         ops.decoder_recon(h, W4, b4, X, want_xhat=False, dP=dP.clone(), se_part=sep)  # fused last layer + recon
         ops.gemm_slabs(ops.GEMM_NN, dP, W4)  # dX[B, 1024] = dP . W4
-        ops.gemm_planes(ops.GEMM_TN, dP, h, out=dW4, want_sq=True)  # dW4[G, 1024] = dP^T . h  (fp32 operands)
+        ops.gemm_planes(ops.GEMM_TN, dP, None, b_planes=hp, out=dW4, want_sq=True)  # dW4[G, 1024] = dP^T . h  (h pre-split)
     if which in ("family", "dw_planes"):  # dW1[1024, G] = dY^T . X from pre-split planes (LDS-DMA stagers)
         ops.gemm_planes(ops.GEMM_TN, None, None, a_planes=dYp, b_planes=Xp, out=dW1, want_sq=True)
     if which == "dw":  # the same product with the in-kernel split (round 2's form)
