@@ -470,6 +470,34 @@ def test_clip_adam_matches_torch(ops):
     assert rel_l2(v, opt.state[pt]["exp_avg_sq"]) < 5e-5
 
 
+def test_adam_confined_to_n_compute_units_is_bit_identical(ops):
+    """mmvae_adam_set_workgroups: the elementwise update on N fat workgroups leaves the same bits as the chip-filling
+    grid (odd length: vector body + scalar tail; the copy rider too)."""
+    from mmvae_amd import _lib
+
+    lib = _lib.load()
+    n = 1_000_003
+    s = torch.cuda.current_stream().cuda_stream
+    state = torch.tensor([4.0, 0, 0.7, 0.9, 0.95, 0.0, 0, 0], device="cuda")  # step, norm, clip, bias corrections, clip value
+    outs = []
+    try:
+        for wg in (0, 7, 64):
+            assert lib.mmvae_adam_set_workgroups(wg) == 0 and lib.mmvae_adam_get_workgroups() == wg
+            p, g = dev(rnd(n, seed=1)), dev(rnd(n, seed=2, scale=0.1))
+            m, v = dev(rnd(n, seed=3, scale=0.01)), dev(rnd(n, seed=4, scale=0.01)).abs()
+            src, dst = dev(rnd(256, seed=5)), torch.zeros(256, device="cuda")
+            rc = lib.mmvae_adam_step_copy(n, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), state.data_ptr(),
+                                          5e-3, 0.9, 0.999, 1e-8, 1e-6, 0.5, 256, src.data_ptr(), dst.data_ptr(), s)
+            assert rc == 0
+            assert torch.equal(dst, src)
+            outs.append((p, m, v))
+    finally:
+        lib.mmvae_adam_set_workgroups(0)
+    assert lib.mmvae_adam_set_workgroups(257) != 0
+    for p, m, v in outs[1:]:
+        assert torch.equal(p, outs[0][0]) and torch.equal(m, outs[0][1]) and torch.equal(v, outs[0][2])
+
+
 def test_norm_ranges_and_prepare_in_one_launch_equal_the_separate_launches(ops):
     """mmvae_grad_sqnorm_ranges_prepare: the partials of up to 4 arena ranges + adam_prepare by the workgroup that finishes
     last -- bit for bit what mmvae_grad_sqnorm per range followed by mmvae_adam_prepare leave (partials and state words),
