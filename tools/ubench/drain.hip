@@ -42,16 +42,35 @@ int main() {
     hipMalloc(&st, WG * 2 * sizeof(long long));
     hipMalloc(&sb, sizeof(long long));
     hipMalloc(&sink, 4);
+    for (int graph = 0; graph < 2; ++graph)
     for (int nt = 0; nt < 2; ++nt)
         for (int mb : {0, 2, 8, 32, 64, 128}) {
             const long n4 = ((long)mb << 20) / 16 / WG;
             std::vector<double> gaps, spans;
-            for (int rep = 0; rep < 12; ++rep) {
+            hipGraphExec_t exec = nullptr;
+            if (graph) {  // the same pair as a captured graph
+                hipStream_t cs;
+                hipStreamCreate(&cs);
+                hipGraph_t gr;
+                hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
                 if (nt)
-                    hipLaunchKernelGGL(writer<1>, dim3(WG), dim3(512), 0, 0, buf, n4, st);
+                    hipLaunchKernelGGL(writer<1>, dim3(WG), dim3(512), 0, cs, buf, n4, st);
                 else
-                    hipLaunchKernelGGL(writer<0>, dim3(WG), dim3(512), 0, 0, buf, n4, st);
-                hipLaunchKernelGGL(reader, dim3(64), dim3(256), 0, 0, buf, (long)(1 << 16), sb, sink);
+                    hipLaunchKernelGGL(writer<0>, dim3(WG), dim3(512), 0, cs, buf, n4, st);
+                hipLaunchKernelGGL(reader, dim3(64), dim3(256), 0, cs, buf, (long)(1 << 16), sb, sink);
+                hipStreamEndCapture(cs, &gr);
+                hipGraphInstantiate(&exec, gr, nullptr, nullptr, 0);
+            }
+            for (int rep = 0; rep < 12; ++rep) {
+                if (graph) {
+                    hipGraphLaunch(exec, 0);
+                } else {
+                    if (nt)
+                        hipLaunchKernelGGL(writer<1>, dim3(WG), dim3(512), 0, 0, buf, n4, st);
+                    else
+                        hipLaunchKernelGGL(writer<0>, dim3(WG), dim3(512), 0, 0, buf, n4, st);
+                    hipLaunchKernelGGL(reader, dim3(64), dim3(256), 0, 0, buf, (long)(1 << 16), sb, sink);
+                }
                 hipDeviceSynchronize();
                 std::vector<long long> h(WG * 2);
                 long long b;
@@ -69,8 +88,8 @@ int main() {
             }
             std::sort(gaps.begin(), gaps.end());
             std::sort(spans.begin(), spans.end());
-            printf("%s stores, %3d MB written: writer span %7.1f us   boundary (last exit -> next kernel's entry) %6.2f us (min %5.2f)\n",
-                   nt ? "non-temporal" : "ordinary    ", mb, spans[spans.size() / 2], gaps[gaps.size() / 2], gaps[0]);
+            printf("%s %s stores, %3d MB written: writer span %7.1f us   boundary (last exit -> next kernel's entry) %6.2f us (min %5.2f)\n",
+                   graph ? "graph " : "stream", nt ? "non-temporal" : "ordinary    ", mb, spans[spans.size() / 2], gaps[gaps.size() / 2], gaps[0]);
         }
     return 0;
 }
