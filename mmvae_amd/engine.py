@@ -212,6 +212,9 @@ class StepEngine:
         # VAE optimiser) on a second branch stream
         self.side_dw2 = int(os.environ.get("MMVAE_SIDE_DW2", "185"))
         self.side_branches = os.environ.get("MMVAE_SIDE_BRANCHES", "1") != "0"
+        # the same branch inside the exchange program (data parallelism): the decoder's weight gradient beside the part
+        # of the backward chain that lies ahead of the shared VAE's exchange point (the cut joins it); 0 = in order
+        self.side_dw_dp = int(os.environ.get("MMVAE_SIDE_DW_DP", "0"))
         self.side_dw_any = os.environ.get("MMVAE_SIDE_DW_ANY", "0") != "0"  # fork outside the measured geometry too
         self.side_max_rows = int(os.environ.get("MMVAE_SIDE_MAX_ROWS", "640"))  # see _Plan._build
         if self.side_dw:
@@ -700,6 +703,38 @@ class _Plan:
             call = launch
         self._cur.append(call)
         return True
+
+    def _side_capped_gemm(self, layout, M, N, K, A, lda, Bm, ldb, Cm, ldc, cap: int, planes=None) -> None:
+        """Unsplit GEMM on the side stream with its persistent grid capped to `cap` workgroups (no fused norm partials:
+        under a gradient exchange the clip's norm is that of the REDUCED gradients); joined by the next cut / _join()."""
+        plan = self
+        ap, bp = (planes[0].args() if planes and planes[0] else _NOPL), (planes[1].args() if planes and planes[1] else _NOPL)
+        tag, self._probe_next = self._probe_next, None
+
+        def launch_gemm():
+            if planes:
+                rc = plan.lib.mmvae_gemm_planes_f32(layout, M, N, K, 1.0, _p(A), lda, *ap, _p(Bm), ldb, *bp, _p(Cm), ldc,
+                                                    None, SLACK, 1, None, 0, None, 0, _s())
+            else:
+                rc = plan.lib.mmvae_gemm_f32(layout, M, N, K, 1.0, _p(A), lda, _p(Bm), ldb, _p(Cm), ldc, None, SLACK, 1,
+                                             None, 0, _s())
+            if rc != 0:
+                raise _lib.HipLibraryError(f"capped side GEMM failed with code {rc} (layout {layout}, {M}x{N}x{K})")
+
+        launch = self._probed(tag, 2.0 * M * N * K, launch_gemm, bound="mfma", cus=cap, planes=_planes_desc(planes),
+                              shape=f"{('NT', 'NN', 'TN')[layout]} {M}x{N}x{K}")
+        side = self.eng.side_stream
+        self._fork()
+
+        def call():
+            plan.lib.mmvae_gemm_set_workgroup_cap(cap)
+            try:
+                with torch.cuda.stream(side):
+                    launch()
+            finally:
+                plan.lib.mmvae_gemm_set_workgroup_cap(0)
+
+        self._cur.append(call)
 
     def _queue_gemm(self, layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags) -> bool:
         """Weight-gradient GEMMs of the core layers (the planner's 64x64-tile class) are independent of each other and
@@ -1413,6 +1448,17 @@ class _Plan:
             if early_branch:  # behind the weight gradient on its stream: one branch, in order (probe: DESIGN.md 5)
                 self._fork()  # (the weight gradient may have stayed on the main stream)
                 self._branch(eng.side_stream, early_calls)
+        elif (eng.side_dw_dp and eng.overlap and eng.side_stream is not None and train and K == 1 and not self.has_adv
+              and big and (measured or eng.side_dw_any) and self.cond is None
+              and self._plan_gemm(TN, G, last.n_in, self.kpad(R)) == 1):
+            # exchange program: input gradient first, the weight gradient capped on the side stream beside the chain up
+            # to the VAE's exchange point (the cut there joins it)
+            self._probe_next = "dec_l2_dx"
+            S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in, planes=dx_pl)
+            self._probe_next = "dec_l2_dw"
+            self._side_capped_gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in,
+                                   eng.side_dw_dp, planes=dw_pl)
+            self._probe_next = None
         else:
             self._probe_next = "dec_l2_dw" if big else None
             self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True,

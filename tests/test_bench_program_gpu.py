@@ -131,6 +131,23 @@ def test_forked_program_is_bit_identical_to_the_single_stream_one():
         assert not bad, f"{env}: {len(bad)} tensors differ, e.g. {bad[:3]}"
 
 
+def test_exchange_program_with_its_side_branch_is_bit_identical():
+    """The overlapped exchange program on one rank (MMVAE_DP_OVERLAP=1: the program data parallelism runs, without the
+    transfers) with the decoder's weight gradient on its capped side branch (MMVAE_SIDE_DW_DP) against the same program
+    in order: identical parameters after 8 steps.  (Against the single-rank in-order program the clip's norm comes from
+    a pass of its own instead of the GEMM epilogues' partials: the same value to rounding, not bit for bit.)"""
+    import gc
+
+    ref, f0 = _run_c2(8, {"MMVAE_DP_OVERLAP": "1"})
+    assert not f0
+    gc.collect()
+    torch.cuda.empty_cache()
+    got, f = _run_c2(8, {"MMVAE_DP_OVERLAP": "1", "MMVAE_SIDE_DW_DP": "125"})
+    assert f, "the exchange program forks its weight-gradient branch when asked"
+    bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+    assert not bad, f"{len(bad)} tensors differ, e.g. {bad[:3]}"
+
+
 def test_fork_is_gated_to_the_measured_geometry():
     """Shapes away from C2's (here: 8 000 genes, 512 rows: a 8.4 GFLOP weight gradient) stay on one stream unless asked."""
     from mmvae_amd import synthetic
