@@ -215,6 +215,10 @@ class StepEngine:
         # the same branch inside the exchange program (data parallelism): the decoder's weight gradient beside the part
         # of the backward chain that lies ahead of the shared VAE's exchange point (the cut joins it); 0 = in order
         self.side_dw_dp = int(os.environ.get("MMVAE_SIDE_DW_DP", "0"))
+        # adversarial programs (C4): the decoder's last layer backward -- weight gradient AND input gradient -- needs only
+        # dP, which the reconstruction epilogue has written before the adversaries' phases start: both GEMMs run capped
+        # on the side stream beside those phases (~700 us of latency-bound launches), joined ahead of the backward chain
+        self.side_dw_adv = int(os.environ.get("MMVAE_SIDE_DW_ADV", "0"))
         self.side_dw_any = os.environ.get("MMVAE_SIDE_DW_ANY", "0") != "0"  # fork outside the measured geometry too
         self.side_max_rows = int(os.environ.get("MMVAE_SIDE_MAX_ROWS", "640"))  # see _Plan._build
         if self.side_dw:
@@ -640,7 +644,7 @@ class _Plan:
         return sk.value
 
     def _fuse_sqnorm(self, layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, side_cap: int = 0,
-                     on_side: bool = True, planes=None) -> bool:
+                     on_side: bool = True, planes=None, fork: bool = True) -> bool:
         """Unsplit weight-gradient GEMM straight into a gradient arena: let its epilogue also leave the partial sums of
         squares of what it stores (mmvae_gemm_f32_sq), so that the clip's norm pass does not read the 82 MB back.  Only
         without a gradient exchange: under data parallelism the norm is that of the REDUCED gradients."""
@@ -686,7 +690,7 @@ class _Plan:
 
         if side_cap:  # persistent grid capped to `side_cap` workgroups: the CUs left over serve another branch
             side = eng.side_stream if on_side else None
-            if on_side:
+            if on_side and fork:
                 self._fork()
 
             def call():
@@ -704,7 +708,8 @@ class _Plan:
         self._cur.append(call)
         return True
 
-    def _side_capped_gemm(self, layout, M, N, K, A, lda, Bm, ldb, Cm, ldc, cap: int, planes=None) -> None:
+    def _side_capped_gemm(self, layout, M, N, K, A, lda, Bm, ldb, Cm, ldc, cap: int, planes=None, flags: int = 0,
+                          sk: int = 1, fork: bool = True) -> None:
         """Unsplit GEMM on the side stream with its persistent grid capped to `cap` workgroups (no fused norm partials:
         under a gradient exchange the clip's norm is that of the REDUCED gradients); joined by the next cut / _join()."""
         plan = self
@@ -714,17 +719,18 @@ class _Plan:
         def launch_gemm():
             if planes:
                 rc = plan.lib.mmvae_gemm_planes_f32(layout, M, N, K, 1.0, _p(A), lda, *ap, _p(Bm), ldb, *bp, _p(Cm), ldc,
-                                                    None, SLACK, 1, None, 0, None, 0, _s())
+                                                    None, flags | SLACK, sk, None, 0, None, 0, _s())
             else:
-                rc = plan.lib.mmvae_gemm_f32(layout, M, N, K, 1.0, _p(A), lda, _p(Bm), ldb, _p(Cm), ldc, None, SLACK, 1,
-                                             None, 0, _s())
+                rc = plan.lib.mmvae_gemm_f32(layout, M, N, K, 1.0, _p(A), lda, _p(Bm), ldb, _p(Cm), ldc, None,
+                                             flags | SLACK, sk, None, 0, _s())
             if rc != 0:
                 raise _lib.HipLibraryError(f"capped side GEMM failed with code {rc} (layout {layout}, {M}x{N}x{K})")
 
         launch = self._probed(tag, 2.0 * M * N * K, launch_gemm, bound="mfma", cus=cap, planes=_planes_desc(planes),
-                              shape=f"{('NT', 'NN', 'TN')[layout]} {M}x{N}x{K}")
+                              shape=f"{('NT', 'NN', 'TN')[layout]} {M}x{N}x{K}" + (f" split-K {sk}" if sk > 1 else ""))
         side = self.eng.side_stream
-        self._fork()
+        if fork:
+            self._fork()
 
         def call():
             plan.lib.mmvae_gemm_set_workgroup_cap(cap)
@@ -1416,8 +1422,34 @@ class _Plan:
             hidden.append(self.z)  # first sample (rows 0..B-1)
         self.adv_grad_into: Dict[int, torch.Tensor] = {}
         self.dz_lat = eng.buf("dz_lat", (R, Z))
+        last_ = self.dec_layers[-1]
+        adv_side = bool(self.has_adv and eng.side_dw_adv and train and K == 1 and eng.side_stream is not None
+                        and not eng.overlap and eng.world == 1 and big and (measured or eng.side_dw_any)
+                        and self.cond is None and R <= eng.side_max_rows and self.dp_colpart is not None
+                        and self._plan_gemm(TN, G, last_.n_in, self.kpad(R)) == 1)
+        self._adv_dx = None
+        if adv_side:
+            # the branch is emitted ahead of the phases it runs beside (enqueued behind them it started behind them), and
+            # the adversaries' optimisers do not join it (joined at their first clip it cost 1.55 -> 1.7-2.0 ms)
+            self._fork()
+            dw_pl_ = (self.dPp, self.hp) if self.pl_dec else ((None, self.hp) if self.pl_dec_h else None)
+            self._probe_next = "dec_l2_dw"
+            if not self._fuse_sqnorm(TN, G, last_.n_in, self.kpad(R), 1.0, self.dP, G, last_.inp, last_.ld_inp, last_.gW,
+                                     last_.n_in, None, 0, side_cap=eng.side_dw_adv, planes=dw_pl_, fork=False):
+                self._side_capped_gemm(TN, G, last_.n_in, self.kpad(R), self.dP, G, last_.inp, last_.ld_inp, last_.gW,
+                                       last_.n_in, eng.side_dw_adv, planes=dw_pl_, fork=False)
+            sk_dx = self._plan_gemm(NN, R, last_.n_in, G)
+            dx_slab = eng.buf(f"dx_slab.{sk_dx}", (sk_dx, R, last_.n_in))
+            self._probe_next = "dec_l2_dx"
+            self._side_capped_gemm(NN, R, last_.n_in, G, self.dP, G, last_.W, last_.n_in, dx_slab, last_.n_in,
+                                   eng.side_dw_adv, planes=(self.dPp, None) if self.pl_dec else None, flags=RAW, sk=sk_dx,
+                                   fork=False)
+            self._probe_next = None
+            self._adv_dx = (dx_slab, sk_dx)
         if self.has_adv:
+            held_dirty, self._dirty = self._dirty, []  # (the adversaries' optimisers must not join this branch)
             self._build_adversaries(hidden)
+            self._dirty = held_dirty + [d for d in self._dirty if d not in held_dirty]
 
         # ---- backward, decoder side
         if K > 1:
@@ -1430,7 +1462,11 @@ class _Plan:
                 early_calls += self._take(start)
         dx_pl = (self.dPp, None) if self.pl_dec else None
         dw_pl = (self.dPp, self.hp) if self.pl_dec else ((None, self.hp) if self.pl_dec_h else None)
-        if side_dw:  # input gradient first (the chain waits for it), then the weight gradient on the side branch
+        din_first = None
+        if self._adv_dx is not None:  # both GEMMs ran beside the adversaries' phases
+            self._join()
+            din_first, S = self._adv_dx
+        elif side_dw:  # input gradient first (the chain waits for it), then the weight gradient on the side branch
             self._probe_next = "dec_l2_dx"
             S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in, planes=dx_pl)
             xs = getattr(self, "_x_split_side", None)
@@ -1469,10 +1505,11 @@ class _Plan:
         rest = self.dec_layers[:-1]
         for j in range(len(rest) - 1, -1, -1):
             l = rest[j]
+            d_in = din_first if j == len(rest) - 1 else None
             if j > 0:
-                S = self.bwd_layer(l, None, S, need_dx="raw")
+                S = self.bwd_layer(l, d_in, S, need_dx="raw")
             else:
-                self.bwd_layer(l, None, S, need_dx="full",
+                self.bwd_layer(l, d_in, S, need_dx="full",
                                dx_out=self.dz_lat if self.cond is None else self.cond.d_out)
         if self.cond is not None:
             self.cond.emit_backward(self.dz_lat)
