@@ -1012,20 +1012,33 @@ struct XwOperand {
 struct XwCursor {
     int w, kt, kt_end, bm, bn, z;
     __device__ __forceinline__ bool valid(const GemmArgs& g) const { return w < g.nwork; }
+    template <bool NF>
     __device__ __forceinline__ void open(const GemmArgs& g) {  // item w -> tile, slice, k-tile range
         if (w >= g.nwork) return;
         const int tiles = g.mt * g.nt;
         z = w / tiles;
         const int t = w - z * tiles;
-        bm = t % g.mt;
-        bn = t / g.mt;
+        // Consecutive items (one XCD's share of a round, running together over one L2) cycle through the tiles of the
+        // axis with FEWER tiles: the panels they cycle through stay in that L2, and the other operand's panel is fetched
+        // once for all of them.  (dW = dP^T h: 125 x 4 tiles -- M fastest walked all 125 dP panels per h panel and
+        // re-read dP four times: 179 MB fetched against 43 MB of operands.)  NF is the tile's shape, not the launch's tile
+        // counts: the tall-output tile (160 x 256) is the one planned for many row tiles x few column tiles, and a
+        // run-time choice cost the register-bound planes kernels their spill-free loops (3 x slower).
+        if (NF) {
+            bn = t % g.nt;
+            bm = t / g.nt;
+        } else {
+            bm = t % g.mt;
+            bn = t / g.mt;
+        }
         kt = z * g.ktiles_per_split;
         kt_end = min(kt + g.ktiles_per_split, g.ktiles);
     }
+    template <bool NF>
     __device__ __forceinline__ bool advance(const GemmArgs& g, int nwg) {  // next k-tile; true when a new item began
         if (++kt < kt_end) return false;
         w += nwg;
-        open(g);
+        open<NF>(g);
         return true;
     }
 };
@@ -1132,6 +1145,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
     constexpr int PA = BM * XW_ROWB, PB = BN * XW_ROWB;       // plane strides
     constexpr int IMG = 3 * (PA + PB);                        // one image (A planes, then B planes)
     constexpr bool A_PL = ASRC == SRC_PLANES, B_PL = BSRC == SRC_PLANES;
+    constexpr bool NFAST = BM < BN;  // walk order of the work items (XwCursor::open)
     constexpr bool ANY_F32 = !A_PL || !B_PL, ANY_PL = A_PL || B_PL;
     constexpr bool A_TR = A_PL && AFORM == FORM_RC, B_TR = B_PL && BFORM == FORM_RC;  // transposed-read images
     // 16x16x32 MFMAs: the same flops with a quarter of the accumulator registers per instruction -- the chip is
@@ -1172,9 +1186,9 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
         XwCursor dm_c;  // planes operands: the k-tile the next DMA fetches (= the one being staged)
         XwCursor br_c;  // the k-tile whose barrier comes next (= the one the multipliers work on)
         ld_c.w = dm_c.w = br_c.w = L;
-        ld_c.open(g);
-        dm_c.open(g);
-        br_c.open(g);
+        ld_c.template open<NFAST>(g);
+        dm_c.template open<NFAST>(g);
+        br_c.template open<NFAST>(g);
         if (!br_c.valid(g)) return;
         const int dlane = st & 63;
         const int wv = __builtin_amdgcn_readfirstlane(st >> 6);
@@ -1206,7 +1220,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
         };
         auto bump = [&](XwCursor& c) {
             XwCursor nx = c;
-            nx.advance(g, nwg);
+            nx.template advance<NFAST>(g, nwg);
             if (nx.valid(g)) c = nx;  // (a select per field, not a branch around the loads)
         };
         auto issue_load = [&](auto SET) {  // prologue only
@@ -1336,7 +1350,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
 #if MMVAE_X3_STAMPS
             sst[3] += 1;
 #endif
-            if (br_c.advance(g, nwg))
+            if (br_c.template advance<NFAST>(g, nwg))
                 for (int e = 0; e < epi_barriers; ++e) __syncthreads();
             if (!br_c.valid(g)) break;
             step(S0{}, 0);
@@ -1346,7 +1360,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
 #if MMVAE_X3_STAMPS
             sst[3] += 1;
 #endif
-            if (br_c.advance(g, nwg))
+            if (br_c.template advance<NFAST>(g, nwg))
                 for (int e = 0; e < epi_barriers; ++e) __syncthreads();
             if (!br_c.valid(g)) break;
         }
@@ -1474,7 +1488,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
 
     XwCursor c;
     c.w = L;
-    c.open(g);
+    c.template open<NFAST>(g);
     if (!c.valid(g)) return;
     int s = 0;
     // the multipliers' MFMAs and fragment reads win every issue arbitration against the stager wave of their SIMD: the
@@ -1718,7 +1732,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
             }
 #endif
             ++s;
-            more = !c.advance(g, nwg);
+            more = !c.template advance<NFAST>(g, nwg);
 #if MMVAE_X3_STAMPS
             {
                 const long long tn_ = clock64();
