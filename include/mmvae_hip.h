@@ -40,7 +40,7 @@ typedef void* mmvae_stream_t; /* hipStream_t */
 /* ABI version: bumped whenever an entry point is added or a signature changes (mmvae_abi_version() returns the
  * value the library was built with; bindings compare it with the header they were written against).
  *   1  round-1 surface (first 20 entry points)      2  end of round 1 (50 entry points)      3+  round 2 */
-#define MMVAE_ABI_VERSION 5
+#define MMVAE_ABI_VERSION 6
 int mmvae_abi_version(void);
 const char* mmvae_build_arch(void);
 
@@ -586,6 +586,108 @@ int mmvae_cond_linear_bwd_dw(int n_chunks, const int32_t* chunk_dst, const int32
                              int64_t ldx, float* grads, const int64_t* w_off, const int64_t* b_off, int n_red,
                              const int32_t* red_cond, const int32_t* red_slot, const int32_t* red_n, float* partials,
                              mmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Row-owner adversary passes (ABI 6).  Replaces, per adversarial phase, the whole chain of
+ * `CMMVAEModel.grf` (cmmvae_model.py:59-101): Adversarial.encoder (FCBlock of Linear -> ReLU -> Dropout layers WITHOUT
+ * BatchNorm, components.py:638-674) -> every head -> CrossEntropyLoss(sum) (:54,85) -> its backward down to the hidden
+ * representation, with the sign flip of GradientReversalFunction (components.py:879-899) -- two launches per phase for
+ * ALL adversaries instead of 12-17 launches per adversary.
+ *
+ *   mmvae_adv_pass_f32   a workgroup owns 16 cells.  It runs the encoder layers with the activations in LDS (exact-f32
+ *       MFMA, weights streamed from L2), then the stacked heads [Ct, width[L]] flash-style: per 16-class tile the
+ *       logits (stored once to `logits`, -inf in a head's padding columns), a running max / sum of exponentials per
+ *       (cell, head) and the running product softmax . W -- so that d(loss)/d(encoded) = gscale * (softmax . W - W[y])
+ *       needs no second pass over the head weights.  The class tiles of a cell tile are split over `splits` workgroups
+ *       (more parallelism than 16-cell tiles alone give); each leaves its partial (max, sum, product) in `partials` and
+ *       takes a ticket -- the LAST one (no spinning, no grid barrier) merges them in split order, writes lse / loss_rows,
+ *       and runs the backward chain: dz[l] (gradient at layer l's pre-activation, for the weight-gradient launch) and,
+ *       with `gx`, the reversed input gradient gx = -d(loss)/dx.  The workgroup that finishes the launch last sums the
+ *       per-cell losses of every job (fp64, fixed order) into loss_each[h] / loss_total and adds total_scale * loss_total
+ *       to *total_loss (jobs in order).  Bitwise reproducible.
+ *   mmvae_adv_dw_f32     every weight / bias gradient of the pass in one launch: job = one Linear, gW[M,N] = dz^T . inp
+ *       over the B cells, gb = column sums of dz (32 x 64 tiles, exact-f32 MFMA).  A heads job reads `logits` and
+ *       forms dlogits = gscale * (exp(logit - lse) - onehot) while staging.  Every workgroup leaves the sum of squares
+ *       of what it stored; the last one to finish (ticket) turns them into each optimiser's global gradient norm, clip
+ *       coefficient, step count and bias corrections (mmvae_adam_prepare's arithmetic) -- no norm pass, no prepare
+ *       launch.  The jobs of an optimiser must cover its whole gradient arena for that norm to be the arena's.
+ *   mmvae_adam_step_multi   mmvae_adam_step over several optimisers' arenas in one launch.
+ * Limits: <= 4 encoder layers, <= 8 heads, widths <= 1024 (LDS permitting: mmvae_adv_pass_plan), any B.
+ * ------------------------------------------------------------------------------------------------------------ */
+#define MMVAE_ADV_MAX_LAYERS 4
+#define MMVAE_ADV_MAX_HEADS 8
+typedef struct {
+    const float* x;       /* [B, width[0]] the hidden representation the adversary reads */
+    int64_t ldx;
+    const float* W[MMVAE_ADV_MAX_LAYERS];      /* encoder layer l: [width[l+1], width[l]] row-major */
+    const float* b[MMVAE_ADV_MAX_LAYERS];      /* [width[l+1]] or NULL */
+    const uint8_t* mask[MMVAE_ADV_MAX_LAYERS]; /* dropout keep mask [B, width[l+1]] or NULL */
+    float* act[MMVAE_ADV_MAX_LAYERS];          /* out [B, width[l+1]]: layer output (after dropout) */
+    float* dz[MMVAE_ADV_MAX_LAYERS];           /* out [B, width[l+1]]: gradient at the layer's pre-activation */
+    const float* Wh;      /* stacked heads [Ct, width[L]] */
+    const float* bh;      /* [Ct] or NULL */
+    const int64_t* labels; /* [H, B]; a label outside [0, classes[h]) contributes nothing (like ignore) */
+    float* logits;        /* out [B, Ct] */
+    float* lse;           /* out [H, B] log-sum-exp per cell and head */
+    float* loss_rows;     /* out [H, B] */
+    float* gx;            /* out [B, width[0]] = -d(loss)/dx, or NULL (discriminator phase: x is detached) */
+    float* partials;      /* scratch, mmvae_adv_pass_plan's partial_floats */
+    uint32_t* tickets;    /* ceil(B / 16) words, zero before the first launch (the kernel leaves them zero) */
+    float* loss_each;     /* out [H] */
+    float* loss_total;    /* out [1] */
+    float* total_loss;    /* total_loss[0] += total_scale * loss_total[0], or NULL */
+    float total_scale;
+    float gscale;         /* scale of d(loss)/d(logits): 1 (discriminator) or adv_weight (generator) */
+    float p_drop[MMVAE_ADV_MAX_LAYERS];
+    int32_t relu[MMVAE_ADV_MAX_LAYERS];
+    int32_t width[MMVAE_ADV_MAX_LAYERS + 1];
+    int32_t n_layers, H, Ct, B;
+    int32_t col[MMVAE_ADV_MAX_HEADS];     /* first column of head h in the stacked matrix (multiple of 4 when H > 1) */
+    int32_t classes[MMVAE_ADV_MAX_HEADS];
+} mmvae_adv_job;
+/* host-only: MMVAE_OK when the job's shape is supported.  *net in: 0 = choose (out: 1, 2, 4 or 8 >= ceil(width[L] / 16)),
+ * or the tile count of the launch the job will share with wider jobs; out: the dynamic LDS bytes of a workgroup and the
+ * floats of `partials` for `splits` class splits, both at that tile count */
+int mmvae_adv_pass_plan(const mmvae_adv_job* job_host, int splits, int* net, size_t* lds_bytes, int64_t* partial_floats);
+/* jobs_dev: DEVICE array of n_jobs jobs with the same B; net / lds_bytes: the maxima of mmvae_adv_pass_plan over the
+ * jobs; launch_ticket: one zero word */
+int mmvae_adv_pass_f32(int n_jobs, const mmvae_adv_job* jobs_dev, int B, int splits, int net, size_t lds_bytes,
+                       uint32_t* launch_ticket, mmvae_stream_t stream);
+
+typedef struct {
+    const float* dz;      /* [B, M] gradient at the Linear's output -- or, with `lse`, the logits of mmvae_adv_pass_f32 */
+    int64_t ld_dz;
+    const float* inp;     /* [B, N] the Linear's input */
+    int64_t ld_inp;
+    float* gW;            /* out [M, N] */
+    float* gb;            /* out [M] or NULL */
+    const float* lse;     /* heads job: [H, B] (NULL: dz is a gradient) */
+    const int64_t* labels; /* heads job: [H, B] */
+    float gscale;
+    int32_t M, N, B, H;
+    int32_t opt;          /* index into the launch's optimiser table: which norm this gradient belongs to */
+    int32_t col[MMVAE_ADV_MAX_HEADS], classes[MMVAE_ADV_MAX_HEADS];
+    int32_t first_block, n_blocks; /* filled by mmvae_adv_dw_prepare */
+} mmvae_adv_dw_job;
+typedef struct {
+    float* state;         /* the optimiser's state words (mmvae_adam_prepare) */
+    float* norm_out;      /* the pre-clip norm is also stored here (a metrics word), or NULL */
+    float max_norm, grad_scale, beta1, beta2;
+    uint32_t flags;       /* MMVAE_PREPARE_*; 0: leave the state alone (norm_out is still written) */
+    uint32_t reserved;
+} mmvae_adv_opt;
+int mmvae_adv_dw_prepare(int n_jobs, mmvae_adv_dw_job* jobs_host, int* total_blocks);
+/* partials: total_blocks floats; ticket: one zero word */
+int mmvae_adv_dw_f32(int n_jobs, const mmvae_adv_dw_job* jobs_dev, int total_blocks, int n_opts,
+                     const mmvae_adv_opt* opts_dev, float* partials, uint32_t* ticket, mmvae_stream_t stream);
+
+typedef struct {
+    float *p, *g, *m, *v;
+    const float* state;
+    int64_t n;
+    float lr, beta1, beta2, eps, weight_decay, grad_scale;
+} mmvae_adam_arena;
+int mmvae_adam_step_multi(int n_arenas, const mmvae_adam_arena* arenas_dev, int64_t max_n, mmvae_stream_t stream);
 
 /* Diagnostics: `workgroups` workgroups that each hold `lds_bytes` of LDS and spin for `micros` microseconds -- a stand-in
  * for a collective occupying workgroup slots beside the step (bench.py --sim-comm). */

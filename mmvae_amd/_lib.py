@@ -144,6 +144,11 @@ PROTOTYPES = {
     "mmvae_gemm_batch_job_ok": (_i, [_p]),
     "mmvae_gemm_batch_prepare": (_i, [_i, _p, C.POINTER(_i)]),
     "mmvae_gemm_batch_f32": (_i, [_i, _p, _i, _p]),
+    "mmvae_adv_pass_plan": (_i, [_p, _i, C.POINTER(_i), C.POINTER(_z), C.POINTER(_l)]),
+    "mmvae_adv_pass_f32": (_i, [_i, _p, _i, _i, _i, _z, _p, _p]),
+    "mmvae_adv_dw_prepare": (_i, [_i, _p, C.POINTER(_i)]),
+    "mmvae_adv_dw_f32": (_i, [_i, _p, _i, _i, _p, _p, _p, _p]),
+    "mmvae_adam_step_multi": (_i, [_i, _p, _l, _p]),
 }
 
 
@@ -166,6 +171,41 @@ class GemmJob(C.Structure):
                 ("ldb", C.c_int64), ("ldc", C.c_int64), ("layout", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
                 ("K", C.c_int32), ("alpha", C.c_float), ("flags", C.c_uint32), ("first_block", C.c_int32),
                 ("n_blocks", C.c_int32)]
+
+
+ADV_MAX_LAYERS, ADV_MAX_HEADS = 4, 8
+
+
+class AdvJob(C.Structure):
+    """mmvae_adv_job (include/mmvae_hip.h): one adversary in one phase of mmvae_adv_pass_f32."""
+    _fields_ = [("x", _p), ("ldx", _l), ("W", _p * ADV_MAX_LAYERS), ("b", _p * ADV_MAX_LAYERS),
+                ("mask", _p * ADV_MAX_LAYERS), ("act", _p * ADV_MAX_LAYERS), ("dz", _p * ADV_MAX_LAYERS), ("Wh", _p),
+                ("bh", _p), ("labels", _p), ("logits", _p), ("lse", _p), ("loss_rows", _p), ("gx", _p), ("partials", _p),
+                ("tickets", _p), ("loss_each", _p), ("loss_total", _p), ("total_loss", _p), ("total_scale", _f),
+                ("gscale", _f), ("p_drop", _f * ADV_MAX_LAYERS), ("relu", C.c_int32 * ADV_MAX_LAYERS),
+                ("width", C.c_int32 * (ADV_MAX_LAYERS + 1)), ("n_layers", C.c_int32), ("H", C.c_int32),
+                ("Ct", C.c_int32), ("B", C.c_int32), ("col", C.c_int32 * ADV_MAX_HEADS),
+                ("classes", C.c_int32 * ADV_MAX_HEADS)]
+
+
+class AdvDwJob(C.Structure):
+    """mmvae_adv_dw_job: one Linear's weight / bias gradient of mmvae_adv_dw_f32."""
+    _fields_ = [("dz", _p), ("ld_dz", _l), ("inp", _p), ("ld_inp", _l), ("gW", _p), ("gb", _p), ("lse", _p),
+                ("labels", _p), ("gscale", _f), ("M", C.c_int32), ("N", C.c_int32), ("B", C.c_int32), ("H", C.c_int32),
+                ("opt", C.c_int32), ("col", C.c_int32 * ADV_MAX_HEADS), ("classes", C.c_int32 * ADV_MAX_HEADS),
+                ("first_block", C.c_int32), ("n_blocks", C.c_int32)]
+
+
+class AdvOpt(C.Structure):
+    """mmvae_adv_opt: one optimiser of a mmvae_adv_dw_f32 launch (norm / clip / step bookkeeping)."""
+    _fields_ = [("state", _p), ("norm_out", _p), ("max_norm", _f), ("grad_scale", _f), ("beta1", _f), ("beta2", _f),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class AdamArena(C.Structure):
+    """mmvae_adam_arena: one optimiser's arenas in a mmvae_adam_step_multi launch."""
+    _fields_ = [("p", _p), ("g", _p), ("m", _p), ("v", _p), ("state", _p), ("n", _l), ("lr", _f), ("beta1", _f),
+                ("beta2", _f), ("eps", _f), ("weight_decay", _f), ("grad_scale", _f)]
 
 
 class HipLibraryError(RuntimeError):

@@ -49,6 +49,26 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     return v;
 }
 
+// Thread-0 tail of the clip + Adam preparation (mmvae_adam_prepare; also the last workgroup of mmvae_adv_dw_f32): the
+// global gradient norm from the fp64 sum of squares, the clip coefficient, the step count and the bias corrections.
+__device__ __forceinline__ void adam_state_finish(float* __restrict__ state, double sumsq, unsigned flags, float max_norm,
+                                                  float grad_scale, float beta1, float beta2) {
+    float norm = state[1];
+    if (flags & MMVAE_PREPARE_NORM) norm = (float)(sqrt(sumsq) * (double)fabsf(grad_scale));
+    float step = state[0];
+    if (flags & MMVAE_PREPARE_ADVANCE) step += 1.f;
+    state[0] = step;
+    state[1] = norm;
+    float clip = 1.f;
+    if (max_norm > 0.f) {
+        clip = max_norm / (norm + 1e-6f);
+        if (clip > 1.f) clip = 1.f;
+    }
+    state[2] = clip;
+    state[3] = 1.f - powf(beta1, step);
+    state[4] = 1.f - powf(beta2, step);
+}
+
 // Exact three-way bf16 split of an fp32 value by truncation: a = p0 + p1 + p2, each piece an fp32 bit pattern whose low
 // 16 bits are zero (p0 = top 16 bits of a, p1 = top 16 bits of a - p0, p2 = a - p0 - p1: 3 x 8 = 24 significant bits).
 // The bf16x3 GEMMs (gemm_dev.h) multiply such pieces; producers that write pre-split planes use the same function.

@@ -499,24 +499,10 @@ __device__ __forceinline__ void adam_prepare_body(int64_t np, const float* parti
     red[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float norm = state[1];
-        if (flags & MMVAE_PREPARE_NORM) {
-            double t = 0.0;
+        double t = 0.0;
+        if (flags & MMVAE_PREPARE_NORM)
             for (int i = 0; i < 256; ++i) t += red[i];
-            norm = (float)(sqrt(t) * (double)fabsf(grad_scale));
-        }
-        float step = state[0];
-        if (flags & MMVAE_PREPARE_ADVANCE) step += 1.f;
-        state[0] = step;
-        state[1] = norm;
-        float clip = 1.f;
-        if (max_norm > 0.f) {
-            clip = max_norm / (norm + 1e-6f);
-            if (clip > 1.f) clip = 1.f;
-        }
-        state[2] = clip;
-        state[3] = 1.f - powf(beta1, step);
-        state[4] = 1.f - powf(beta2, step);
+        adam_state_finish(state, t, flags, max_norm, grad_scale, beta1, beta2);
     }
 }
 
@@ -659,6 +645,16 @@ __global__ __launch_bounds__(1024) void adam_step_wide_kernel(int64_t n, float* 
                                                               float grad_scale, int vec, int copy_n,
                                                               const float* copy_src, float* copy_dst) {
     adam_step_body(n, p, g, m, v, state, lr, b1, b2, eps, wd, grad_scale, vec, copy_n, copy_src, copy_dst);
+}
+
+// The update of several optimisers' arenas in one launch (blockIdx.y = arena): the adversaries of a step.  Arithmetic of
+// adam_step_kernel per arena.
+__global__ __launch_bounds__(256) void adam_step_multi_kernel(const mmvae_adam_arena* __restrict__ arenas) {
+    const mmvae_adam_arena a = arenas[blockIdx.y];
+    const uintptr_t al = reinterpret_cast<uintptr_t>(a.p) | reinterpret_cast<uintptr_t>(a.g) |
+                         reinterpret_cast<uintptr_t>(a.m) | reinterpret_cast<uintptr_t>(a.v);
+    adam_step_body(a.n, a.p, a.g, a.m, a.v, a.state, a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, a.grad_scale,
+                   (al & 15u) == 0, 0, nullptr, nullptr);
 }
 
 inline int grid_for(int64_t n, int per_block, int cap);
@@ -1196,6 +1192,15 @@ extern "C" int mmvae_adam_step(int64_t n, float* param, const float* grad, float
     const int vec = aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq);
     return launch_adam_step(n, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps,
                             weight_decay, grad_scale, vec, 0, (const float*)nullptr, (float*)nullptr);
+}
+
+extern "C" int mmvae_adam_step_multi(int n_arenas, const mmvae_adam_arena* arenas_dev, int64_t max_n,
+                                     mmvae_stream_t stream) {
+    if (n_arenas < 1 || n_arenas > 64 || !arenas_dev || max_n <= 0) return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(adam_step_multi_kernel, dim3(grid_for(max_n, 1024, 4096), n_arenas), dim3(256), 0, (hipStream_t)stream,
+                 arenas_dev);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
 }
 
 extern "C" int mmvae_adam_step_copy(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,

@@ -220,6 +220,9 @@ class StepEngine:
         # on the side stream beside those phases (~700 us of latency-bound launches), joined ahead of the backward chain
         self.side_dw_adv = int(os.environ.get("MMVAE_SIDE_DW_ADV", "0"))
         self.side_dw_any = os.environ.get("MMVAE_SIDE_DW_ANY", "0") != "0"  # fork outside the measured geometry too
+        # adversaries without BatchNorm: both phases of all of them as five launches (_Plan._build_adversaries_fused);
+        # 0 = the per-layer program (the path of adversaries with BatchNorm)
+        self.adv_fused = os.environ.get("MMVAE_ADV_FUSED", "1") != "0"
         self.side_max_rows = int(os.environ.get("MMVAE_SIDE_MAX_ROWS", "640"))  # see _Plan._build
         if self.side_dw:
             side_stream = True
@@ -1703,8 +1706,110 @@ class _Plan:
             if key[0] == "gemm_slabs" and t.numel() > self.slab.numel():
                 self.slab = t
 
+    def _build_adversaries_fused(self, hidden) -> bool:
+        """Both phases of ALL adversaries as five launches (adv_program.py; kernels: csrc/adv_fused.hip): adversaries
+        whose encoder has no BatchNorm -- every adversary of the reference's configurations -- are row-local up to the
+        weight gradients.  False (nothing emitted): a shape outside those kernels; the per-layer program follows."""
+        from .adv_program import AdvLayer, AdvNet, AdvProgram, supported
+
+        eng, lib, B = self.eng, self.lib, self.B
+        pairs = list(zip(hidden, self.advs))
+        H = len(self.conditions)
+        if not pairs or not (1 <= H <= _lib.ADV_MAX_HEADS):
+            return False
+        g = eng.grad_of
+        pad4 = lambda c: (c + 3) // 4 * 4  # noqa: E731
+        nets, mask_refs = [], []
+        for i, (h, adv) in enumerate(pairs, start=1):
+            opt = self.opt_adv[i - 1]
+            lins = [adv.heads[c].fc_layers[0].lin for c in self.conditions]
+            if any(l.bias is None for l in lins):
+                return False
+            n_e = lins[0].in_features
+            a = opt.arena
+            if H > 1:  # the heads as ONE matrix / bias vector of the arena (HipAdam pack=): rows padded to 4 per head
+                ws, bs = [l.weight for l in lins], [l.bias for l in lins]
+                rows_of = [pad4(l.out_features) for l in lins]
+                chain = lambda ts, per_row: all(ts[k + 1].data_ptr() == ts[k].data_ptr() + 4 * rows_of[k] * per_row  # noqa: E731
+                                                for k in range(H - 1))
+                if not (chain(ws, n_e) and chain(bs, 1) and chain([g(w) for w in ws], n_e) and chain([g(b) for b in bs], 1)):
+                    return False
+                Ct = sum(rows_of)
+                ow, ob = a.offsets[arena_of(ws[0])[1]], a.offsets[arena_of(bs[0])[1]]
+                Wh, bh = a.data[ow:ow + Ct * n_e].view(Ct, n_e), a.data[ob:ob + Ct]
+                gWh, gbh = a.grad[ow:ow + Ct * n_e].view(Ct, n_e), a.grad[ob:ob + Ct]
+                col = [sum(rows_of[:k]) for k in range(H)]
+            else:
+                Wh, bh, gWh, gbh, col = lins[0].weight, lins[0].bias, g(lins[0].weight), g(lins[0].bias), [0]
+            layers, covered = [], {id(l.weight) for l in lins} | {id(l.bias) for l in lins}
+            for j, seq in enumerate(adv.encoder.fc_layers):
+                if getattr(seq, "bn", None) is not None or getattr(seq.lin, "bias", None) is None:
+                    return False
+                refs = {ph: _LayerRef(seq, g, False, adv.encoder, j) for ph in ("discriminator", "generator")}
+                r = refs["discriminator"]
+                lay = AdvLayer(W=r.W, b=r.b, gW=r.gW, gb=r.gb, relu=r.relu, p_drop=r.p)
+                covered |= {id(r.W), id(r.b)}
+                if r.p > 0:
+                    for ph, ref in refs.items():
+                        ref.mask = eng.buf(f"adv{i}.{ph}.enc{j}.mask", (B, r.n_out), torch.uint8)
+                        lay.masks[ph] = ref.mask
+                        mask_refs.append((ref, 1000 + 64 * i + 32 * int(ph == "generator") + j))
+                layers.append(lay)
+            if not layers or {id(p) for p in a.params} != covered:  # the fused norm is the norm of what the jobs write
+                return False
+            net = AdvNet(x=h, ldx=layers[0].W.shape[1], layers=layers, Wh=Wh, bh=bh, gWh=gWh, gbh=gbh, col=col,
+                         classes=[l.out_features for l in lins], opt=opt)
+            if supported(lib, net, B) is None:
+                return False
+            nets.append(net)
+        self._labels_all = eng.buf("labels.all", (H, B), torch.int64)
+        self.labels_dev = {c: self._labels_all[k] for k, c in enumerate(self.conditions)}
+        self.n_adv = len(nets)
+        self._mask_layers += mask_refs
+        prog = AdvProgram(lib, eng.buf, nets, B, self._labels_all, eng.device)
+        self.adv_prog = prog
+        # a gradient exchange (data parallelism) sits between the weight gradients and the norm: the optimiser launches
+        # of the per-layer program then follow the fused passes
+        dp = eng.overlap or any(o.reducer is not None for o in self.opt_adv[:len(nets)])
+        gs = 1.0 / eng.world
+        for phase, gen in (("discriminator", False), ("generator", True)):
+            firsts, totals = [], []
+            for i in range(1, len(nets) + 1):
+                first = self.slot(f"{phase}_{i}/{self.conditions[0]}")
+                for k, c in enumerate(self.conditions):
+                    assert self.slot(f"{phase}_{i}/{c}") == first + k
+                assert self.slot(f"{phase}_{i}/summed") == first + H
+                firsts.append(self.metrics.data_ptr() + 4 * first)
+                totals.append(self.metrics.data_ptr() + 4 * (first + H))
+            opts = None
+            if not dp:
+                opts = [dict(flags=_lib.PREPARE_NORM | (0 if gen else _lib.PREPARE_ADVANCE),
+                             max_norm=0.0 if gen else self.clip_adv,
+                             norm_out=None if gen else self.mptr(f"grad_norms/discriminator_{i}"))
+                        for i in range(1, len(nets) + 1)]
+            prog.build_phase(phase, dict(gscale=self.adv_weight if gen else 1.0, reverse=gen, loss_each=firsts,
+                                         loss_total=totals, total_loss=self.mptr("total_loss") if gen else None,
+                                         total_scale=self.adv_weight, opts=opts, grad_scale=gs))
+        prog.build_adam(gs)
+        for phase, gen in (("discriminator", False), ("generator", True)):
+            self._cur.append(lambda ph=phase: prog.launch_pass(ph))
+            self._cur.append(lambda ph=phase: prog.launch_dw(ph))
+            for i, net in enumerate(nets, start=1):
+                if dp:
+                    self.optimizer(net.opt, 0.0 if gen else self.clip_adv, step=not gen)
+                    self.log_norm(net.opt, f"grad_norms/{phase}_{i}", final=gen)
+                elif gen:
+                    self.log_norm(net.opt, f"grad_norms/generator_{i}")
+            if not gen and not dp:
+                self._cur.append(prog.launch_adam)
+        for (h, _), b in zip(pairs, prog.bufs):
+            self.adv_grad_into[id(h)] = b["gx"]
+        return True
+
     def _build_adversaries(self, hidden):
         eng, lib, B = self.eng, self.lib, self.B
+        if eng.adv_fused and self._build_adversaries_fused(hidden):
+            return
         self._labels_all = eng.buf("labels.all", (len(self.conditions), B), torch.int64)
         self.labels_dev = {c: self._labels_all[i] for i, c in enumerate(self.conditions)}  # one upload per step
         self.n_adv = min(len(hidden), len(self.advs))
