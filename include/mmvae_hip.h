@@ -594,23 +594,24 @@ int mmvae_cond_linear_bwd_dw(int n_chunks, const int32_t* chunk_dst, const int32
  * representation, with the sign flip of GradientReversalFunction (components.py:879-899) -- two launches per phase for
  * ALL adversaries instead of 12-17 launches per adversary.
  *
- *   mmvae_adv_pass_f32   a workgroup owns 16 cells.  It runs the encoder layers with the activations in LDS (exact-f32
- *       MFMA, weights streamed from L2), then the stacked heads [Ct, width[L]] flash-style: per 16-class tile the
- *       logits (stored once to `logits`, -inf in a head's padding columns), a running max / sum of exponentials per
+ *   mmvae_adv_pass_f32   a workgroup owns 16 cells.  Forward launch: the encoder layers with the activations in LDS
+ *       (exact-f32 MFMA, weights streamed from L2), then the stacked heads [Ct, width[L]] flash-style: per 16-class tile
+ *       the logits (stored once to `logits`, -inf in a head's padding columns), a running max / sum of exponentials per
  *       (cell, head) and the running product softmax . W -- so that d(loss)/d(encoded) = gscale * (softmax . W - W[y])
  *       needs no second pass over the head weights.  The class tiles of a cell tile are split over `splits` workgroups
- *       (more parallelism than 16-cell tiles alone give); each leaves its partial (max, sum, product) in `partials` and
- *       takes a ticket -- the LAST one (no spinning, no grid barrier) merges them in split order, writes lse / loss_rows,
- *       and runs the backward chain: dz[l] (gradient at layer l's pre-activation, for the weight-gradient launch) and,
- *       with `gx`, the reversed input gradient gx = -d(loss)/dx.  The workgroup that finishes the launch last sums the
- *       per-cell losses of every job (fp64, fixed order) into loss_each[h] / loss_total and adds total_scale * loss_total
- *       to *total_loss (jobs in order).  Bitwise reproducible.
+ *       (more parallelism than 16-cell tiles alone give); each leaves its partial (max, sum, product) in `partials`.
+ *       Backward launch (the kernel boundary makes the partials visible: no ticket, no cache write-back): one workgroup
+ *       per cell tile merges them in split order, writes lse / loss_rows, and runs the backward chain: dz[l] (gradient
+ *       at layer l's pre-activation, for the weight-gradient launch) and, with `gx`, the reversed input gradient
+ *       gx = -d(loss)/dx.  Bitwise reproducible.
  *   mmvae_adv_dw_f32     every weight / bias gradient of the pass in one launch: job = one Linear, gW[M,N] = dz^T . inp
  *       over the B cells, gb = column sums of dz (32 x 64 tiles, exact-f32 MFMA).  A heads job reads `logits` and
  *       forms dlogits = gscale * (exp(logit - lse) - onehot) while staging.  Every workgroup leaves the sum of squares
  *       of what it stored; the last one to finish (ticket) turns them into each optimiser's global gradient norm, clip
  *       coefficient, step count and bias corrections (mmvae_adam_prepare's arithmetic) -- no norm pass, no prepare
- *       launch.  The jobs of an optimiser must cover its whole gradient arena for that norm to be the arena's.
+ *       launch.  The jobs of an optimiser must cover its whole gradient arena for that norm to be the arena's.  With
+ *       `adv_jobs_dev` its first workgroup also sums the per-cell losses of every adversary (fp64, fixed order) into
+ *       loss_each[h] / loss_total and adds total_scale * loss_total to *total_loss, adversaries in order.
  *   mmvae_adam_step_multi   mmvae_adam_step over several optimisers' arenas in one launch.
  * Limits: <= 4 encoder layers, <= 8 heads, widths <= 1024 (LDS permitting: mmvae_adv_pass_plan), any B.
  * ------------------------------------------------------------------------------------------------------------ */
@@ -632,7 +633,6 @@ typedef struct {
     float* loss_rows;     /* out [H, B] */
     float* gx;            /* out [B, width[0]] = -d(loss)/dx, or NULL (discriminator phase: x is detached) */
     float* partials;      /* scratch, mmvae_adv_pass_plan's partial_floats */
-    uint32_t* tickets;    /* ceil(B / 16) words, zero before the first launch (the kernel leaves them zero) */
     float* loss_each;     /* out [H] */
     float* loss_total;    /* out [1] */
     float* total_loss;    /* total_loss[0] += total_scale * loss_total[0], or NULL */
@@ -647,12 +647,14 @@ typedef struct {
 } mmvae_adv_job;
 /* host-only: MMVAE_OK when the job's shape is supported.  *net in: 0 = choose (out: 1, 2, 4 or 8 >= ceil(width[L] / 16)),
  * or the tile count of the launch the job will share with wider jobs; out: the dynamic LDS bytes of a workgroup and the
- * floats of `partials` for `splits` class splits, both at that tile count */
-int mmvae_adv_pass_plan(const mmvae_adv_job* job_host, int splits, int* net, size_t* lds_bytes, int64_t* partial_floats);
+ * floats of `partials` for `splits` (<= 8) class splits, both at that tile count; *fast: 1 when every width, Ct, ldx and
+ * head start is a multiple of 4 and the pointers filled in so far are 16-byte aligned (the kernels' 16-byte loaders) */
+int mmvae_adv_pass_plan(const mmvae_adv_job* job_host, int splits, int* net, size_t* lds_bytes, int64_t* partial_floats,
+                        int* fast);
 /* jobs_dev: DEVICE array of n_jobs jobs with the same B; net / lds_bytes: the maxima of mmvae_adv_pass_plan over the
- * jobs; launch_ticket: one zero word */
-int mmvae_adv_pass_f32(int n_jobs, const mmvae_adv_job* jobs_dev, int B, int splits, int net, size_t lds_bytes,
-                       uint32_t* launch_ticket, mmvae_stream_t stream);
+ * jobs; fast: 1 only if every job planned fast.  Two launches (forward, backward). */
+int mmvae_adv_pass_f32(int n_jobs, const mmvae_adv_job* jobs_dev, int B, int splits, int net, int fast, size_t lds_bytes,
+                       mmvae_stream_t stream);
 
 typedef struct {
     const float* dz;      /* [B, M] gradient at the Linear's output -- or, with `lse`, the logits of mmvae_adv_pass_f32 */
@@ -676,10 +678,13 @@ typedef struct {
     uint32_t flags;       /* MMVAE_PREPARE_*; 0: leave the state alone (norm_out is still written) */
     uint32_t reserved;
 } mmvae_adv_opt;
-int mmvae_adv_dw_prepare(int n_jobs, mmvae_adv_dw_job* jobs_host, int* total_blocks);
+/* host-only: fills first_block / n_blocks; *fast: 1 when every job's M, N and leading dimensions are multiples of 4 and its
+ * operands 16-byte aligned (pass it on to the launch: the 16-byte loaders) */
+int mmvae_adv_dw_prepare(int n_jobs, mmvae_adv_dw_job* jobs_host, int* total_blocks, int* fast);
 /* partials: total_blocks floats; ticket: one zero word */
 int mmvae_adv_dw_f32(int n_jobs, const mmvae_adv_dw_job* jobs_dev, int total_blocks, int n_opts,
-                     const mmvae_adv_opt* opts_dev, float* partials, uint32_t* ticket, mmvae_stream_t stream);
+                     const mmvae_adv_opt* opts_dev, float* partials, uint32_t* ticket, int n_adv,
+                     const mmvae_adv_job* adv_jobs_dev, int fast, mmvae_stream_t stream);
 
 typedef struct {
     float *p, *g, *m, *v;

@@ -144,10 +144,10 @@ PROTOTYPES = {
     "mmvae_gemm_batch_job_ok": (_i, [_p]),
     "mmvae_gemm_batch_prepare": (_i, [_i, _p, C.POINTER(_i)]),
     "mmvae_gemm_batch_f32": (_i, [_i, _p, _i, _p]),
-    "mmvae_adv_pass_plan": (_i, [_p, _i, C.POINTER(_i), C.POINTER(_z), C.POINTER(_l)]),
-    "mmvae_adv_pass_f32": (_i, [_i, _p, _i, _i, _i, _z, _p, _p]),
-    "mmvae_adv_dw_prepare": (_i, [_i, _p, C.POINTER(_i)]),
-    "mmvae_adv_dw_f32": (_i, [_i, _p, _i, _i, _p, _p, _p, _p]),
+    "mmvae_adv_pass_plan": (_i, [_p, _i, C.POINTER(_i), C.POINTER(_z), C.POINTER(_l), C.POINTER(_i)]),
+    "mmvae_adv_pass_f32": (_i, [_i, _p, _i, _i, _i, _i, _z, _p]),
+    "mmvae_adv_dw_prepare": (_i, [_i, _p, C.POINTER(_i), C.POINTER(_i)]),
+    "mmvae_adv_dw_f32": (_i, [_i, _p, _i, _i, _p, _p, _p, _i, _p, _i, _p]),
     "mmvae_adam_step_multi": (_i, [_i, _p, _l, _p]),
 }
 
@@ -181,7 +181,7 @@ class AdvJob(C.Structure):
     _fields_ = [("x", _p), ("ldx", _l), ("W", _p * ADV_MAX_LAYERS), ("b", _p * ADV_MAX_LAYERS),
                 ("mask", _p * ADV_MAX_LAYERS), ("act", _p * ADV_MAX_LAYERS), ("dz", _p * ADV_MAX_LAYERS), ("Wh", _p),
                 ("bh", _p), ("labels", _p), ("logits", _p), ("lse", _p), ("loss_rows", _p), ("gx", _p), ("partials", _p),
-                ("tickets", _p), ("loss_each", _p), ("loss_total", _p), ("total_loss", _p), ("total_scale", _f),
+                ("loss_each", _p), ("loss_total", _p), ("total_loss", _p), ("total_scale", _f),
                 ("gscale", _f), ("p_drop", _f * ADV_MAX_LAYERS), ("relu", C.c_int32 * ADV_MAX_LAYERS),
                 ("width", C.c_int32 * (ADV_MAX_LAYERS + 1)), ("n_layers", C.c_int32), ("H", C.c_int32),
                 ("Ct", C.c_int32), ("B", C.c_int32), ("col", C.c_int32 * ADV_MAX_HEADS),

@@ -69,7 +69,7 @@ def supported(lib, net: AdvNet, B: int, splits: int = 1, tiles: int = 0):
     for h, (c, n) in enumerate(zip(net.col, net.classes)):
         job.col[h], job.classes[h] = c, n
     nt, lds, pf = C.c_int(tiles), C.c_size_t(0), C.c_int64(0)
-    if lib.mmvae_adv_pass_plan(C.addressof(job), splits, C.byref(nt), C.byref(lds), C.byref(pf)) != _lib.OK:
+    if lib.mmvae_adv_pass_plan(C.addressof(job), splits, C.byref(nt), C.byref(lds), C.byref(pf), None) != _lib.OK:
         return None
     return nt.value, lds.value, pf.value
 
@@ -82,12 +82,15 @@ class AdvProgram:
     total_loss (address or None), total_scale, opt flags / max_norm / norm_out[i]).
     """
 
-    def __init__(self, lib, alloc: Callable, nets: List[AdvNet], B: int, labels: torch.Tensor, device, tag: str = "adv"):
+    def __init__(self, lib, alloc: Callable, nets: List[AdvNet], B: int, labels: torch.Tensor, device, tag: str = "adv",
+                 splits: Optional[int] = None):
         self.lib, self.nets, self.B, self.labels, self.device = lib, nets, B, labels, device
         self.H = len(nets[0].classes)
         n_rt = (B + 15) // 16
         tiles = min(sum((((c + 3) // 4 * 4) + 15) // 16 for c in n.classes) for n in nets)
-        self.splits = max(1, min(8, tiles, 256 // max(1, n_rt * len(nets))))
+        # class splits per cell tile: enough workgroups to cover the chip (results depend on the split count only
+        # through the order in which the partial sums are merged)
+        self.splits = max(1, min(8, tiles, 256 // max(1, n_rt * len(nets)))) if splits is None else int(splits)
         plans = [supported(lib, n, B, self.splits) for n in nets]
         if any(p is None for p in plans):
             raise _lib.HipLibraryError("adv_program: unsupported adversary shape (call supported() first)")
@@ -108,7 +111,6 @@ class AdvProgram:
                 loss_rows=alloc(f"{tag}{i}.ce_rows", (self.H, B), torch.float32),
                 gx=alloc(f"{tag}{i}.gh", (B, widths[0]), torch.float32),
                 partials=alloc(f"{tag}{i}.partials.{self.splits}.{self.net}", (plan[2],), torch.float32),
-                tickets=alloc(f"{tag}{i}.tickets", (n_rt,), torch.int32),
             )
             self.bufs.append(b)
         self.launch_tickets = alloc(f"{tag}.launch_tickets", (4,), torch.int32)
@@ -134,7 +136,7 @@ class AdvProgram:
             for l in range(len(n.layers)):
                 job.act[l], job.dz[l] = _p(b["act"][l]), _p(b["dz"][l])
             job.logits, job.lse, job.loss_rows = _p(b["logits"]), _p(b["lse"]), _p(b["loss_rows"])
-            job.partials, job.tickets = _p(b["partials"]), _p(b["tickets"])
+            job.partials = _p(b["partials"])
             job.gx = _p(b["gx"]) if cfg["reverse"] else None
             job.loss_each, job.loss_total = cfg["loss_each"][i], cfg["loss_total"][i]
             job.total_loss, job.total_scale = cfg.get("total_loss"), float(cfg.get("total_scale", 0.0))
@@ -152,6 +154,12 @@ class AdvProgram:
         lib, nets = self.lib, self.nets
         jobs = (_lib.AdvJob * len(nets))(*[self._host_job(n, b, phase, cfg, i)
                                            for i, (n, b) in enumerate(zip(nets, self.bufs))])
+        fast = 1
+        for j in jobs:  # the 16-byte loaders need every job's rows aligned (mmvae_adv_pass_plan decides)
+            f, nt = C.c_int(0), C.c_int(self.net)
+            _lib.check(lib.mmvae_adv_pass_plan(C.addressof(j), self.splits, C.byref(nt), None, None, C.byref(f)),
+                       "mmvae_adv_pass_plan")
+            fast &= f.value
         dw = []
         for i, (n, b) in enumerate(zip(nets, self.bufs)):
             inputs = [(n.x, n.ldx)] + [(a, a.shape[1]) for a in b["act"]]
@@ -173,8 +181,9 @@ class AdvProgram:
                 j.col[h], j.classes[h] = c, k
             dw.append(j)
         dw_arr = (_lib.AdvDwJob * len(dw))(*dw)
-        total = C.c_int(0)
-        _lib.check(lib.mmvae_adv_dw_prepare(len(dw), C.addressof(dw_arr), C.byref(total)), "mmvae_adv_dw_prepare")
+        total, dw_fast = C.c_int(0), C.c_int(0)
+        _lib.check(lib.mmvae_adv_dw_prepare(len(dw), C.addressof(dw_arr), C.byref(total), C.byref(dw_fast)),
+                   "mmvae_adv_dw_prepare")
         opts_dev, n_opts = None, 0
         if cfg.get("opts") is not None:
             arr = []
@@ -188,7 +197,7 @@ class AdvProgram:
                 arr.append(a)
             opts_dev, n_opts = self._to_device((_lib.AdvOpt * len(arr))(*arr)), len(arr)
         self.phase_tables[phase] = dict(
-            jobs=self._to_device(jobs), dw=self._to_device(dw_arr), n_dw=len(dw), blocks=total.value, opts=opts_dev,
+            jobs=self._to_device(jobs), fast=fast, dw=self._to_device(dw_arr), dw_fast=dw_fast.value, n_dw=len(dw), blocks=total.value, opts=opts_dev,
             n_opts=n_opts)
         self.dw_partials = getattr(self, "dw_partials", None)
         if self.dw_partials is None or self.dw_partials.numel() < total.value:
@@ -209,14 +218,14 @@ class AdvProgram:
     # ------------------------------------------------------------------------------------------------ launches
     def launch_pass(self, phase: str) -> None:
         t = self.phase_tables[phase]
-        _lib.check(self.lib.mmvae_adv_pass_f32(len(self.nets), t["jobs"].data_ptr(), self.B, self.splits, self.net, self.lds,
-                                               self.launch_tickets.data_ptr(), _stream()), "mmvae_adv_pass_f32")
+        _lib.check(self.lib.mmvae_adv_pass_f32(len(self.nets), t["jobs"].data_ptr(), self.B, self.splits, self.net, t["fast"],
+                                               self.lds, _stream()), "mmvae_adv_pass_f32")
 
     def launch_dw(self, phase: str) -> None:
         t = self.phase_tables[phase]
         _lib.check(self.lib.mmvae_adv_dw_f32(t["n_dw"], t["dw"].data_ptr(), t["blocks"], t["n_opts"], _p(t["opts"]),
-                                             self.dw_partials.data_ptr(), self.launch_tickets.data_ptr() + 4, _stream()),
-                   "mmvae_adv_dw_f32")
+                                             self.dw_partials.data_ptr(), self.launch_tickets.data_ptr(), len(self.nets),
+                                             t["jobs"].data_ptr(), t["dw_fast"], _stream()), "mmvae_adv_dw_f32")
 
     def launch_adam(self) -> None:
         _lib.check(self.lib.mmvae_adam_step_multi(len(self.nets), self.adam_table.data_ptr(), self.adam_max_n, _stream()),

@@ -207,7 +207,7 @@ def test_adv_two_jobs_one_launch_and_adam_multi():
     def run(which):
         nets = [_build(w, classes, B, seed=s, p_drop=0.0, device=dev)[0] for w, s in which]
         metrics = torch.zeros(256, device=dev)
-        prog = AdvProgram(lib, _Pool(dev), nets, B, labels, dev)
+        prog = AdvProgram(lib, _Pool(dev), nets, B, labels, dev, splits=4)  # (the merge order follows the split count)
         n = len(nets)
         cfg = dict(gscale=25.0, reverse=True, loss_each=[metrics.data_ptr() + 4 * 8 * i for i in range(n)],
                    loss_total=[metrics.data_ptr() + 4 * (8 * i + H) for i in range(n)], total_loss=metrics.data_ptr() + 4 * 100,
