@@ -644,12 +644,15 @@ typedef struct {
     int32_t n_layers, H, Ct, B;
     int32_t col[MMVAE_ADV_MAX_HEADS];     /* first column of head h in the stacked matrix (multiple of 4 when H > 1) */
     int32_t classes[MMVAE_ADV_MAX_HEADS];
+    /* filled by mmvae_adv_pass_plan: class split s works on the 16-class tiles [seg_lo, seg_hi) of head h */
+    int16_t seg_lo[8][MMVAE_ADV_MAX_HEADS], seg_hi[8][MMVAE_ADV_MAX_HEADS];
 } mmvae_adv_job;
 /* host-only: MMVAE_OK when the job's shape is supported.  *net in: 0 = choose (out: 1, 2, 4 or 8 >= ceil(width[L] / 16)),
  * or the tile count of the launch the job will share with wider jobs; out: the dynamic LDS bytes of a workgroup and the
  * floats of `partials` for `splits` (<= 8) class splits, both at that tile count; *fast: 1 when every width, Ct, ldx and
- * head start is a multiple of 4 and the pointers filled in so far are 16-byte aligned (the kernels' 16-byte loaders) */
-int mmvae_adv_pass_plan(const mmvae_adv_job* job_host, int splits, int* net, size_t* lds_bytes, int64_t* partial_floats,
+ * head start is a multiple of 4 and the pointers filled in so far are 16-byte aligned (the kernels' 16-byte loaders).
+ * Also fills the job's seg_lo / seg_hi (which class tiles each split works on): plan every job before uploading it. */
+int mmvae_adv_pass_plan(mmvae_adv_job* job_host, int splits, int* net, size_t* lds_bytes, int64_t* partial_floats,
                         int* fast);
 /* jobs_dev: DEVICE array of n_jobs jobs with the same B; net / lds_bytes: the maxima of mmvae_adv_pass_plan over the
  * jobs; fast: 1 only if every job planned fast.  Two launches (forward, backward). */

@@ -185,7 +185,8 @@ class AdvJob(C.Structure):
                 ("gscale", _f), ("p_drop", _f * ADV_MAX_LAYERS), ("relu", C.c_int32 * ADV_MAX_LAYERS),
                 ("width", C.c_int32 * (ADV_MAX_LAYERS + 1)), ("n_layers", C.c_int32), ("H", C.c_int32),
                 ("Ct", C.c_int32), ("B", C.c_int32), ("col", C.c_int32 * ADV_MAX_HEADS),
-                ("classes", C.c_int32 * ADV_MAX_HEADS)]
+                ("classes", C.c_int32 * ADV_MAX_HEADS), ("seg_lo", (C.c_int16 * ADV_MAX_HEADS) * 8),
+                ("seg_hi", (C.c_int16 * ADV_MAX_HEADS) * 8)]
 
 
 class AdvDwJob(C.Structure):

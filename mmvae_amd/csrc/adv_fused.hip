@@ -232,19 +232,14 @@ __global__ __launch_bounds__(AT) void adv_fwd_kernel(const mmvae_adv_job* __rest
     float* wt = lds + Y.wt_off + wave * 16 * WS;
     const float* __restrict__ Wh = J.Wh;
     const float* __restrict__ bh = J.bh;
-    int T = 0;
-    for (int h = 0; h < H; ++h) T += head_tiles(J.classes[h]);
-    const int t_lo = (int)((int64_t)sp * T / splits), t_hi = (int)((int64_t)(sp + 1) * T / splits);
     float* part = J.partials + (int64_t)(rt * splits + sp) * H * PST;
     float* trash = J.partials + (int64_t)((B + AR - 1) / AR) * splits * H * PST;  // 256 floats nobody reads
 #if MMVAE_ADV_STAMPS
     long long qsum[4] = {0, 0, 0, 0};
 #endif
-    int base = 0;
     for (int h = 0; h < H; ++h) {
-        const int C = J.classes[h], col = J.col[h], C4 = pad4(C), th = head_tiles(C);
-        const int lo = (t_lo > base ? t_lo : base) - base, hi = (t_hi < base + th ? t_hi : base + th) - base;
-        base += th;
+        const int C = J.classes[h], col = J.col[h], C4 = pad4(C);
+        const int lo = J.seg_lo[sp][h], hi = J.seg_hi[sp][h];  // this split's tiles of head h (mmvae_adv_pass_plan)
         float m_run = -INFINITY, s_run = 0.f;
         f32x4 acc[NET];
 #pragma unroll
@@ -874,9 +869,12 @@ __global__ __launch_bounds__(AT) void adv_dw_kernel(const mmvae_adv_dw_job* __re
         }
         dred[tid] = s;
         __syncthreads();
+        for (int st = AT / 2; st >= 1; st >>= 1) {  // fixed tree (a serial sum by one thread cost ~10 us per optimiser)
+            if (tid < st) dred[tid] += dred[tid + st];
+            __syncthreads();
+        }
         if (tid == 0) {
-            double t = 0.0;
-            for (int i = 0; i < AT; ++i) t += dred[i];
+            const double t = dred[0];
             const mmvae_adv_opt op = opts[o];
             if (op.flags) adam_state_finish(op.state, t, op.flags, op.max_norm, op.grad_scale, op.beta1, op.beta2);
             if (op.norm_out) op.norm_out[0] = (float)(sqrt(t) * (double)fabsf(op.grad_scale));
@@ -906,8 +904,56 @@ int launch_pass(int n_jobs, const mmvae_adv_job* jobs_dev, int B, int splits, si
 
 }  // namespace
 
-extern "C" int mmvae_adv_pass_plan(const mmvae_adv_job* job, int splits, int* net, size_t* lds_bytes,
-                                   int64_t* partial_floats, int* fast) {
+// Which class tiles of which head a split works on.  A head costs a round of fixed overhead (first loads, the waves'
+// merge) plus its tiles / 8 waves; the rounds of a split run one after the other.  Small heads go whole to the least
+// loaded split, the tiles of big heads then fill the splits up to a common level.
+static void plan_segments(mmvae_adv_job* job, int splits) {
+    const int H = job->H;
+    const double round_cost = 2.5;  // in units of one tile per wave (~4 us against ~1.7 us, measured at config C4)
+    double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int tiles[MMVAE_ADV_MAX_HEADS];
+    bool big[MMVAE_ADV_MAX_HEADS];
+    for (int s = 0; s < 8; ++s)
+        for (int h = 0; h < MMVAE_ADV_MAX_HEADS; ++h) job->seg_lo[s][h] = job->seg_hi[s][h] = 0;
+    for (int h = 0; h < H; ++h) {
+        tiles[h] = head_tiles(job->classes[h]);
+        big[h] = tiles[h] >= 16 * splits;
+    }
+    for (int pass = 0; pass < H; ++pass) {  // small heads, largest first
+        int h = -1;
+        for (int q = 0; q < H; ++q)
+            if (!big[q] && tiles[q] > 0 && (h < 0 || tiles[q] > tiles[h])) h = q;
+        if (h < 0) break;
+        int best = 0;
+        for (int s = 1; s < splits; ++s)
+            if (load[s] < load[best]) best = s;
+        job->seg_lo[best][h] = 0;
+        job->seg_hi[best][h] = tiles[h];
+        load[best] += round_cost + (tiles[h] + 7) / 8;
+        tiles[h] = 0;
+    }
+    for (int h = 0; h < H; ++h) {
+        if (!big[h]) continue;
+        // level the splits: every split takes a share; rounds(s) = level - load(s) - round_cost
+        double sum = 0;
+        for (int s = 0; s < splits; ++s) sum += load[s] + round_cost;
+        const double level = (sum + tiles[h] / 8.0) / splits;
+        int next = 0;
+        for (int s = 0; s < splits; ++s) {
+            double want = (level - load[s] - round_cost) * 8.0;
+            int n = s == splits - 1 ? tiles[h] - next : (int)(want + 0.5);
+            if (n < 0) n = 0;
+            if (n > tiles[h] - next) n = tiles[h] - next;
+            job->seg_lo[s][h] = next;
+            job->seg_hi[s][h] = next + n;
+            next += n;
+            load[s] += n > 0 ? round_cost + (n + 7) / 8 : 0;
+        }
+    }
+}
+
+extern "C" int mmvae_adv_pass_plan(mmvae_adv_job* job, int splits, int* net, size_t* lds_bytes, int64_t* partial_floats,
+                                   int* fast) {
     if (!job || splits < 1 || splits > 8) return MMVAE_ERR_ARG;
     const int L = job->n_layers, H = job->H;
     if (L < 1 || L > MMVAE_ADV_MAX_LAYERS || H < 1 || H > MMVAE_ADV_MAX_HEADS || job->B < 1) return MMVAE_ERR_ARG;
@@ -935,6 +981,7 @@ extern "C" int mmvae_adv_pass_plan(const mmvae_adv_job* job, int splits, int* ne
     adv_lds_layout(Y, job->width, L, pick, H, splits);
     const size_t bytes = (size_t)Y.total * 4;
     if (bytes > 160 * 1024 - 2048 - sizeof(mmvae_adv_job) - 64) return MMVAE_ERR_ARG;
+    plan_segments(job, splits);
     if (net) *net = pick;
     if (lds_bytes) *lds_bytes = bytes;
     if (fast) {
