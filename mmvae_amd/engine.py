@@ -258,6 +258,10 @@ class StepEngine:
             ov = os.environ.get("MMVAE_DP_OVERLAP", os.environ.get("MMVAE_DEFER_EXPERT_ADAM", ""))
             defer = (ov != "0") if ov != "" else mdist.collectives_active()
         self.overlap = bool(defer)
+        # sharded expert update under data parallelism: reduce-scatter of the gradient arena, clip + Adam on this rank's
+        # 1 / world of it, all-gather of the parameters -- the same bytes on the wire as the all-reduce, the 1.2 GB
+        # Adam pass world times shorter (MMVAE_DP_SHARD=0: all-reduce + the full update on every rank)
+        self.shard = mdist.collectives_active() and os.environ.get("MMVAE_DP_SHARD", "1") != "0"
         # The wave-specialised GEMM kernel runs ONE persistent workgroup per CU with statically dealt work items: a
         # collective's workgroups holding CUs beside it (the previous step's all-reduce under data parallelism) would
         # delay whole workgroups by a round.  Under a gradient exchange the 2 x 4-wave kernel (measured sensitivity:
@@ -1136,6 +1140,11 @@ class _Plan:
         b1, b2 = g["betas"]
         gs = 1.0 / self.eng.world
         npart = self.lib.mmvae_sqnorm_partials(a.numel)
+        sh = a.shard(self.eng.world, mdist.rank()) if (self.eng.shard and opt is self.opt_exp and self.cond is None
+                                                       and exchange in ("inline", "deferred")
+                                                       and opt.reducer is not None) else None
+        if sh is not None:
+            return self._optimizer_sharded(opt, sh, max_norm, advance, step, exchange)
         if opt.reducer is not None or self.eng.overlap:
             self._cut(("ar_" + exchange, opt))
         if self.cond is not None and opt is self.opt_vae:
@@ -1186,6 +1195,39 @@ class _Plan:
                        _p(opt.state_dev), g["lr"], b1, b2, g["eps"], g["weight_decay"], gs, probe=pr)
         if step and pr:
             self.probe_meta["adam_expert"].update(bound="hbm", cus=0, shape=f"{a.numel} parameters, 28 B each")
+
+    def _optimizer_sharded(self, opt: HipAdam, sh, max_norm, advance, step, exchange):
+        """The expert's update under data parallelism, sharded ("prefer direct reduce-scatter + all-gather"):
+        reduce-scatter of the gradient arena -> sum of squares of this rank's slice, all-gathered (world floats; every
+        rank sums them in rank order: identical norms) -> clip + Adam on the slice -> all-gather of the parameters.
+        Replicas stay bit-identical: every parameter is computed once, by its owner."""
+        a, g, lib = opt.arena, opt.param_groups[0], self.lib
+        b1, b2 = g["betas"]
+        gs = 1.0 / self.eng.world
+        per, lo, n_loc = sh
+        W = self.eng.world
+        mine = self.eng.buf(f"shard.sq.{id(opt)}", (1,))
+        allsq = self.eng.buf(f"shard.allsq.{id(opt)}", (W,))
+        self.shard_info = dict(per=per, lo=lo, n_loc=n_loc, mine=mine, allsq=allsq)
+        opt.sharded = True
+        self._cut(("rs_" + exchange, opt))
+        if n_loc > 0:
+            np_loc = int(lib.mmvae_sqnorm_partials(n_loc))
+            parts = self.eng.buf(f"shard.parts.{id(opt)}", (np_loc,))
+            self._emit(lib.mmvae_grad_sqnorm, n_loc, a.grad.data_ptr() + 4 * lo, _p(parts))
+            self._emit(lib.mmvae_sum_f32, np_loc, _p(parts), _p(mine), 0)
+        else:  # (more ranks than 4-element groups: this rank owns nothing)
+            self._emit(lib.mmvae_axpby, 1, 0.0, _p(mine), 0.0, _p(mine))
+        self._cut(("ag_norm", opt))
+        flags = _lib.PREPARE_NORM | (_lib.PREPARE_ADVANCE if (advance and step) else 0)
+        self._emit(lib.mmvae_adam_prepare, W, _p(allsq), max_norm, gs, b1, b2, _p(opt.state_dev), flags)
+        if step and n_loc > 0:
+            self._emit(lib.mmvae_adam_step, n_loc, a.data.data_ptr() + 4 * lo, a.grad.data_ptr() + 4 * lo,
+                       a.exp_avg.data_ptr() + 4 * lo, a.exp_avg_sq.data_ptr() + 4 * lo, _p(opt.state_dev), g["lr"], b1, b2,
+                       g["eps"], g["weight_decay"], gs, probe=("adam_expert", 28.0 * n_loc))
+            self.probe_meta["adam_expert"].update(bound="hbm", cus=0, shape=f"{n_loc} parameters (1/{W} of the arena), 28 B each")
+        if step:
+            self._cut(("ag_params", opt))
 
     def _begin_exchange(self, opt: HipAdam):
         """All gradients of `opt` are final here: start their all-reduce on the small-message stream."""
@@ -1622,7 +1664,8 @@ class _Plan:
         # in-order program: the log copy rides on the expert's Adam launch (its words -- losses, both norms -- are final
         # once adam_prepare has run) when the expert's norm is a state word inside the metrics buffer
         ride = (not early and eng.fuse_norm_prepare and self.cond is None
-                and eng._state_slot.get(id(self.opt_exp)) is not None)
+                and eng._state_slot.get(id(self.opt_exp)) is not None
+                and not (eng.shard and self.opt_exp.reducer is not None))
         self.optimizer(self.opt_exp, self.clip_exp, exchange="deferred" if early else "inline",
                        tail_copy=(256, self.metrics, self.log_buf) if ride else None)
         if early:
@@ -1989,6 +2032,29 @@ class _Plan:
                 with torch.cuda.stream(eng.comm_stream):
                     red.reduce_here(opt.arena.grad)
             return eng.comm_stream
+        elif kind in ("rs_inline", "rs_deferred", "ag_norm", "ag_params"):
+            import contextlib
+            import torch.distributed as tdist
+
+            si, a, W = self.shard_info, opt.arena, eng.world
+            if kind == "rs_deferred":
+                eng.comm_stream.wait_stream(main)
+                tail = eng.comm_stream
+            live = red is not None and not mdist.DRY_RUN
+            with (torch.cuda.stream(tail) if tail is not None else contextlib.nullcontext()):
+                if kind.startswith("rs_"):
+                    full = a.grad_full[:si["per"] * W]
+                    if live:
+                        tdist.reduce_scatter_tensor(full[si["lo"]:si["lo"] + si["per"]], full, op=tdist.ReduceOp.SUM,
+                                                    group=red.group)
+                elif kind == "ag_norm":
+                    if live:
+                        tdist.all_gather_into_tensor(si["allsq"], si["mine"], group=red.group)
+                    else:  # (no peers to hear from: the slice's own sum)
+                        si["allsq"][:1].copy_(si["mine"])
+                elif live:
+                    full = a.data_full[:si["per"] * W]
+                    tdist.all_gather_into_tensor(full, full[si["lo"]:si["lo"] + si["per"]], group=red.group)
         else:
             raise _lib.HipLibraryError(f"engine: unknown exchange marker {kind}")
         return tail

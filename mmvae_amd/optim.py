@@ -68,14 +68,26 @@ class ParamArena:
         # 32 spare elements behind each arena: its tensors may be read as rows-contiguous GEMM operands in 16-byte groups
         # up to 12 bytes past their end (MMVAE_GEMM_OPERAND_SLACK), a weight matrix row up to the next multiple of 32
         # columns (mmvae_recon_set_h_kpad)
-        self.data = torch.zeros(n + 32, dtype=torch.float32, device=dev)[:n]
-        self.grad = torch.zeros(n + 32, dtype=torch.float32, device=dev)[:n]
+        # (the padded tensors themselves: a sharded exchange works on the arena rounded up to 4 x world elements)
+        self.data_full = torch.zeros(n + 32, dtype=torch.float32, device=dev)
+        self.grad_full = torch.zeros(n + 32, dtype=torch.float32, device=dev)
+        self.data, self.grad = self.data_full[:n], self.grad_full[:n]
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         for p, off in zip(self.params, self.offsets):
             view = self.data[off:off + p.numel()].view(p.shape)
             view.copy_(p.data)
             p.data = view
+
+    def shard(self, world: int, rank: int):
+        """(elements per shard, first element, valid elements) of rank `rank`'s contiguous slice when the arena, rounded up
+        to world equal slices of a multiple of 4 elements, is reduce-scattered / all-gathered; None when the rounding
+        does not fit in the 32 spare elements behind the arena."""
+        per = (self.numel + 4 * world - 1) // (4 * world) * 4
+        if per * world > self.numel + 32:
+            return None
+        lo = rank * per
+        return per, lo, max(0, min(per, self.numel - lo))
 
     def view(self, arena: torch.Tensor, i: int) -> torch.Tensor:
         p, off = self.params[i], self.offsets[i]
@@ -137,6 +149,10 @@ class HipAdam(torch.optim.Optimizer):
         self.max_grad_norm = max_grad_norm
         self.grad_scale = 1.0  # 1 / world_size under DDP (gradient averaging)
         self.reducer = None  # mmvae_amd.dist.GradAllReducer under DDP
+        # The step engine's data-parallel program updates only this rank's slice of the arena (reduce-scatter -> clip + Adam
+        # on the slice -> all-gather of the parameters): the Adam moments of the other slices are then stale here until
+        # sync_sharded_state() gathers them (checkpoints, a switch to the module path).
+        self.sharded = False
         self._hip = self.arena.device.type == "cuda"
         if not self._hip and not backend.cpu_plumbing_enabled():
             raise RuntimeError("HipAdam needs device parameters (or caller-enabled backend.cpu_plumbing())")
@@ -150,6 +166,24 @@ class HipAdam(torch.optim.Optimizer):
         self._inactive: List[int] = []
         if self._hip:
             self.partials = torch.empty(max(ops.sqnorm_partials(self.arena.numel), 1), dtype=torch.float32, device=dev)
+
+    def sync_sharded_state(self) -> None:
+        """All-gather the Adam moments after sharded steps (collective: every rank must call it at the same point)."""
+        if not self.sharded:
+            return
+        self.sharded = False
+        if not mdist.collectives_active():
+            return
+        a = self.arena
+        sh = a.shard(mdist.world_size(), mdist.rank())
+        per, lo, n_loc = sh
+        dev = a.data.device
+        for t in (a.exp_avg, a.exp_avg_sq):
+            full = torch.zeros(per * mdist.world_size(), dtype=torch.float32, device=dev)
+            mine = torch.zeros(per, dtype=torch.float32, device=dev)
+            mine[:n_loc] = t[lo:lo + n_loc]
+            torch.distributed.all_gather_into_tensor(full, mine)
+            t.copy_(full[:a.numel])
 
     # ---- Lightning-style clipping hook: remembered, applied inside step()
     def set_clip(self, max_norm: Optional[float]) -> None:
@@ -241,6 +275,7 @@ class HipAdam(torch.optim.Optimizer):
         if closure is not None:
             raise NotImplementedError("closures are not used by the MMVAE trainer")
         a = self.arena
+        self.sync_sharded_state()
         reuse = getattr(self, "_norm_valid", False)
         if not reuse:
             self._inactive = self._gather()
@@ -375,6 +410,7 @@ class HipAdam(torch.optim.Optimizer):
     # ---- checkpoint surface compatible with torch.optim.Adam's per-parameter state
     def state_dict(self):
         a = self.arena
+        self.sync_sharded_state()
         step_of = (lambda i: torch.tensor(float(self._steps[i]))) if self._steps is not None else (
             lambda i: self.state_dev[0].detach().clone().cpu())
         st = {i: {"step": step_of(i), "exp_avg": a.view(a.exp_avg, i).clone(),

@@ -312,3 +312,87 @@ def test_two_rank_adversarial_steps_keep_the_replicas_identical():
     adversaries, shared VAE, active expert -- exchanges its gradients; the replicas stay bit-identical."""
     world, port = 2, _free_port()
     mp.spawn(_adv_worker, args=(world, port, ""), nprocs=world, join=True)
+
+
+# ------------------------------------------------------------------------------------------- sharded expert update
+@pytest.mark.parametrize("numel,world", [(42_003_456, 8), (1000, 8), (1001, 2), (7, 8), (4, 1), (170_000_123, 4)])
+def test_arena_shards_partition_the_padded_arena(numel, world):
+    """ParamArena.shard: equal slices of a multiple of 4 elements, in rank order, covering the arena once; the rounding
+    stays inside the 32 spare elements behind an arena (else None: the engine falls back to the all-reduce)."""
+    from mmvae_amd.optim import ParamArena
+
+    a = ParamArena.__new__(ParamArena)
+    a.numel = numel
+    sh = [a.shard(world, r) for r in range(world)]
+    assert all(s is not None for s in sh)
+    per = sh[0][0]
+    assert per % 4 == 0 and per * world >= numel and per * world <= numel + 32
+    assert [s[1] for s in sh] == [r * per for r in range(world)]
+    assert sum(s[2] for s in sh) == numel and all(0 <= s[2] <= per for s in sh)
+
+
+def _shard_worker(rank, world, port, out_dir):
+    """The arithmetic of the engine's sharded update (engine._optimizer_sharded) replayed with torch ops over gloo:
+    reduce-scatter -> slice norm, all-gathered -> clip + Adam on the slice -> all-gather of the parameters; against the
+    unsharded all-reduce + full update (HipAdam CPU plumbing).  Then HipAdam.sync_sharded_state()."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      MMVAE_DIST_TIMEOUT_S="120")
+    torch.set_num_threads(1)
+    from mmvae_amd import backend, dist as mdist
+    from mmvae_amd.optim import HipAdam
+
+    assert mdist.init_from_env("gloo") == world
+    with backend.cpu_plumbing():
+        torch.manual_seed(5)
+        params = [torch.nn.Parameter(torch.randn(n)) for n in (1001, 37, 4096, 3)]
+        ref_params = [torch.nn.Parameter(p.detach().clone()) for p in params]
+        opt, ref = HipAdam(params, max_grad_norm=10.0), HipAdam(ref_params, max_grad_norm=10.0)
+        a, ar = opt.arena, ref.arena
+        per, lo, n_loc = a.shard(world, rank)
+        g_cfg = opt.param_groups[0]
+        b1, b2 = g_cfg["betas"]
+        for step in range(1, 4):
+            torch.manual_seed(100 * step + rank)
+            local = torch.randn(a.numel) * 3.0  # this rank's gradients
+            # unsharded: all-reduce, then the full update on every rank
+            ar.grad.copy_(local)
+            dist.all_reduce(ar.grad)
+            ref.grad_scale = 1.0 / world
+            ar.gather_grads = lambda *x, **k: []
+            ref.step()
+            # sharded
+            a.grad.copy_(local)
+            full = a.grad_full[:per * world]
+            dist.reduce_scatter_tensor(full[lo:lo + per], full)
+            gs = 1.0 / world
+            mine = (a.grad[lo:lo + n_loc].double() ** 2).sum().float().reshape(1)
+            allsq = torch.zeros(world)
+            dist.all_gather_into_tensor(allsq, mine)
+            norm = float(allsq.double().sum().sqrt()) * gs
+            clip = min(1.0, 10.0 / (norm + 1e-6))
+            sl = slice(lo, lo + n_loc)
+            gr = a.grad[sl] * gs * clip + g_cfg["weight_decay"] * a.data[sl]
+            a.exp_avg[sl].lerp_(gr, 1 - b1)
+            a.exp_avg_sq[sl].mul_(b2).addcmul_(gr, gr, value=1 - b2)
+            denom = a.exp_avg_sq[sl].sqrt() / ((1 - b2 ** step) ** 0.5) + g_cfg["eps"]
+            a.data[sl].addcdiv_(a.exp_avg[sl], denom, value=-g_cfg["lr"] / (1 - b1 ** step))
+            dfull = a.data_full[:per * world]
+            dist.all_gather_into_tensor(dfull, dfull[lo:lo + per])
+            assert H.rel_l2(a.data, ar.data) < 2e-6, (step, H.rel_l2(a.data, ar.data))
+            gathered = [torch.empty_like(a.data) for _ in range(world)]
+            dist.all_gather(gathered, a.data.clone())
+            assert all(torch.equal(gathered[0], t) for t in gathered), "replicas diverged"
+        # the moments of the other slices are stale until they are gathered
+        stale = a.exp_avg.clone()
+        opt.sharded = True
+        opt.sync_sharded_state()
+        assert not opt.sharded
+        assert H.rel_l2(a.exp_avg, ar.exp_avg) < 2e-6 and H.rel_l2(a.exp_avg_sq, ar.exp_avg_sq) < 2e-6
+        assert world == 1 or not torch.equal(stale, a.exp_avg)
+        assert torch.equal(a.exp_avg[sl], stale[sl])
+    dist.destroy_process_group()
+
+
+def test_sharded_update_equals_all_reduce_update_and_moments_gather(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_shard_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
