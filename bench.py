@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--sim-comm", default="", help="diagnostics: CUS,LDS_KB,MICROS -- a stand-in for a collective beside the "
                                                    "step: that many workgroups holding that much LDS each spin on a side "
                                                    "stream for that long, started with every step (DESIGN.md section 7)")
+    ap.add_argument("--sim-world", type=int, default=0, help="diagnostics (timing only): with --gpus 1 and "
+                    "MMVAE_SINGLE_RANK_COLLECTIVES=1, give the sharded expert update the slice of a world of N ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block (one step of the timed program "
                                                              "against the oracle, ~2 s, outside the timed region)")
@@ -265,10 +267,17 @@ def build_model(a, cfg, device):
 
 def main():
     a = parse()
+    if a.sim_world:
+        os.environ["MMVAE_DP_SIM_WORLD"] = str(a.sim_world)
     if a.gpus > 1 and "RANK" not in os.environ:  # plain launch: this process becomes the launcher (no GPU call so far)
         sys.exit(spawn_ranks(sys.argv[1:], a.gpus))
     from mmvae_amd import backend, dist as mdist, synthetic
 
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner when its
+    # communicator comes up): file descriptor 1 points at stderr until the line is written.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     on_gpu = a.device == "cuda"
     world = mdist.init_from_env(None if on_gpu else "gloo")
     if world != a.gpus:
@@ -377,6 +386,13 @@ def main():
     n_setup = 4 * period if on_gpu else 0
     for i in range(n_setup):
         step(i)
+    # data parallelism: the engine times its two GEMM kernel families on its first replayed steps and keeps the faster
+    # (engine._dp_autotune); those steps belong to the set-up
+    eng = getattr(model, "_engine", None) if a.mode == "train" else None
+    while eng is not None and getattr(eng, "_tune", None) is not None and n_setup < 400:
+        for _ in range(period):
+            step(n_setup)
+            n_setup += 1
     sync()
     for i in range(a.warmup):
         step(n_setup + i)
@@ -433,7 +449,7 @@ def main():
             if k.startswith(("loss/", "recon_loss/", "kl_loss/"))}
     parity = None
     if (leg is not None and world == 1 and rank == 0 and a.config == "c2" and a.input == "dense" and not a.genes
-            and not a.hidden and not a.no_parity):
+            and not a.hidden and not a.no_parity and not a.sim_world):
         i_par = n_setup + a.warmup + a.steps + 8
         eid_par = eids[i_par % len(eids)]
         x_par, m_par = data[eid_par][(i_par // len(eids)) % n_res]
@@ -523,12 +539,16 @@ def main():
                 out["parity"] = parity
         elif not on_gpu:
             out["rehearsal"] = "CPU plumbing over gloo: launch / exchange / timing logic only, not a measurement"
+        if eng is not None and getattr(eng, "dp_tuned", None):
+            out["dp_kernels"] = dict(eng.dp_tuned, note="ms per step of the two GEMM kernel families under the exchange, "
+                                     "timed on this run's first replayed steps (max over ranks); the faster one ran the timed region")
         if dp_diag is not None:
             dp_diag["ms_exposed_exchange"] = el / a.steps * 1e3 - dp_diag["ms_per_step_without_transfers"]
             out["data_parallel"] = dp_diag
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

@@ -214,7 +214,7 @@ class StepEngine:
         self.side_branches = os.environ.get("MMVAE_SIDE_BRANCHES", "1") != "0"
         # the same branch inside the exchange program (data parallelism): the decoder's weight gradient beside the part
         # of the backward chain that lies ahead of the shared VAE's exchange point (the cut joins it); 0 = in order
-        self.side_dw_dp = int(os.environ.get("MMVAE_SIDE_DW_DP", "0"))
+        self.side_dw_dp = int(os.environ.get("MMVAE_SIDE_DW_DP", "125"))
         # adversarial programs (C4): the decoder's last layer backward -- weight gradient AND input gradient -- needs only
         # dP, which the reconstruction epilogue has written before the adversaries' phases start: both GEMMs run capped
         # on the side stream beside those phases (~700 us of latency-bound launches), joined ahead of the backward chain
@@ -262,14 +262,35 @@ class StepEngine:
         # 1 / world of it, all-gather of the parameters -- the same bytes on the wire as the all-reduce, the 1.2 GB
         # Adam pass world times shorter (MMVAE_DP_SHARD=0: all-reduce + the full update on every rank)
         self.shard = mdist.collectives_active() and os.environ.get("MMVAE_DP_SHARD", "1") != "0"
+        # diagnostics (timing only, wrong numbers): on ONE rank, update the slice a rank of a world of N would own and skip
+        # the collectives -- what the compute side of the N-rank program costs (bench.py --sim-world)
+        self.shard_sim_world = int(os.environ.get("MMVAE_DP_SIM_WORLD", "0")) if self.world == 1 else 0
         # The wave-specialised GEMM kernel runs ONE persistent workgroup per CU with statically dealt work items: a
         # collective's workgroups holding CUs beside it (the previous step's all-reduce under data parallelism) would
         # delay whole workgroups by a round.  Under a gradient exchange the 2 x 4-wave kernel (measured sensitivity:
         # DESIGN.md section 7) is kept unless the caller chose explicitly.
         # (library launch state, set and restored here -- not the process environment: a later single-rank engine of
         # the same process gets the persistent kernel back)
+        # MMVAE_DP_KERNELS = dynamic | persistent | auto (default): which of the two the exchange program launches.  With
+        # this rank's slice of a world of 8, side branch on (r4_dp_rehearsal.txt): persistent 0.94 ms against 1.04 ms --
+        # but only a real run knows how the collectives' resident workgroups treat the static deal, so "auto" times both
+        # on the first steps of a multi-rank run and keeps the faster one (_dp_autotune).
+        self.dp_kernels = os.environ.get("MMVAE_DP_KERNELS", "auto")
+        if self.dp_kernels not in ("auto", "dynamic", "persistent"):
+            raise _lib.HipLibraryError(f"MMVAE_DP_KERNELS={self.dp_kernels!r}: dynamic | persistent | auto")
+        if not hasattr(self, "_tune"):
+            self._tune = None
+            self.dp_tuned: Dict[str, float] = {}
         if "MMVAE_X3W" not in os.environ:
-            self.lib.mmvae_gemm_set_x3w(0 if mdist.collectives_active() else -1)
+            if not mdist.collectives_active():
+                self.lib.mmvae_gemm_set_x3w(-1)
+            else:
+                choice = self.dp_kernels if self.dp_kernels != "auto" else (self.dp_tuned.get("choice") or "dynamic")
+                self.lib.mmvae_gemm_set_x3w(1 if choice == "persistent" else 0)
+                tune = (self.dp_kernels == "auto" and "choice" not in self.dp_tuned
+                        and (mdist.world_size() > 1 or os.environ.get("MMVAE_DP_AUTOTUNE_FORCE", "0") != "0"))
+                if tune and self._tune is None:
+                    self._tune = dict(phase="warm", kind="dynamic", steady=0, count=0, ev=None)
         if self.overlap and self.comm_stream is None:
             self.comm_stream = torch.cuda.Stream(device=self.device)
             self.small_stream = torch.cuda.Stream(device=self.device)
@@ -286,6 +307,54 @@ class StepEngine:
         return (per_opt, clip(ac.vae_gradient_clip), clip(ac.expert_gradient_clip), clip(ac.adversarial_gradient_clip),
                 float(self.model.adv_weight), mdist.world_size(), mdist.collectives_active())
 
+    def _drop_train_plans(self) -> None:
+        self.flush()
+        torch.cuda.synchronize(self.device)
+        for k, p in self._plans.items():
+            if str(k[0]).startswith("train"):
+                p.release()
+        self._plans = {k: p for k, p in self._plans.items() if not str(k[0]).startswith("train")}
+        self._ptr_seen.clear()
+
+    DP_TUNE_STEADY, DP_TUNE_STEPS = 4, 12
+
+    def _dp_autotune(self, plan: "_Plan") -> None:
+        """MMVAE_DP_KERNELS=auto under a real exchange: time DP_TUNE_STEPS replayed steps with the 2 x 4-wave (hardware-
+        scheduled) GEMM kernels, then with the persistent ones, take the maximum over the ranks of each and keep the
+        faster.  The steps are ordinary training steps; a switch drops the captured programs (they bake the kernel in)."""
+        t = self._tune
+        st = torch.cuda.current_stream()
+        if t["phase"] == "warm":
+            t["steady"] = t["steady"] + 1 if plan._runs >= 3 else 0  # (a third run is a replay of a captured program)
+            if t["steady"] >= self.DP_TUNE_STEADY:
+                t["ev"] = torch.cuda.Event(enable_timing=True)
+                t["ev"].record(st)
+                t.update(phase="measure", count=0)
+            return
+        t["count"] += 1
+        if t["count"] < self.DP_TUNE_STEPS:
+            return
+        end = torch.cuda.Event(enable_timing=True)
+        end.record(st)
+        end.synchronize()
+        self.dp_tuned[t["kind"]] = t["ev"].elapsed_time(end) / self.DP_TUNE_STEPS
+        if t["kind"] == "dynamic":
+            self.lib.mmvae_gemm_set_x3w(1)
+            self._drop_train_plans()
+            t.update(phase="warm", kind="persistent", steady=0, count=0, ev=None)
+            return
+        both = torch.tensor([self.dp_tuned["dynamic"], self.dp_tuned["persistent"]], dtype=torch.float64, device=self.device)
+        if mdist.world_size() > 1:
+            import torch.distributed as tdist
+
+            tdist.all_reduce(both, op=tdist.ReduceOp.MAX)
+        d, p = (float(v) for v in both.cpu())
+        self.dp_tuned.update(dynamic=d, persistent=p, choice="persistent" if p <= d else "dynamic")
+        if self.dp_tuned["choice"] == "dynamic":
+            self.lib.mmvae_gemm_set_x3w(0)
+            self._drop_train_plans()
+        self._tune = None
+
     def _check_signature(self) -> None:
         sig = self._signature()
         if sig != self._sig:
@@ -299,13 +368,7 @@ class StepEngine:
                 warnings.warn("mmvae_amd.engine: optimiser settings changed on several training steps; every change drops "
                               "the captured step programs and re-captures them (a learning-rate schedule stepping per "
                               "batch costs milliseconds per step) -- change them per epoch, or set use_engine=False")
-            self.flush()
-            torch.cuda.synchronize(self.device)
-            for k, p in self._plans.items():
-                if str(k[0]).startswith("train"):
-                    p.release()
-            self._plans = {k: p for k, p in self._plans.items() if not str(k[0]).startswith("train")}
-            self._ptr_seen.clear()
+            self._drop_train_plans()
             self._configure_parallel()
             self._sig = sig
 
@@ -496,6 +559,8 @@ class StepEngine:
             plan.cond.commit()
         model.kl_annealing_fn.step()
         plan.log(model, expert_id)
+        if self._tune is not None:
+            self._dp_autotune(plan)
 
 
 def _planes_desc(planes) -> str:
@@ -1140,7 +1205,8 @@ class _Plan:
         b1, b2 = g["betas"]
         gs = 1.0 / self.eng.world
         npart = self.lib.mmvae_sqnorm_partials(a.numel)
-        sh = a.shard(self.eng.world, mdist.rank()) if (self.eng.shard and opt is self.opt_exp and self.cond is None
+        sh = a.shard(self.eng.shard_sim_world or self.eng.world, mdist.rank()) if (
+            self.eng.shard and opt is self.opt_exp and self.cond is None
                                                        and exchange in ("inline", "deferred")
                                                        and opt.reducer is not None) else None
         if sh is not None:
@@ -1206,9 +1272,10 @@ class _Plan:
         gs = 1.0 / self.eng.world
         per, lo, n_loc = sh
         W = self.eng.world
+        sim = bool(self.eng.shard_sim_world)
         mine = self.eng.buf(f"shard.sq.{id(opt)}", (1,))
         allsq = self.eng.buf(f"shard.allsq.{id(opt)}", (W,))
-        self.shard_info = dict(per=per, lo=lo, n_loc=n_loc, mine=mine, allsq=allsq)
+        self.shard_info = dict(per=per, lo=lo, n_loc=n_loc, mine=mine, allsq=allsq, sim=sim)
         opt.sharded = True
         self._cut(("rs_" + exchange, opt))
         if n_loc > 0:
@@ -2040,7 +2107,7 @@ class _Plan:
             if kind == "rs_deferred":
                 eng.comm_stream.wait_stream(main)
                 tail = eng.comm_stream
-            live = red is not None and not mdist.DRY_RUN
+            live = red is not None and not mdist.DRY_RUN and not si["sim"]
             with (torch.cuda.stream(tail) if tail is not None else contextlib.nullcontext()):
                 if kind.startswith("rs_"):
                     full = a.grad_full[:si["per"] * W]
@@ -2118,6 +2185,8 @@ class _Plan:
             for seg in self.segments:
                 if isinstance(seg, tuple):
                     graphs.append(seg)
+                    continue
+                if not seg:  # (nothing between two exchange points)
                     continue
                 g = torch.cuda.CUDAGraph()
                 # thread-local capture mode: a process group's watchdog thread may touch its events meanwhile

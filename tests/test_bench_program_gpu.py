@@ -71,8 +71,9 @@ def test_bench_program_matches_oracle():
     model._engine.close()
 
 
-def _run_c2(steps, env):
-    """`steps` training steps of the C2 model under `env`; returns the final parameters and whether the plan forked."""
+def _run_c2(steps, env, attach=False, keep_engine=False):
+    """`steps` training steps of the C2 model under `env`; returns the final parameters and whether the plan forked
+    (attach: gradients exchanged over the initialised process group; keep_engine: + the engine's dp_tuned record)."""
     import bench
     from mmvae_amd import synthetic
 
@@ -86,6 +87,10 @@ def _run_c2(steps, env):
         model.train()
         model.trainer.set_stage("training")
         model.optimizers()
+        if attach:
+            from mmvae_amd import dist as mdist
+
+            mdist.attach(model)
         from mmvae_amd import rng
 
         rng.state(device)
@@ -101,9 +106,10 @@ def _run_c2(steps, env):
         torch.cuda.synchronize()
         forked = bool(model._engine.last_plan._forked)
         sd = {k: v.detach().cpu().clone() for k, v in model.module.state_dict().items()}
+        tuned = dict(getattr(model._engine, "dp_tuned", {}))
         model._engine.close()
         del model
-        return sd, forked
+        return (sd, forked, tuned) if keep_engine else (sd, forked)
     finally:
         for k, v in old.items():
             if v is None:
@@ -138,7 +144,7 @@ def test_exchange_program_with_its_side_branch_is_bit_identical():
     a pass of its own instead of the GEMM epilogues' partials: the same value to rounding, not bit for bit.)"""
     import gc
 
-    ref, f0 = _run_c2(8, {"MMVAE_DP_OVERLAP": "1"})
+    ref, f0 = _run_c2(8, {"MMVAE_DP_OVERLAP": "1", "MMVAE_SIDE_DW_DP": "0"})
     assert not f0
     gc.collect()
     torch.cuda.empty_cache()
@@ -146,6 +152,44 @@ def test_exchange_program_with_its_side_branch_is_bit_identical():
     assert f, "the exchange program forks its weight-gradient branch when asked"
     bad = [k for k in ref if not torch.equal(ref[k], got[k])]
     assert not bad, f"{len(bad)} tensors differ, e.g. {bad[:3]}"
+
+
+def test_sharded_exchange_program_on_one_rank_with_rccl(monkeypatch):
+    """The data-parallel program as N > 1 runs it, on one rank with a real RCCL communicator: reduce-scatter of the
+    expert's gradient arena, clip + Adam on this rank's slice (= the whole arena), all-gather of the parameters -- against
+    the all-reduce + full update (MMVAE_DP_SHARD=0): parameters to 2e-6 after 3 steps (the norm is summed in another
+    order; the GEMMs are the same kernels).  Then the engine's autotuner: both GEMM kernel families timed, one kept (the
+    families tile and split K differently -- each is held to fp64 by the kernel tests, not to the other)."""
+    import gc
+
+    import torch.distributed as td
+
+    from mmvae_amd import dist as mdist
+    from tests.helpers import rel_l2
+
+    monkeypatch.setenv("MMVAE_SINGLE_RANK_COLLECTIVES", "1")
+    monkeypatch.setenv("MASTER_PORT", "29617")
+    mdist.init_from_env()
+    try:
+        assert mdist.collectives_active()
+        runs = {}
+        for tag, env in (("unsharded", {"MMVAE_DP_SHARD": "0", "MMVAE_DP_KERNELS": "dynamic"}),
+                         ("sharded", {"MMVAE_DP_KERNELS": "dynamic"}),
+                         ("auto", {"MMVAE_DP_AUTOTUNE_FORCE": "1"})):
+            gc.collect()
+            torch.cuda.empty_cache()
+            runs[tag] = _run_c2(44 if tag == "auto" else 3, env, attach=True, keep_engine=(tag == "auto"))  # (3: Adam amplifies the norm's rounding over more steps)
+        sd_u, sd_s = runs["unsharded"][0], runs["sharded"][0]
+        # (Linear biases that feed a BatchNorm have a zero true gradient: Adam steps on rounding noise -- exempt everywhere)
+        chaotic = {k for k in sd_u if k.endswith("lin.bias") and k.replace("lin.bias", "bn.weight") in sd_u}
+        worst = max(rel_l2(sd_s[k].double(), sd_u[k].double()) for k in sd_u
+                    if sd_u[k].is_floating_point() and k not in chaotic)
+        assert worst <= 2e-6, worst
+        tuned = runs["auto"][2]
+        assert tuned.get("choice") in ("dynamic", "persistent") and tuned["dynamic"] > 0 and tuned["persistent"] > 0, tuned
+    finally:
+        torch.cuda.synchronize()
+        td.destroy_process_group()
 
 
 def test_fork_is_gated_to_the_measured_geometry():
