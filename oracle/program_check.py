@@ -30,14 +30,24 @@ def _fc_spec(block) -> O.FCSpec:
 
 
 def spec_of(model, eid: str) -> O.ModelSpec:
-    """ModelSpec of the active expert + the shared VAE of a (non-adversarial, non-conditional) CMMVAEModel."""
+    """ModelSpec of the active expert + the shared VAE (+ the adversaries: BASELINE config 4) of a CMMVAEModel."""
+    from mmvae_amd.modules.base.components import Adversarial
+
     m = model.module
-    if len(m.adversarials) or getattr(m.vae, "conditionals", None) is not None:
-        raise ValueError("program_check covers the plain expert + VAE step (BASELINE config 2)")
+    if getattr(m.vae, "conditionals", None) is not None:
+        raise ValueError("program_check covers the expert + VAE (+ adversaries) step; conditional layers draw their "
+                         "selection order on the host: see tests/test_step_gpu.py for those programs")
+    advs = []
+    for adv in m.adversarials:
+        enc = _fc_spec(adv.encoder)
+        if any(p > 0 for p in enc.dropout_rate):
+            raise ValueError("program_check: adversary dropout draws one keep mask per phase; the oracle takes one per layer")
+        advs.append(O.AdvSpec(encoder=enc, heads={c: adv.heads[c].fc_layers[0].lin.out_features
+                                                  for c in Adversarial.labels.keys()}))
     exp = m.experts[eid]
     return O.ModelSpec(experts={eid: (_fc_spec(exp.encoder), _fc_spec(exp.decoder))}, vae_encoder=_fc_spec(m.vae.encoder.fc),
                        vae_decoder=_fc_spec(m.vae.decoder), latent_dim=m.vae.encoder.mean_encoder.out_features,
-                       var_eps=float(m.vae.encoder.var_eps), hidden_z=bool(m.vae.encoder.hidden_z))
+                       var_eps=float(m.vae.encoder.var_eps), hidden_z=bool(m.vae.encoder.hidden_z), adversarials=advs)
 
 
 def _rel_l2(a, b) -> float:
@@ -54,12 +64,14 @@ def snapshot(model, eid: str):
     """(state_dict of the VAE + expert `eid` on the host, oracle optimiser state, common Adam step count)."""
     model._flush_engine()
     torch.cuda.synchronize()
-    keep = ("vae.", f"experts.{eid}.")
+    keep = ("vae.", f"experts.{eid}.", "adversarials.")
     sd = {k: v.detach().cpu().clone() for k, v in model.module.state_dict().items() if k.startswith(keep)}
     names = _names(model)
     opts = model.get_optimizers()
     state, counts = {}, []
-    for group, opt in (("vae", opts["vae"]), (f"expert_{eid}", opts["experts"][eid])):
+    groups = [("vae", opts["vae"]), (f"expert_{eid}", opts["experts"][eid])]
+    groups += [(f"adversarial_{i + 1}", o) for i, o in enumerate(opts.get("adversarials", {}).values())]
+    for group, opt in groups:
         a = opt.arena
         count = int(round(float(opt.state_dev[0])))
         counts.append(count)
@@ -104,8 +116,13 @@ def _slopes(model, eid: str) -> Dict[str, torch.Tensor]:
 def check_step(model, eid: str, x: torch.Tensor, meta, step_index: int, strict: bool = True) -> dict:
     """Take ONE training step of `model` on (x, meta, eid) the way the caller's loop does (captured program, Philox
     noise) and compare it with the oracle.  Returns the measured deviations; `strict` asserts the tolerances TOL."""
+    from mmvae_amd.modules.base.components import Adversarial
+
     spec = spec_of(model, eid)
-    hp = O.HParams()
+    hp = O.HParams(adv_weight=float(model.adv_weight))
+    labels = None
+    if spec.adversarials:  # cmmvae_model.py:111-115
+        labels = {c: torch.tensor([table[v] for v in meta[c].values]) for c, table in Adversarial.labels.items()}
     sd_in, opt_state, count = snapshot(model, eid)
     kl_weight = float(model.kl_annealing_fn.kl_weight)
     model.logged.clear()
@@ -124,7 +141,7 @@ def check_step(model, eid: str, x: torch.Tensor, meta, step_index: int, strict: 
     eps = plan.eps.detach().cpu().clone()
     eps = eps[0] if eps.shape[0] == 1 else eps
     slopes = _slopes(model, eid)
-    ref, sd_new = O.train_step(spec, sd_in, opt_state, x.detach().cpu(), eid, eps, masks, None, kl_weight, hp,
+    ref, sd_new = O.train_step(spec, sd_in, opt_state, x.detach().cpu(), eid, eps, masks, labels, kl_weight, hp,
                                relu_slopes=slopes)
     # slopes that differ from the oracle's own 1[y > 0] must be kinks: |y| within rounding distance of zero
     kinks = 0
@@ -150,6 +167,15 @@ def check_step(model, eid: str, x: torch.Tensor, meta, step_index: int, strict: 
     for k, key in (("loss", "total_loss"), ("recon_loss", "recon_loss"), ("kl_loss", "kl_loss")):
         r = float(ref[key])
         out[k] = abs(logged[f"{k}/training/{eid}"] - r) / max(abs(r), 1e-30)
+    for i in range(len(spec.adversarials)):  # both phases: every head's loss, their sum, the (pre-clip) gradient norm
+        worst = 0.0
+        for phase in ("discriminator", "generator"):
+            got = {c: logged[f"{phase}_{i + 1}/training/{eid}/adversarial_loss/{c}"] for c in list(labels) + ["summed"]}
+            want = dict({c: float(v) for c, v in ref[phase][i]["heads"].items()}, summed=float(ref[phase][i]["summed"]))
+            worst = max([worst] + [abs(got[c] - want[c]) / max(abs(want[c]), 1e-30) for c in want])
+            gn = float(ref["grad_norms"][f"{phase}_{i + 1}"])
+            out[f"grad_norm_{phase}_{i + 1}"] = abs(logged[f"grad_norms/{phase}_{i + 1}"] - gn) / gn
+        out[f"adversarial_loss_{i + 1}"] = worst
     out["grad_norm_vae"] = abs(logged["grad_norms/vae"] - float(ref["grad_norms"]["vae"])) / float(ref["grad_norms"]["vae"])
     ge = float(ref["grad_norms"][f"expert_{eid}"])
     out["grad_norm_expert"] = abs(logged[f"grad_norms/expert_{eid}"] - ge) / ge
@@ -175,8 +201,11 @@ def check_step(model, eid: str, x: torch.Tensor, meta, step_index: int, strict: 
         wp = max(wp, _rel_l2(v, sd_new[n]))
     out["grad"], out["param"] = wg, wp
     if strict:
-        for k in ("loss", "recon_loss", "kl_loss"):
+        for k in ["loss", "recon_loss", "kl_loss"] + [k for k in out if k.startswith("adversarial_loss_")]:
             assert out[k] <= TOL["loss"], (k, out)
+        for k in out:
+            if k.startswith(("grad_norm_discriminator", "grad_norm_generator")):
+                assert out[k] <= TOL["grad_norm"], (k, out)
         assert out["grad_norm_vae"] <= TOL["grad_norm"] and out["grad_norm_expert"] <= TOL["grad_norm"], out
         assert out["grad"] <= TOL["grad"], out
         assert out["param"] <= (TOL["param_cold"] if out["cold"] else TOL["param"]), out

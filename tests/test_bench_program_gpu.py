@@ -15,13 +15,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_program_matches_oracle():
+@pytest.mark.parametrize("config", ["c2", "c4"])
+def test_bench_program_matches_oracle(config):
+    """c4: + both adversaries (row-owner passes, csrc/adv_fused.hip): every head's loss in both phases, the discriminator
+    / generator gradient norms and the adversaries' post-step parameters (cmmvae_model.py:59-136)."""
     import bench
     from mmvae_amd import synthetic
     from oracle import program_check as PC
 
-    a = argparse.Namespace(config="c2", genes="", no_engine=False)
-    cfg = dict(synthetic.CONFIGS["c2"])
+    a = argparse.Namespace(config=config, genes="", no_engine=False)
+    cfg = dict(synthetic.CONFIGS[config])
     device = torch.device("cuda", 0)
     model = bench.build_model(a, cfg, device).to(device)
     model.train()
@@ -41,6 +44,21 @@ def test_bench_program_matches_oracle():
 
     period = len(eids) * n_res
     step = 0
+    sd0 = {k: v.detach().clone() for k, v in model.module.state_dict().items()}
+
+    def restart():
+        """Back to the initial parameters and a fresh optimiser state (plans, graphs and the Philox counter stay).  C4's
+        dynamics on synthetic data are violent (gradient reversal at adv_weight 25: losses of 1e11 and gradient norms
+        of 1e16 within ten steps, on the per-layer and the fused adversary programs alike): the replayed program is
+        checked over the first steps from the initial state, where fp32 sums do not overflow."""
+        model._flush_engine()
+        torch.cuda.synchronize()
+        model.module.load_state_dict(sd0)
+        for o in model.optimizers():
+            o.arena.exp_avg.zero_()
+            o.arena.exp_avg_sq.zero_()
+            o.state_dev[0] = 0.0
+
     # the very first step of every expert is a cold Adam step taken eagerly (plan build): checked too
     first = []
     for i in range(period):
@@ -54,17 +72,21 @@ def test_bench_program_matches_oracle():
         step += 1
     rows = []
     for i in range(12):
+        if config != "c2" and i % len(eids) == 0:
+            restart()
         x, meta, eid = batch(step)
         r = PC.check_step(model, eid, x, meta, step)
         assert r["replayed"] and r["philox"], r  # the program under test: a replayed graph with device noise
         rows.append(r)
         step += 1
-    assert any(r["forked"] for r in rows), "the bench program runs with its side branches"
-    worst = {k: max(r[k] for r in rows) for k in ("loss", "recon_loss", "kl_loss", "grad_norm_vae", "grad_norm_expert",
-                                                   "grad", "param")}
+    if config == "c2":
+        assert any(r["forked"] for r in rows), "the bench program runs with its side branches"
+    else:
+        assert getattr(model._engine.last_plan, "adv_prog", None) is not None, "C4 runs the fused adversary passes"
+    worst = {k: max(r[k] for r in rows) for k in rows[0] if isinstance(rows[0][k], float)}
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "bench_program_parity.jsonl"), "w") as f:
+    with open(os.path.join(out, f"bench_program_parity{'' if config == 'c2' else '_' + config}.jsonl"), "w") as f:
         for r in first + rows:
             f.write(json.dumps(r) + "\n")
         f.write(json.dumps({"worst_of_12_replayed_steps": worst, "kinks": sum(r["kinks"] for r in rows)}) + "\n")
