@@ -137,8 +137,7 @@ def time_step_kernels(model, step, first, steps=8):
     same kernels are slower (cold clocks and caches, tools/debug/leg_probe.py).  Returns {tag: (median seconds,
     work per launch, meta)}."""
     eng = model._engine
-    prev = os.environ.get("MMVAE_NO_GRAPH")
-    os.environ["MMVAE_NO_GRAPH"] = "1"
+    eng.eager_only = True
     probe = {}
     try:
         for p in eng._plans.values():
@@ -149,10 +148,7 @@ def time_step_kernels(model, step, first, steps=8):
     finally:
         for p in eng._plans.values():
             p.probe = None
-        if prev is None:
-            os.environ.pop("MMVAE_NO_GRAPH", None)
-        else:
-            os.environ["MMVAE_NO_GRAPH"] = prev
+        eng.eager_only = False
     meta = {}
     for p in eng._plans.values():
         meta.update(p.probe_meta)
@@ -460,7 +456,8 @@ def main():
         if a.config == "c4":
             # C4 on synthetic data diverges within ten steps (gradient reversal at adv_weight 25: losses of 1e11, fp32
             # sums of squares overflow -- on the per-layer and the fused adversary programs alike): the checked step
-            # starts from the initial parameters and a fresh optimiser state, the program (graphs, Philox) is the timed one
+            # starts from the initial parameters and a warm optimiser state (Adam 100 steps in, second moments 1e8: a cold,
+            # sign-like step turns rounding noise into +-lr); the program (graphs, Philox) is the timed one
             model._flush_engine()
             torch.cuda.synchronize()
             model.module.load_state_dict(sd_initial)
@@ -505,7 +502,9 @@ def main():
             # bf16x3: every fp32 product costs 6 bf16 MFMA products, so the matrix-core ceiling for ALGORITHMIC fp32
             # flops is the dense bf16 peak / 6; the exact-f32 mode is bounded by the fp32 MFMA peak.
             peak = BF16_DENSE_TFLOPS / 6.0 if x3 else F32_MFMA_TFLOPS
-            traffic = pmc_traffic()
+            # (the tracked counters are C2's: default gene counts and hidden width, dense input)
+            profiled_shape = a.config == "c2" and not a.genes and not a.hidden and a.input == "dense"
+            traffic = pmc_traffic() if profiled_shape else {}
             kernels, fl_sum, t_sum, tr_sum, tr_n = [], 0.0, 0.0, 0, 0
             for tag, what, sub in FAMILY:
                 if tag not in leg:

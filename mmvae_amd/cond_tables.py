@@ -1,5 +1,5 @@
 """Host-side index tables of one conditional layer application, shared by the module path
-(`ConditionalLayer._forward_grouped`) and the captured engine (`engine._CondProgram`).
+(`ConditionalLayer._forward_grouped`) and the captured engine (`engine_cond.CondProgram`).
 
 From the per-cell block index of a batch (`local`, what `ConditionalLayer.forward` derives from the metadata column,
 components.py:365-413) the kernels of `csrc/cond_layers.hip` need:

@@ -556,7 +556,8 @@ __global__ __launch_bounds__(256) void sqnorm_ranges_prepare_kernel(SqRanges r, 
 // of the (averaged) gradient is clamped to [-cv, cv] ahead of the weight decay; the norm coefficient is 1 then.
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float gmul, float wd, float b1, float b2,
                                          float step_size, float inv_bc2_sqrt, float eps, float cv = 0.f) {
-    const float gc = fminf(fmaxf(g * gmul, -cv), cv) + wd * p;
+    const float gs = g * gmul;
+    const float gc = (gs != gs ? gs : fminf(fmaxf(gs, -cv), cv)) + wd * p;  // (torch.clamp keeps a NaN; fminf would hide it)
     g = g * gmul + wd * p;
     if (cv > 0.f) g = gc;
     m = m + (1.f - b1) * (g - m);

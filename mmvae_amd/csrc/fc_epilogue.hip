@@ -69,8 +69,9 @@ __device__ __forceinline__ void split_rows_job(const FwdArgs& a, int wg, int nwg
 #pragma unroll
         for (int p = 0; p < 3; ++p)
             *reinterpret_cast<uint4*>(dp + p * a.sp_pstride) =
-                make_uint4((q[0][p] >> 16) | q[1][p], (q[2][p] >> 16) | q[3][p], (q[4][p] >> 16) | q[5][p],
-                           (q[6][p] >> 16) | q[7][p]);
+                // (the odd element keeps its top half only: the last piece of a value in the fp32 denormal range has low bits)
+                make_uint4((q[0][p] >> 16) | (q[1][p] & 0xFFFF0000u), (q[2][p] >> 16) | (q[3][p] & 0xFFFF0000u),
+                           (q[4][p] >> 16) | (q[5][p] & 0xFFFF0000u), (q[6][p] >> 16) | (q[7][p] & 0xFFFF0000u));
     }
 }
 

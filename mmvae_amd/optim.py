@@ -377,7 +377,10 @@ class HipAdam(torch.optim.Optimizer):
             for j, i in enumerate(active):
                 p, o = a.params[i], a.offsets[i]
                 sl = slice(o, o + p.numel())
-                gr = a.grad[sl] * self.grad_scale * float(clip) + g["weight_decay"] * a.data[sl]
+                gr = a.grad[sl] * self.grad_scale * float(clip)
+                if getattr(self, "clip_value", None):  # gradient_clip_algorithm "value" (config.py:8)
+                    gr = gr.clamp(-self.clip_value, self.clip_value)
+                gr = gr + g["weight_decay"] * a.data[sl]
                 a.exp_avg[sl].lerp_(gr, 1 - b1)
                 a.exp_avg_sq[sl].mul_(b2).addcmul_(gr, gr, value=1 - b2)
                 denom = a.exp_avg_sq[sl].sqrt() / (float(bc2[j]) ** 0.5) + g["eps"]

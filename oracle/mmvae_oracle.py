@@ -378,14 +378,17 @@ class _GRL(torch.autograd.Function):
 
 
 def adversarial_losses(spec: ModelSpec, sd, hidden, labels: Dict[str, torch.Tensor], detach: bool, hp: HParams,
-                       masks: Optional[dict] = None):
+                       masks: Optional[dict] = None, relu_slopes: Optional[dict] = None,
+                       relu_inputs: Optional[dict] = None):
     """CMMVAEModel.grf (models/cmmvae_model.py:59-101): per adversary, CE(sum) per head then summed.
     Heads are iterated in the order of `labels` (cmmvae_model.py:83: `for condition, label in labels.items()`).
-    `masks`: explicit dropout keep masks of adversary encoders with dropout (the adversaries run in training mode)."""
+    `masks`: explicit dropout keep masks of adversary encoders with dropout (the adversaries run in training mode);
+    `relu_slopes` / `relu_inputs`: as for fcblock_forward (keys "adversarials.<i>.encoder.fc_layers.<j>")."""
     out = []
     for i, (h, adv) in enumerate(zip(hidden, spec.adversarials)):
         h = h.detach() if detach else _GRL.apply(h, 1)
-        e, _ = fcblock_forward(sd, f"adversarials.{i}.encoder", adv.encoder, h, True, masks, hp)
+        e, _ = fcblock_forward(sd, f"adversarials.{i}.encoder", adv.encoder, h, True, masks, hp, None, relu_slopes,
+                               relu_inputs)
         heads = {}
         for cond, y in labels.items():
             p = f"adversarials.{i}.heads.{cond}.fc_layers.0.lin"
@@ -465,6 +468,7 @@ def train_step(spec: ModelSpec, sd: Dict[str, torch.Tensor], opt_state: dict, x:
     total = e["loss"]
     if spec.adversarials:
         assert labels is not None
+        # (given slopes are the generator phase's: the discriminator phase runs on the weights before its own update)
         d = adversarial_losses(spec, live, fwd["hidden"], labels, True, hp, masks)
         out["discriminator"] = [{"heads": {c: v.detach() for c, v in a["heads"].items()}, "summed": a["summed"].detach()}
                                 for a in d]
@@ -477,7 +481,7 @@ def train_step(spec: ModelSpec, sd: Dict[str, torch.Tensor], opt_state: dict, x:
             new_sd.update(upd)
             for n in names:
                 live[n] = upd[n].detach().clone().requires_grad_(True)
-        g = adversarial_losses(spec, live, fwd["hidden"], labels, False, hp, masks)  # :134
+        g = adversarial_losses(spec, live, fwd["hidden"], labels, False, hp, masks, relu_slopes, relu_inputs)  # :134
         out["generator"] = [{"heads": {c: v.detach() for c, v in a["heads"].items()}, "summed": a["summed"].detach()}
                             for a in g]
         for a in g:  # :182-184

@@ -101,15 +101,18 @@ def _slopes(model, eid: str) -> Dict[str, torch.Tensor]:
         if not l.relu:
             continue
         if l is plan.dec_layers[-1]:  # fused with the reconstruction epilogue: dP = 2 (xhat - x) 1[P > 0]
-            if getattr(plan, "pl_dec", False) and plan.dPp is not None:  # dP lives as bf16 planes
-                pl = (plan.dPp.data[:, : plan.R].to(torch.int32) << 16).view(torch.float32)
-                dP = (pl[0] + pl[1]) + pl[2]
-            else:
-                dP = plan.dP[: plan.R]
-            slopes[name] = (dP != 0).cpu()
+            slopes[name] = (plan.dP[: plan.R] != 0).cpu()
         else:
             act = l.a if l.a is not None else l.d
             slopes[name] = (act[: l.rows] > 0).cpu()
+    # the adversaries' encoders, generator phase (fused passes: its activations are what the step left behind; the oracle's
+    # discriminator phase keeps its own slopes)
+    prog = getattr(plan, "adv_prog", None)
+    if prog is not None:
+        for i, (net, bufs) in enumerate(zip(prog.nets, prog.bufs)):
+            for j, lay in enumerate(net.layers):
+                if lay.relu and lay.p_drop == 0:
+                    slopes[f"adversarials.{i}.encoder.fc_layers.{j}"] = (bufs["act"][j][: plan.B] > 0).cpu()
     return slopes
 
 
@@ -145,7 +148,8 @@ def check_step(model, eid: str, x: torch.Tensor, meta, step_index: int, strict: 
                                relu_slopes=slopes)
     # slopes that differ from the oracle's own 1[y > 0] must be kinks: |y| within rounding distance of zero
     kinks = 0
-    last = list(slopes)[-1]
+    last = f"experts.{eid}.decoder.fc_layers.{len(model.module.experts[eid].decoder.fc_layers) - 1}"
+    assert last in slopes
     for name, slope in slopes.items():
         y = ref["relu_inputs"][name]
         diff = (y > 0) != slope.reshape(y.shape)
@@ -193,12 +197,16 @@ def check_step(model, eid: str, x: torch.Tensor, meta, step_index: int, strict: 
             n = names[id(p)]
             if n in skip or n not in ref["grads"]:
                 continue
-            wg = max(wg, _rel_l2(opt.arena.grad_view(i), ref["grads"][n]))
+            e = _rel_l2(opt.arena.grad_view(i), ref["grads"][n])
+            if e > wg:
+                wg, out["worst_grad"] = e, n
     sd_got = {k: v.detach().cpu() for k, v in model.module.state_dict().items() if k in sd_new}
     for n, v in sd_got.items():
         if n in skip or not v.is_floating_point() or n.endswith("running_mean"):
             continue
-        wp = max(wp, _rel_l2(v, sd_new[n]))
+        e = _rel_l2(v, sd_new[n])
+        if e > wp:
+            wp, out["worst_param"] = e, n
     out["grad"], out["param"] = wg, wp
     if strict:
         for k in ["loss", "recon_loss", "kl_loss"] + [k for k in out if k.startswith("adversarial_loss_")]:

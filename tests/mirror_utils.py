@@ -87,7 +87,7 @@ def set_explicit_masks(model, masks, eid, device):
         block.explicit_masks[int(rest.split(".")[0])] = m.to(device)
 
 
-def replay_training(name, device, use_engine=False, check=True, prepare=None, before_step=None):
+def replay_training(name, device, use_engine=False, check=True, prepare=None, before_step=None, resync=True):
     """Runs the golden schedule through CMMVAEModel.training_step; returns list of per-step result dicts."""
     from mmvae_amd import backend
 
@@ -122,7 +122,7 @@ def replay_training(name, device, use_engine=False, check=True, prepare=None, be
             logged = {k: (float(v.detach()) if torch.is_tensor(v) else v) for k, v in model.logged.items()}
             sd = {k: v.detach().cpu().clone() for k, v in model.module.state_dict().items()}
             results.append({"logged": logged, "sd": sd, "eid": eid})
-            if case.get("param_tol"):
+            if case.get("param_tol") and resync:
                 # a case whose cold Adam step is noise-sensitive (ln_dist: sign-like update on softmax-damped gradients)
                 # continues from the REFERENCE's post-step parameters, so that later steps' scalars keep their strict
                 # tolerances (moments stay the model's own)

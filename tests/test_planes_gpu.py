@@ -201,6 +201,20 @@ def test_layer_tail_with_piggybacked_split(ops):
     got = xp.to_float()
     assert torch.equal(got[r0:r0 + nrows], x[r0:r0 + nrows])
     assert float(got[:r0].abs().max()) == 0 and float(got[r0 + nrows:].abs().max()) == 0
+    # values in the fp32 denormal range (below ~2^-110 the third piece of the split keeps low bits): the
+    # piggy-backed split must write the same planes as mmvae_split_planes_f32 -- not OR a piece's low half into its neighbour
+    tiny = torch.zeros(B, G, device="cuda")
+    e = torch.randint(-149, -110, (B, G), device="cuda").float()
+    tiny[:] = torch.exp2(e) * (1 + torch.rand(B, G, device="cuda")) * torch.where(torch.rand(B, G, device="cuda") < 0.5, -1.0, 1.0)
+    tiny[::3, ::5] = rnd(B, G, seed=23)[::3, ::5]  # ordinary neighbours beside the tiny ones
+    want = ops.split_planes(tiny)
+    xp2 = ops.Planes(B, G, "cuda")
+    rc = lib.mmvae_fc_epilogue_fwd_split(B, N, slabs.data_ptr(), N, S, bias.data_ptr(), C.byref(bnp), 1, 1, mask.data_ptr(),
+                                         0.1, z.data_ptr(), a.data_ptr(), d.data_ptr(), N, mean.data_ptr(),
+                                         invstd.data_ptr(), ws.data_ptr(), ws.numel() * 4, B, G, tiny.data_ptr(), G,
+                                         xp2.ptr(), xp2.ld, xp2.plane_stride, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert torch.equal(xp2.data[:, :B], want.data[:, :B])
 
 
 @pytest.mark.parametrize("layout", [NT, NN, TN])
