@@ -611,7 +611,7 @@ int mmvae_cond_linear_bwd_dw(int n_chunks, const int32_t* chunk_dst, const int32
  *       coefficient, step count and bias corrections (mmvae_adam_prepare's arithmetic) -- no norm pass, no prepare
  *       launch.  The jobs of an optimiser must cover its whole gradient arena for that norm to be the arena's.  With
  *       `adv_jobs_dev` its first workgroup also sums the per-cell losses of every adversary (fp64, fixed order) into
- *       loss_each[h] / loss_total and adds total_scale * loss_total to *total_loss, adversaries in order.
+ *       loss_each[h] / loss_total and stores the sum of total_scale * loss_total over the adversaries in *total_loss.
  *   mmvae_adam_step_multi   mmvae_adam_step over several optimisers' arenas in one launch.
  * Limits: <= 4 encoder layers, <= 8 heads, widths <= 1024 (LDS permitting: mmvae_adv_pass_plan), any B.
  * ------------------------------------------------------------------------------------------------------------ */
@@ -635,7 +635,7 @@ typedef struct {
     float* partials;      /* scratch, mmvae_adv_pass_plan's partial_floats */
     float* loss_each;     /* out [H] */
     float* loss_total;    /* out [1] */
-    float* total_loss;    /* total_loss[0] += total_scale * loss_total[0], or NULL */
+    float* total_loss;    /* total_loss[0] = sum over the launch's adversaries of total_scale * loss_total[0], or NULL */
     float total_scale;
     float gscale;         /* scale of d(loss)/d(logits): 1 (discriminator) or adv_weight (generator) */
     float p_drop[MMVAE_ADV_MAX_LAYERS];

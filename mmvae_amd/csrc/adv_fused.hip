@@ -830,6 +830,8 @@ __global__ __launch_bounds__(AT) void adv_dw_kernel(const mmvae_adv_dw_job* __re
     if (blockIdx.x == 0 && adv) {
         // the pass's per-cell losses (written by the launch before this one) -> the logged sums of every adversary, in
         // order: fp64, fixed tree
+        float adv_sum = 0.f;  // sum over the adversaries of total_scale * loss_total, in order
+        float* adv_out = nullptr;
         for (int j = 0; j < n_adv; ++j) {
             const mmvae_adv_job* Jj = adv + j;
             const int Hj = Jj->H, Bj = Jj->B;
@@ -849,11 +851,13 @@ __global__ __launch_bounds__(AT) void adv_dw_kernel(const mmvae_adv_dw_job* __re
                 if (tid == 0) Jj->loss_each[h] = r;
                 total = h == 0 ? r : total + r;
             }
-            if (tid == 0) {
-                Jj->loss_total[0] = total;
-                if (Jj->total_loss) Jj->total_loss[0] += Jj->total_scale * total;
+            if (tid == 0) Jj->loss_total[0] = total;
+            if (Jj->total_loss) {
+                adv_sum += Jj->total_scale * total;
+                adv_out = Jj->total_loss;
             }
         }
+        if (tid == 0 && adv_out) adv_out[0] = adv_sum;
         __syncthreads();
     }
     if (!s_last) return;

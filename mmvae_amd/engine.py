@@ -54,6 +54,7 @@ class EngineSettings:
     side_dw_dp: int = 125        # MMVAE_SIDE_DW_DP: that branch inside the exchange (data-parallel) program; 0 = in order
     side_dw_any: bool = False    # MMVAE_SIDE_DW_ANY=1: fork outside the measured geometry too
     adv_fused: bool = True       # MMVAE_ADV_FUSED=0: the per-layer adversary program (the path of adversaries with BatchNorm)
+    adv_aside: bool = True       # MMVAE_ADV_ASIDE=0: the fused adversary passes in order instead of on the branch stream
     dp_overlap: Optional[bool] = None  # MMVAE_DP_OVERLAP: None = overlapped exchange whenever gradients are exchanged
     dp_shard: bool = True        # MMVAE_DP_SHARD=0: all-reduce + full update instead of the sharded expert update
     dp_kernels: str = "auto"     # MMVAE_DP_KERNELS: dynamic | persistent | auto (timed on the first multi-rank steps)
@@ -72,6 +73,7 @@ class EngineSettings:
             planes=e("MMVAE_PLANES", "1") != "0", side_dw=int(e("MMVAE_SIDE_DW", "125")),
             side_dw2=int(e("MMVAE_SIDE_DW2", "185")), side_dw_dp=int(e("MMVAE_SIDE_DW_DP", "125")),
             side_dw_any=e("MMVAE_SIDE_DW_ANY", "0") != "0", adv_fused=e("MMVAE_ADV_FUSED", "1") != "0",
+            adv_aside=e("MMVAE_ADV_ASIDE", "1") != "0",
             dp_overlap=None if ov == "" else ov != "0", dp_shard=e("MMVAE_DP_SHARD", "1") != "0", dp_kernels=kernels,
             dp_sim_world=int(e("MMVAE_DP_SIM_WORLD", "0")), dp_autotune_force=e("MMVAE_DP_AUTOTUNE_FORCE", "0") != "0")
 
@@ -566,6 +568,11 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
                                   and K == 1 and R <= SIDE_MAX_ROWS and not self.has_adv and big
                                   and (measured or eng.side_dw_any)) else 0
         early_branch = bool(side_dw and not self.iwae)  # the small branches: loss words, bias sums, the VAE's optimiser
+        # the late branch alone (the shared VAE's optimiser beside the encoder's capped weight gradient) also serves the
+        # adversarial programs: their branch stream is free again once the adversaries' passes have been joined
+        side_late = bool(side_dw or (eng.side_dw2 and eng.side_stream is not None and train and self.has_adv
+                                     and not eng.overlap and eng.world == 1 and K == 1 and R <= SIDE_MAX_ROWS and big
+                                     and (measured or eng.side_dw_any) and eng.settings.adv_aside))
         loss_aside, early_calls = False, []
         # ---- pre-split operands of the G-wide weight gradients (K = 1 training programs on the wave-specialised
         # kernels): x (split beside the forward chain) and the gradient at the first layer (from its column kernel) feed
@@ -618,6 +625,26 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
         if self.iwae:  # sampled log q(z) - log p(z) per (sample, cell)
             self.logratio = eng.buf("iwae.logratio", (K, B))
             self._emit(lib.mmvae_iwae_logratio, B, Z, K, _p(self.std), _p(self.eps), _p(self.z), _p(self.logratio))
+        # ---- adversaries (fused passes): they read the hidden representations only -- h1 and z exist from here on.  In
+        # the single-rank program of the measured geometry the seven launches of both phases run on the branch stream
+        # beside the decoder's forward and the reconstruction GEMM, and are joined where the backward pass first reads
+        # the reversed gradients; elsewhere they keep their place behind the ELBO.
+        hidden = [l.a if l.a is not None else l.d for l in self.enc_layers if l.return_hidden]
+        if self.hidden_z:
+            hidden.append(self.z)  # first sample (rows 0..B-1)
+        self.adv_grad_into: Dict[int, torch.Tensor] = {}
+        adv_calls, adv_aside = None, False
+        # (under a gradient exchange the adversaries' optimisers cut the program: built in place, further down)
+        adv_dp = eng.overlap or any(o.reducer is not None for o in self.opt_adv)
+        if self.has_adv and train and eng.adv_fused and not adv_dp:
+            start = len(self._cur)
+            if self._build_adversaries_fused(hidden):
+                adv_calls = self._take(start)
+                adv_aside = bool(eng.settings.adv_aside and eng.side_stream is not None and not eng.overlap
+                                 and eng.world == 1 and K == 1 and big and (measured or eng.side_dw_any)
+                                 and self.cond is None)
+                if adv_aside:
+                    self._fork()
         # ---- forward, decoder side (rows R = K*B)
         cur, ld = self.z, Z
         if self.cond is not None:  # CLVAE.after_reparameterize: the sample passes through the conditional layers
@@ -695,20 +722,21 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
                 early_calls = self._take(start)
         if not train:  # validation: the program ends with the ELBO terms in the metrics buffer
             return self._finish_forward_only()
-        # total loss slot starts as the ELBO loss (without adversaries it IS the ELBO loss word: no launch)
-        if self.has_adv:
-            self._emit(lib.mmvae_axpby, 1, 1.0, _p(self.metrics), 0.0, self.mptr("total_loss"))
-        else:
-            self.metric_slots["total_loss"] = 0
-
-        # ---- adversarial phases
-        hidden = [l.a if l.a is not None else l.d for l in self.enc_layers if l.return_hidden]
-        if self.hidden_z:
-            hidden.append(self.z)  # first sample (rows 0..B-1)
-        self.adv_grad_into: Dict[int, torch.Tensor] = {}
+        # ---- adversarial phases: total loss = ELBO loss + adv_weight * sum of the generator-phase losses
+        # (cmmvae_model.py:182-184; without adversaries it IS the ELBO loss word: no launch)
         self.dz_lat = eng.buf("dz_lat", (R, Z))
-        if self.has_adv:
+        if not self.has_adv:
+            self.metric_slots["total_loss"] = 0
+        elif adv_calls is None and eng.adv_fused and adv_dp and self._build_adversaries_fused(hidden):
+            self._emit(lib.mmvae_axpby, 1, 1.0, _p(self.metrics), 1.0, self.mptr("total_loss"))
+        elif adv_calls is None:  # per-layer program: the slot starts as the ELBO loss, every generator phase adds to it
+            self._emit(lib.mmvae_axpby, 1, 1.0, _p(self.metrics), 0.0, self.mptr("total_loss"))
             self._build_adversaries(hidden)
+        elif adv_aside:  # (emitted behind the main-stream work it runs beside: the executor enqueues in emission order)
+            self._branch(eng.side_stream, adv_calls)
+        else:
+            self._cur.extend(adv_calls)
+            self._emit(lib.mmvae_axpby, 1, 1.0, _p(self.metrics), 1.0, self.mptr("total_loss"))
 
         # ---- backward, decoder side
         if K > 1:
@@ -761,6 +789,9 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
                            _p(self.cond.opt.arena.grad))
         if not rest:
             raise _lib.HipLibraryError("engine: decoder needs at least two layers")
+        if adv_aside:  # the adversaries' branch: its reversed gradients are read from here on
+            self._join()
+            self._emit(lib.mmvae_axpby, 1, 1.0, _p(self.metrics), 1.0, self.mptr("total_loss"))
         # gradient-reversed adversary gradient on z (first sample) joins here
         zi = self.adv_grad_into.get(id(self.z))
         if zi is not None:
@@ -803,7 +834,7 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             l = self.enc_layers[j]
             hid = l.a if l.a is not None else l.d
             addend = self.adv_grad_into.get(id(hid)) if l.return_hidden else None
-            if j == 0 and side_dw:
+            if j == 0 and side_late:
                 self._defer_next_dw = True
             S_next = self.bwd_layer(l, din, S, addend=addend, need_dx="raw" if j > 0 else "none",
                                     dz_planes=self.dYp if (j == 0 and self.pl_enc) else None,
@@ -822,7 +853,7 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
 
         dw = getattr(self, "_deferred_dw", None)
         self._deferred_dw = None
-        late_branch = bool(side_dw and dw is not None and self.cond is None)
+        late_branch = bool(side_late and dw is not None and self.cond is None)
         start = len(self._cur)
         self.optimizer(self.opt_vae, self.clip_vae, exchange="wait" if early else "inline",
                        join=not late_branch)

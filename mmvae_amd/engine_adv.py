@@ -115,8 +115,6 @@ class PlanAdversaries:
 
     def _build_adversaries(self, hidden):
         eng, lib, B = self.eng, self.lib, self.B
-        if eng.adv_fused and self._build_adversaries_fused(hidden):
-            return
         self._labels_all = eng.buf("labels.all", (len(self.conditions), B), torch.int64)
         self.labels_dev = {c: self._labels_all[i] for i, c in enumerate(self.conditions)}  # one upload per step
         self.n_adv = min(len(hidden), len(self.advs))
