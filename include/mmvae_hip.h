@@ -697,6 +697,22 @@ typedef struct {
 } mmvae_adam_arena;
 int mmvae_adam_step_multi(int n_arenas, const mmvae_adam_arena* arenas_dev, int64_t max_n, mmvae_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Sparse weight gradient of the first encoder layer (ABI 6).  Replaces the autograd of nn.Linear
+ * (components.py:276) for the layer that reads the batch: dW[M, G] = dY[B, M]^T . x[B, G] with x ~5-20 % populated
+ * (cellxgene_datapipe.py:169-193 yields CSR; the bench's synthetic batches store 19 %).
+ *   mmvae_ell_from_dense_f32   the dense batch -> gene-major ELL in one pass: gene g owns slots [g * cap, g * cap + cnt[g])
+ *                              of rows (64 * cell index, int32, ascending) / vals, zero-padded to a multiple of 8 entries;
+ *                              cap >= B, a multiple of 8; rows / vals 16-byte aligned.
+ *   mmvae_dw_sparse_ell_f32    a workgroup holds a 64-output slice of dY in LDS (B * 256 bytes <= 140 KB), a wave owns a
+ *                              gene, lane = output: one LDS read + one FMA per stored entry; fp32 FMA chain in cell
+ *                              order (bitwise reproducible).  ldw >= G.
+ * ------------------------------------------------------------------------------------------------------------ */
+int mmvae_ell_from_dense_f32(int B, int G, const float* x, int64_t ldx, int cap, int32_t* rows, float* vals, int32_t* cnt,
+                             mmvae_stream_t stream);
+int mmvae_dw_sparse_ell_f32(int B, int G, int M, const float* dY, int64_t ldy, const int32_t* rows, const float* vals,
+                            const int32_t* cnt, int cap, float* dW, int64_t ldw, mmvae_stream_t stream);
+
 /* Diagnostics: `workgroups` workgroups that each hold `lds_bytes` of LDS and spin for `micros` microseconds -- a stand-in
  * for a collective occupying workgroup slots beside the step (bench.py --sim-comm). */
 int mmvae_debug_occupy(int workgroups, int lds_bytes, int micros, float* sink, mmvae_stream_t stream);

@@ -149,6 +149,8 @@ PROTOTYPES = {
     "mmvae_adv_dw_prepare": (_i, [_i, _p, C.POINTER(_i), C.POINTER(_i)]),
     "mmvae_adv_dw_f32": (_i, [_i, _p, _i, _i, _p, _p, _p, _i, _p, _i, _p]),
     "mmvae_adam_step_multi": (_i, [_i, _p, _l, _p]),
+    "mmvae_ell_from_dense_f32": (_i, [_i, _i, _p, _l, _i, _p, _p, _p, _p]),
+    "mmvae_dw_sparse_ell_f32": (_i, [_i, _i, _i, _p, _l, _p, _p, _p, _i, _p, _l, _p]),
 }
 
 
