@@ -109,7 +109,17 @@ FAMILY = [
     ("dec_l2_dw", "weight gradient of the decoder's last layer (TN)", "gemm_x3w_kernel<1, 1, 160, 256"),
     ("enc_l1_dw", "weight gradient of the encoder's first layer (TN)", "gemm_x3w_kernel<1, 1, 256, 160"),
 ]
-PMC_FAMILY_FILE = os.path.join(ROOT, "profiles", "r3_pmc_family.csv")
+def _latest_pmc_family():
+    """profiles/r<N>_pmc_family.csv of the latest round (tools/collect_profiles.sh writes it ahead of the bench line)."""
+    import glob
+    import re
+
+    found = [(int(re.search(r"r(\d+)_pmc_family", f).group(1)), f)
+             for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_family.csv")) if re.search(r"r(\d+)_pmc_family", f)]
+    return max(found)[1] if found else os.path.join(ROOT, "profiles", "r3_pmc_family.csv")
+
+
+PMC_FAMILY_FILE = _latest_pmc_family()
 
 
 def pmc_traffic():
