@@ -2,7 +2,9 @@
 layer: forward, weight gradient from pre-split planes; the decoder's last layer: fused forward + reconstruction, input
 gradient, weight gradient with h pre-split) a few times each, for rocprofv3 --pmc passes (one counter group per run):
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out -o p -- python3 tools/roofline_kernel.py
-usage: roofline_kernel.py [family | fwd | dw | dw_planes]"""
+usage: roofline_kernel.py [family | fwd | dw | dw_planes | fwd_half]
+(fwd_half: the forward GEMM over half the genes -- half the MFMAs: shows that SQ_VALU_MFMA_BUSY_CYCLES counts, it is
+equal for the five kernels of the family because they do equal work)"""
 import os
 import sys
 
@@ -41,6 +43,8 @@ for _ in range(8):
         ops.gemm_planes(ops.GEMM_TN, dP, None, b_planes=hp, out=dW4, want_sq=True)  # dW4[G, 1024] = dP^T . h  (h pre-split)
     if which in ("family", "dw_planes"):  # dW1[1024, G] = dY^T . X from pre-split planes (LDS-DMA stagers)
         ops.gemm_planes(ops.GEMM_TN, None, None, a_planes=dYp, b_planes=Xp, out=dW1, want_sq=True)
+    if which == "fwd_half":
+        ops.gemm_slabs(ops.GEMM_NT, X[:, : G // 2], W1[:, : G // 2])
     if which == "dw":  # the same product with the in-kernel split (round 2's form)
         ops.gemm_planes(ops.GEMM_TN, dY, X, out=dW1, want_sq=True)
 torch.cuda.synchronize()
