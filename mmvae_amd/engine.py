@@ -40,6 +40,7 @@ from .optim import HipAdam
 
 MAX_POINTER_PLANS = 8
 SIDE_MAX_ROWS = 640  # the forked programs were measured up to this many rows (see _Plan._build)
+ADV_DW_CAP = 170     # adversarial programs: workgroup cap of the decoder's weight gradient on its late branch (_Plan._build)
 
 
 @dataclass(frozen=True)
@@ -54,7 +55,7 @@ class EngineSettings:
     side_dw_dp: int = 125        # MMVAE_SIDE_DW_DP: that branch inside the exchange (data-parallel) program; 0 = in order
     side_dw_any: bool = False    # MMVAE_SIDE_DW_ANY=1: fork outside the measured geometry too
     adv_fused: bool = True       # MMVAE_ADV_FUSED=0: the per-layer adversary program (the path of adversaries with BatchNorm)
-    adv_aside: bool = True       # MMVAE_ADV_ASIDE=0: the fused adversary passes in order instead of on the branch stream
+    adv_aside: int = 2           # MMVAE_ADV_ASIDE: 0 the fused adversary passes in order; 1 on the branch stream; 2 + the decoder's weight gradient on a second branch from where the first is joined
     dp_overlap: Optional[bool] = None  # MMVAE_DP_OVERLAP: None = overlapped exchange whenever gradients are exchanged
     dp_shard: bool = True        # MMVAE_DP_SHARD=0: all-reduce + full update instead of the sharded expert update
     dp_kernels: str = "auto"     # MMVAE_DP_KERNELS: dynamic | persistent | auto (timed on the first multi-rank steps)
@@ -73,7 +74,7 @@ class EngineSettings:
             planes=e("MMVAE_PLANES", "1") != "0", side_dw=int(e("MMVAE_SIDE_DW", "125")),
             side_dw2=int(e("MMVAE_SIDE_DW2", "185")), side_dw_dp=int(e("MMVAE_SIDE_DW_DP", "125")),
             side_dw_any=e("MMVAE_SIDE_DW_ANY", "0") != "0", adv_fused=e("MMVAE_ADV_FUSED", "1") != "0",
-            adv_aside=e("MMVAE_ADV_ASIDE", "1") != "0",
+            adv_aside=int(e("MMVAE_ADV_ASIDE", "2")),
             dp_overlap=None if ov == "" else ov != "0", dp_shard=e("MMVAE_DP_SHARD", "1") != "0", dp_kernels=kernels,
             dp_sim_world=int(e("MMVAE_DP_SIM_WORLD", "0")), dp_autotune_force=e("MMVAE_DP_AUTOTUNE_FORCE", "0") != "0")
 
@@ -157,6 +158,9 @@ class StepEngine:
         # adversaries without BatchNorm: both phases of all of them as seven launches (_Plan._build_adversaries_fused)
         self.adv_fused = st.adv_fused
         self.side_stream = torch.cuda.Stream(device=self.device) if (self.side_dw or self.side_dw_dp) else None
+        # adversarial programs: the first branch stream carries the adversaries' passes from the reparameterisation into
+        # the backward chain, the decoder's capped weight gradient takes a second one
+        self.side_stream2 = torch.cuda.Stream(device=self.device) if (self.side_dw and st.adv_aside >= 2 and st.adv_fused) else None
         self.comm_stream = self.small_stream = None
         self._configure_parallel()
         self._sig = self._signature()
@@ -743,7 +747,28 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             # dP <- diag(w) dP in place (w = softmax weights of the K-sample bound), dbias = column sums
             self._emit_fc_bwd(R, G, self.dP, None, self.w, self.dP, last.gb)
         dw_pl = (None, self.hp) if self.pl_dec_h else None
-        if side_dw:  # input gradient first (the chain waits for it), then the weight gradient on the side branch
+        # (adversaries on the first branch stream: the capped weight gradient beside the chain takes the second one)
+        dw_stream = eng.side_stream2 if adv_aside else None
+        dw4_late = None
+        if adv_aside and dw_stream is not None and eng.settings.adv_aside >= 2:
+            # The branch stream carries the adversaries until the chain needs their reversed gradients; the weight
+            # gradient is forked THERE, on a second branch beside the rest of the chain (reparameterisation, heads, the
+            # encoder's BatchNorm layers: ~105 us), capped to the workgroup count that keeps its 500 work items at
+            # three rounds.  C4 on one box: 1.183 -> 1.135 ms at 185, 1.132 at 170; 1.17 at 125, 1.20 at 150, 1.16 at
+            # 200.  Forked right behind the input gradient instead -- beside the adversaries' generator phase -- the
+            # step is 8 % SLOWER (1.25 ms): the three lanes fight over the CUs (profiles/r4_c4_dw_aside.txt).
+            self._probe_next = "dec_l2_dx"
+            S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
+            self._probe_next = None
+
+            def dw4_late():
+                self._probe_next = "dec_l2_dw"
+                if not self._fuse_sqnorm(TN, G, last.n_in, self.kpad(R), 1.0, self.dP, G, last.inp, last.ld_inp, last.gW,
+                                         last.n_in, None, 0, side_cap=ADV_DW_CAP, planes=dw_pl, stream=dw_stream):
+                    self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in,
+                              side=True, planes=dw_pl)
+                self._probe_next = None
+        elif side_dw:  # input gradient first (the chain waits for it), then the weight gradient on the side branch
             self._probe_next = "dec_l2_dx"
             S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
             self._probe_next = "dec_l2_dw"
@@ -790,7 +815,9 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
         if not rest:
             raise _lib.HipLibraryError("engine: decoder needs at least two layers")
         if adv_aside:  # the adversaries' branch: its reversed gradients are read from here on
-            self._join()
+            self._join(only=eng.side_stream)
+            if dw4_late is not None:
+                dw4_late()
             self._emit(lib.mmvae_axpby, 1, 1.0, _p(self.metrics), 1.0, self.mptr("total_loss"))
         # gradient-reversed adversary gradient on z (first sample) joins here
         zi = self.adv_grad_into.get(id(self.z))

@@ -78,7 +78,7 @@ class PlanEmit:
         return sk.value
 
     def _fuse_sqnorm(self, layout, M, N, K, alpha, A, lda, Bm, ldb, Cm, ldc, bias, flags, side_cap: int = 0,
-                     on_side: bool = True, planes=None, fork: bool = True) -> bool:
+                     on_side: bool = True, planes=None, fork: bool = True, stream=None) -> bool:
         """Unsplit weight-gradient GEMM straight into a gradient arena: let its epilogue also leave the partial sums of
         squares of what it stores (mmvae_gemm_f32_sq), so that the clip's norm pass does not read the 82 MB back.  Only
         without a gradient exchange: under data parallelism the norm is that of the REDUCED gradients."""
@@ -123,9 +123,9 @@ class PlanEmit:
                               shape=f"{('NT', 'NN', 'TN')[layout]} {M}x{N}x{K}")
 
         if side_cap:  # persistent grid capped to `side_cap` workgroups: the CUs left over serve another branch
-            side = eng.side_stream if on_side else None
+            side = (stream if stream is not None else eng.side_stream) if on_side else None
             if on_side and fork:
-                self._fork()
+                self._fork(side)
 
             def call():
                 plan.lib.mmvae_gemm_set_workgroup_cap(side_cap)
@@ -278,11 +278,13 @@ class PlanEmit:
         if side not in self._dirty:
             self._dirty.append(side)
 
-    def _join(self):
-        """Main stream waits for every branch with outstanding work (before the optimiser reads the gradient arenas)."""
+    def _join(self, only=None):
+        """Main stream waits for every branch with outstanding work (before the optimiser reads the gradient arenas);
+        `only`: for that branch stream alone."""
         for side in self._dirty:
-            self._edge(side, None)
-        self._dirty = []
+            if only is None or side is only:
+                self._edge(side, None)
+        self._dirty = [] if only is None else [s for s in self._dirty if s is not only]
 
     def _take(self, start: int) -> list:
         """Remove and return the calls emitted since position `start`."""

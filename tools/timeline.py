@@ -22,3 +22,5 @@ for n, s, e in rows[a:b]:
     print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:7.2f}  gap {gap:6.2f}  {n}")
     prev_end = e
 print(f"step span {(rows[b][1] - t0) / 1e3:.1f} us, kernel busy {busy / 1e3:.1f} us, launches {b - a}")
+per = [(rows[starts[i + 1]][1] - rows[starts[i]][1]) / 1e3 for i in range(max(0, len(starts) - 10), len(starts) - 1)]
+print("start-to-start periods of the last steps (us): " + " ".join(f"{p:.0f}" for p in per))
