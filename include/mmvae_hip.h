@@ -40,7 +40,7 @@ typedef void* mmvae_stream_t; /* hipStream_t */
 /* ABI version: bumped whenever an entry point is added or a signature changes (mmvae_abi_version() returns the
  * value the library was built with; bindings compare it with the header they were written against).
  *   1  round-1 surface (first 20 entry points)      2  end of round 1 (50 entry points)      3+  round 2 */
-#define MMVAE_ABI_VERSION 6
+#define MMVAE_ABI_VERSION 7
 int mmvae_abi_version(void);
 const char* mmvae_build_arch(void);
 
@@ -721,6 +721,14 @@ int mmvae_debug_occupy(int workgroups, int lds_bytes, int micros, float* sink, m
 int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, float* y, mmvae_stream_t stream);
 int mmvae_scale_rows(int B, int N, const float* x, int64_t ldx, const float* row_scale, float* y, int64_t ldy,
                      mmvae_stream_t stream);
+/* Row-weighted column sums of a wide matrix in one read-only pass (ABI 7): partials[chunk][c] = sum over the rows of the
+ * chunk (mmvae_weighted_colsum_chunks(B) chunks of 256 rows) of row_weight[r] * x[r][c]; the caller sums the chunks
+ * (mmvae_sum_parts_batch).  16-byte accesses when x is 16-byte aligned and ldx a multiple of 4.  The K-sample ELBO's decoder-bias gradient
+ * w^T dP (the softmax weights of the bound times the reconstruction gradient; the reference has no K: SURVEY 8 a7)
+ * without scaling the [K B, G] matrix in place. */
+int mmvae_weighted_colsum_chunks(int B);
+int mmvae_weighted_colsum_f32(int B, int N, const float* x, int64_t ldx, const float* row_weight, float* partials,
+                              mmvae_stream_t stream);
 
 #ifdef __cplusplus
 }

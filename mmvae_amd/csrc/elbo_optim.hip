@@ -1456,6 +1456,71 @@ extern "C" int mmvae_sum_parts_batch(int n_jobs, const mmvae_sum_job* jobs, int6
     return MMVAE_OK;
 }
 
+// Row-weighted column sums of a wide matrix, read once in 16-byte accesses: partials[chunk][c] = sum over the chunk's
+// WCS_ROWS rows of w[r] * x[r][c] (fp32 chain in row order inside a wave's share, the four waves' shares added in wave
+// order: reproducible).  A workgroup = 256 columns x one row chunk; wave v takes rows v, v + 4, ... of the chunk, eight
+// rows in flight.  (K-sample ELBO: the decoder bias's gradient is w^T dP; the pass that scaled dP in place for it read
+// and wrote 2 x 410 MB at C3 -- 350 us.)
+constexpr int WCS_ROWS = 256, WCS_COLS = 256;
+__global__ __launch_bounds__(256) void weighted_colsum_kernel(int B, int N, const float* __restrict__ x, int64_t ldx,
+                                                              const float* __restrict__ w, float* __restrict__ partials,
+                                                              int vec) {
+    __shared__ f32x4 red[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * WCS_COLS + 4 * lane;
+    const int r_begin = blockIdx.y * WCS_ROWS, r_end = min(r_begin + WCS_ROWS, B);
+    const bool whole = vec && c + 3 < N;  // (vec == 0: rows that are not 16-byte groups -- odd toy shapes -- go element-wise)
+    const int cc = whole ? c : 0;  // (a straddling group of 4 is handled element-wise below)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = r_begin + wave; vec && r0 < r_end; r0 += 32) {
+        f32x4 v[8];
+        float ws[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {  // clamped, unconditional loads: eight rows in flight
+            const int r = min(r0 + 4 * i, r_end - 1);
+            ws[i] = (r0 + 4 * i < r_end) ? w[r] : 0.f;
+            v[i] = *reinterpret_cast<const f32x4*>(x + (int64_t)r * ldx + cc);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(ws[i], v[i][e], acc[e]);
+    }
+    if (!whole) {  // the last, partial group of columns: scalar
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = r_begin + wave; r < r_end; r += 4)
+            for (int e = 0; e < 4; ++e)
+                if (c + e < N) acc[e] = fmaf(w[r], x[(int64_t)r * ldx + c + e], acc[e]);
+    }
+    if (wave > 0) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += red[v][lane][e];
+        float* out = partials + (int64_t)blockIdx.y * N + c;
+        if (whole && (((uintptr_t)out) & 15u) == 0) {
+            *reinterpret_cast<f32x4*>(out) = acc;
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (c + e < N) out[e] = acc[e];
+        }
+    }
+}
+
+extern "C" int mmvae_weighted_colsum_chunks(int B) { return B > 0 ? (B + WCS_ROWS - 1) / WCS_ROWS : 0; }
+
+extern "C" int mmvae_weighted_colsum_f32(int B, int N, const float* x, int64_t ldx, const float* row_weight, float* partials,
+                                         mmvae_stream_t stream) {
+    if (B <= 0 || N <= 0 || !x || !row_weight || !partials || ldx < N) return MMVAE_ERR_ARG;
+    const int vec = !((((uintptr_t)x) & 15u) || (ldx & 3));  // 16-byte row groups
+    MMVAE_LAUNCH(weighted_colsum_kernel, dim3((N + WCS_COLS - 1) / WCS_COLS, (B + WCS_ROWS - 1) / WCS_ROWS), dim3(256), 0,
+                 (hipStream_t)stream, B, N, x, ldx, row_weight, partials, vec);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
 extern "C" int mmvae_scale_rows(int B, int N, const float* x, int64_t ldx, const float* row_scale, float* y,
                                 int64_t ldy, mmvae_stream_t stream) {
     if (B <= 0 || N <= 0 || !x || !row_scale || !y || ldx < N || ldy < N) return MMVAE_ERR_ARG;

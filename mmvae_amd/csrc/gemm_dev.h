@@ -894,12 +894,21 @@ struct X3Regs {
 // the next output tile (HBM latency) hides behind the epilogue stores of the current one.
 //
 // LDS image: [plane][row][64 B] (32 k as bf16), no padding (2 x 79 872 B would not fit with 80-byte rows); the 16-byte
-// chunk c of row r sits at chunk c ^ ((r >> 2) & 3): conflict-free for the multipliers' ds_read_b128 (its 16-lane
-// groups cover rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}: (r >> 2) & 3 takes each value once per r % 4) and for
-// the stagers' ds_write_b64 (16 lanes = 2 whole rows).  The last 4 KiB of LDS are the epilogue's scratch.
+// chunk c of row r sits at chunk c ^ xw_swz(r), xw_swz(r) = -(r >> 2) & 3.  A ds_read_b128 is served in four groups of
+// 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- each of which must touch 16 distinct
+// 16-byte bank groups (row % 4 picks the 64-byte quarter, the chunk the 16 bytes inside it):
+//   32x32x16 fragments (lane & 31 = row, lane >> 5 = chunk pair): a group covers row blocks r >> 2 = {0, 3, 5, 6} or
+//       {1, 2, 4, 7} with one chunk: any bijection of (r >> 2) & 3 separates them;
+//   16x16x32 fragments (lane & 15 = row, lane >> 4 = chunk): a group covers row blocks {0, 3} with chunk c and {1, 2}
+//       with chunk c ^ 1: needs {s(0), s(3), s(1) ^ 1, s(2) ^ 1} distinct -- s = (0, 3, 2, 1), not the identity (r3's
+//       c ^ (r >> 2) & 3 made rows 4-7 collide with rows 0-3 and 8-11 with 12-15: SQ_LDS_BANK_CONFLICT 5.8 M cycles per
+//       launch of the NT kernel = a third of its LDS cycles, 0 now; the step did not change: profiles/r4_pmc_extra.csv).
+// The stagers' ds_write_b64 cover whole rows (32 lanes = 4 rows): any chunk permutation is conflict-free for them.
+// The last 4 KiB of LDS are the epilogue's scratch.
 constexpr int XW_ROWB = 64;                   // bytes per row per plane
 constexpr int XW_SCRATCH = 4096;              // epilogue scratch behind the two images
-__device__ __forceinline__ int xw_off(int row, int chunk) { return row * XW_ROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
+__device__ __forceinline__ int xw_swz(int row) { return -(row >> 2) & 3; }
+__device__ __forceinline__ int xw_off(int row, int chunk) { return row * XW_ROWB + ((chunk ^ xw_swz(row)) << 4); }
 
 // One operand of the stager: R rows, NU = R / 32 units per thread (a unit = 4 consecutive-k fp32 values of one row).
 // R = 256 over a rows-contiguous operand is handled as two 128-row halves of the 4 k x 4 row patch scheme of x3p_*.
@@ -1049,7 +1058,7 @@ struct XwCursor {
 // the fp32 matrix) is moved global -> LDS by LDS-DMA: global_load_lds_dwordx4, 64 lanes x 16 B = one 1-KiB piece of LDS
 // per wave-instruction, no VGPR destination, no VALU.  The LDS destination of a piece is linear (M0 + 16 * lane), so the
 // image's swizzle is applied to the per-lane SOURCE address and again by the reader.
-//   K-contiguous planes (FORM_KC): the multipliers' usual [plane][row][64 B] image, chunk c of row r at c ^ ((r >> 2) & 3);
+//   K-contiguous planes (FORM_KC): the multipliers' usual [plane][row][64 B] image, chunk c of row r at c ^ xw_swz(r);
 //       a piece = 16 rows x 64 B.
 //   rows-contiguous planes (FORM_RC): the image is [plane][32 k][R rows] bf16 -- the operand's own orientation -- and the
 //       multipliers read their fragments with ds_read_b64_tr_b16 (two per 8-k fragment): no transposing pass anywhere.
@@ -1108,7 +1117,7 @@ struct XwPlanes {
             if (FORM == FORM_KC) {
                 constexpr int PPP = R / 16;  // pieces per plane
                 const int plane = pi / PPP, row = 16 * (pi % PPP) + (lane >> 2);
-                const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+                const int chunk = (lane & 3) ^ xw_swz(row);
                 const int rc = min(r0 + row, Rtot - 1);
                 off[j] = (unsigned)((plane * pstride + (int64_t)rc * ld) * 2 + chunk * 16);
             } else {
@@ -1375,7 +1384,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, half = lane >> 5;
-    const int swz = (l31 >> 2) & 3;
+    const int swz = xw_swz(l31);
     // byte offset of this lane's fragment inside a plane for k-step ks: row l31 of a 32-row block, chunk 2 ks + half
     const int coff[2] = {l31 * XW_ROWB + (((0 + half) ^ swz) << 4), l31 * XW_ROWB + (((2 + half) ^ swz) << 4)};
     const int a_row0 = wm * WTM * XW_ROWB, b_row0 = wn * WTN * XW_ROWB;
@@ -1420,7 +1429,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
     // 16x16x32 fragments: row l15 of a 16-row sub-block, k = 8 grp .. 8 grp + 7 = chunk grp of the row's 64 bytes; the
     // transposed reads address k-row 8 grp + q, the sub-block's half of the 64-byte slot
     const int l15 = lane & 15, grp = lane >> 4;
-    const int coff16 = l15 * XW_ROWB + ((grp ^ ((l15 >> 2) & 3)) << 4);
+    const int coff16 = l15 * XW_ROWB + ((grp ^ xw_swz(l15)) << 4);
     auto tr_lane_off16 = [&](int R, int bg) {  // first transposed read of sub-block 0 of block bg
         const int slot = (R == 160) ? bg : (bg ^ tq);
         return (8 * grp + tq) * (2 * R) + slot * 64 + 8 * (lane & 3);

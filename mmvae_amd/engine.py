@@ -743,9 +743,21 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             self._emit(lib.mmvae_axpby, 1, 1.0, _p(self.metrics), 1.0, self.mptr("total_loss"))
 
         # ---- backward, decoder side
+        dw_inp, dw_ld, w_rows = last.inp, last.ld_inp, None
         if K > 1:
-            # dP <- diag(w) dP in place (w = softmax weights of the K-sample bound), dbias = column sums
-            self._emit_fc_bwd(R, G, self.dP, None, self.w, self.dP, last.gb)
+            # The gradient at the decoder's output is diag(w) dP (w = softmax weights of the K-sample bound, known only
+            # once every sample's loss is).  dP [K B, G] is not rewritten for it (that pass read and wrote 2 x 410 MB
+            # at C3: 350 us of a 4.0 ms step): the bias gradient w^T dP is one read-only pass, the weight gradient
+            # dP^T diag(w) h takes h scaled by w (a [K B, 1024] pass), and the input gradient diag(w) (dP W) gets its
+            # rows scaled where the next layer's column kernel sums the split-K slabs.
+            w_rows = self.w
+            nch = lib.mmvae_weighted_colsum_chunks(R)
+            parts = eng.buf(f"wcolsum.{G}", (nch, G))
+            self._emit(lib.mmvae_weighted_colsum_f32, R, G, _p(self.dP), G, _p(self.w), _p(parts))
+            self._defer_sum(parts, nch, G, 1, G, G, last.gb, G)
+            dw_inp = eng.buf(f"h_weighted.{last.n_in}", (R, last.n_in))
+            dw_ld = last.n_in
+            self._emit(lib.mmvae_scale_rows, R, last.n_in, _p(last.inp), last.ld_inp, _p(self.w), _p(dw_inp), dw_ld)
         dw_pl = (None, self.hp) if self.pl_dec_h else None
         # (adversaries on the first branch stream: the capped weight gradient beside the chain takes the second one)
         dw_stream = eng.side_stream2 if adv_aside else None
@@ -793,7 +805,7 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             self._probe_next = None
         else:
             self._probe_next = "dec_l2_dw" if big else None
-            self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True,
+            self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, dw_inp, dw_ld, last.gW, last.n_in, side=True,
                       planes=dw_pl)
             self._probe_next = "dec_l2_dx" if big else None
             S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
@@ -801,10 +813,11 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
         rest = self.dec_layers[:-1]
         for j in range(len(rest) - 1, -1, -1):
             l = rest[j]
+            rs = w_rows if j == len(rest) - 1 else None  # (the rows of the slabs coming out of the last layer)
             if j > 0:
-                S = self.bwd_layer(l, None, S, need_dx="raw")
+                S = self.bwd_layer(l, None, S, need_dx="raw", row_scale=rs)
             else:
-                self.bwd_layer(l, None, S, need_dx="full",
+                self.bwd_layer(l, None, S, need_dx="full", row_scale=rs,
                                dx_out=self.dz_lat if self.cond is None else self.cond.d_out)
         if self.cond is not None:
             self.cond.emit_backward(self.dz_lat)

@@ -420,9 +420,11 @@ class PlanEmit:
 
     # ---- one layer backward.  din: tensor [rows, n_out] or None (= shared slab buffer holding S_in raw slabs)
     def bwd_layer(self, l: _LayerRef, din, S_in: int, addend=None, need_dx: str = "raw", dx_out=None, dx_flags=0,
-                  dx_alpha=1.0, dz_planes: Optional[_PlaneBuf] = None, inp_planes: Optional[_PlaneBuf] = None):
+                  dx_alpha=1.0, dz_planes: Optional[_PlaneBuf] = None, inp_planes: Optional[_PlaneBuf] = None,
+                  row_scale=None):
         """dz_planes / inp_planes: pre-split forms of this layer's output gradient (written by its column kernel) and of
-        its input -- both operands of its weight-gradient GEMM."""
+        its input -- both operands of its weight-gradient GEMM.  row_scale: per-row factor of the incoming gradient
+        (the K-sample bound's weights, applied where the slabs are summed)."""
         rows = l.rows
         dw_planes = (dz_planes, inp_planes) if (dz_planes is not None and inp_planes is not None) else None
         plan = self
@@ -437,7 +439,7 @@ class PlanEmit:
             din_ptr = _p(din) if din is not None else plan.slab.data_ptr()
             ws = own_ws if own_ws is not None else plan.fcws
             # `addend` is a gradient on the hidden representation = the activation BEFORE dropout: it bypasses the mask
-            args = (rows, l.n_out, din_ptr, l.n_out, S_in, None, _p(addend), None, _p(l.mask), l.p, int(l.relu),
+            args = (rows, l.n_out, din_ptr, l.n_out, S_in, None, _p(addend), _p(row_scale), _p(l.mask), l.p, int(l.relu),
                     _p(relu_src) if l.relu else None, _p(l.z), _p(l.bn.weight) if has_bn else None, _p(l.mean),
                     _p(l.invstd), int(has_bn), _p(l.dz), l.n_out, _p(l.gb) if own_ws is None else None,
                     _p(l.ggamma) if has_bn else None, _p(l.gbeta) if has_bn else None, ws.data_ptr(), ws.numel() * 4)

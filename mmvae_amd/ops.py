@@ -782,6 +782,17 @@ def gemm_batch(jobs) -> None:
     torch.cuda.current_stream().synchronize()  # jobs_dev must outlive the launch
 
 
+def weighted_colsum(x: torch.Tensor, row_weight: torch.Tensor) -> torch.Tensor:
+    """partials [chunks of 256 rows, N]: sum over a chunk's rows of row_weight[r] * x[r, :] (mmvae_weighted_colsum_f32)."""
+    lib = _lib.load()
+    _chk(x, "x"), _chk(row_weight, "row_weight")
+    B, N, ldx = _mat(x, "x")
+    parts = torch.empty((lib.mmvae_weighted_colsum_chunks(B), N), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mmvae_weighted_colsum_f32(B, N, _ptr(x), ldx, _ptr(row_weight), _ptr(parts), _stream()),
+               "mmvae_weighted_colsum_f32")
+    return parts
+
+
 def scale_rows(x: torch.Tensor, row_scale: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
     _chk(x, "x"), _chk(row_scale, "row_scale")

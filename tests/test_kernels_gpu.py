@@ -637,6 +637,21 @@ def test_small_utils(ops):
     torch.testing.assert_close(ops.scale_rows(dev(a), dev(rs)).cpu(), a * rs.unsqueeze(1))
 
 
+@pytest.mark.parametrize("B,N,ld", [(5120, 20000, 20000), (300, 1003, 1004), (7, 5, 8), (256, 256, 256), (513, 260, 272), (70, 33, 33)])
+def test_weighted_colsum(ops, B, N, ld):
+    """w^T x of a wide matrix in one read-only pass (the K-sample bound's decoder-bias gradient): chunk partials whose
+    sum matches fp64; identical on a second run (fixed summation order)."""
+    full = rnd(B, ld, seed=5)
+    x = dev(full)[:, :N]
+    w = dev(torch.rand(B, generator=torch.Generator().manual_seed(6)) / B)
+    parts = ops.weighted_colsum(x, w)
+    assert parts.shape == ((B + 255) // 256, N)
+    want = (w.double().cpu() @ full[:, :N].double())
+    got = parts.double().sum(0).cpu()
+    assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max() + (full[:, :N].abs().double().T @ w.double().cpu()).max())
+    assert torch.equal(parts, ops.weighted_colsum(x, w))
+
+
 def test_bad_arguments_are_rejected_on_host(ops):
     from mmvae_amd import _lib
 
