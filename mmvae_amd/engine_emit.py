@@ -186,6 +186,26 @@ class PlanEmit:
         job = _lib.GemmJob(_p(A), _p(Bm), _p(Cm), _p(bias), lda, ldb, ldc, layout, M, N, K, float(alpha), int(flags), 0, 0)
         if not self.lib.mmvae_gemm_batch_job_ok(C.addressof(job)):
             return False
+        if layout == TN and K >= 2048 and bias is None and not (flags & ~ACC):
+            # K x B sample rows (K-sample programs: 5120): a grouped job runs its whole K in one workgroup per 64 x 64
+            # tile -- 160 k-tiles one after the other, 161 us at C3 for 2.5 GFLOP.  Slices of 512 rows as jobs of their
+            # own into slabs, summed by the deferred reduction that runs behind the grouped launch anyway.
+            n_sl = (K + 511) // 512
+            slabs = self.eng.buf(f"dwslabs.{self._next_defer_id()}", (n_sl, M, N))
+            ok = True
+            sub = []
+            for i in range(n_sl):
+                k0 = 512 * i
+                kk = min(512, K - k0)
+                j = _lib.GemmJob(_p(A) + 4 * k0 * lda, _p(Bm) + 4 * k0 * ldb, _p(slabs[i]), None, lda, ldb, N, layout, M, N,
+                                 kk, 1.0, 0, 0, 0)
+                ok = ok and bool(self.lib.mmvae_gemm_batch_job_ok(C.addressof(j)))
+                sub.append(j)
+            if ok:
+                self._gemm_jobs.extend(sub)
+                self._sum_keep.append((A, Bm, Cm, slabs))
+                self._defer_sum(slabs, n_sl, M * N, M, N, N, Cm, ldc, alpha, flags & ACC)
+                return True
         self._gemm_jobs.append(job)
         self._sum_keep.append((A, Bm, Cm, bias))
         return True
