@@ -79,6 +79,19 @@ class EngineSettings:
             dp_sim_world=int(e("MMVAE_DP_SIM_WORLD", "0")), dp_autotune_force=e("MMVAE_DP_AUTOTUNE_FORCE", "0") != "0")
 
 
+# HIP runtimes (prefixes of torch.version.hip) on which the multi-stream captured programs have been validated: > 10^4
+# replays per program of the measured geometry without a fault.  The box-dependent crash inside hipGraphLaunch that toy
+# shapes showed on 7.0 (tools/debug/graph_crash_stress.py is the reproducer; _Plan._build keeps such shapes on one stream)
+# has no root cause: on a runtime nobody has run them on, the programs stay on ONE stream unless MMVAE_SIDE_DW_ANY=1.
+FORK_VALIDATED_RUNTIMES = ("7.0.",)
+
+
+def forks_allowed(settings: "EngineSettings", runtime: Optional[str] = None) -> bool:
+    """May captured programs fork onto branch streams on this HIP runtime?"""
+    v = (torch.version.hip or "") if runtime is None else runtime
+    return bool(settings.side_dw_any) or any(v.startswith(p) for p in FORK_VALIDATED_RUNTIMES)
+
+
 class StepEngine:
     @staticmethod
     def try_build(model) -> Optional["StepEngine"]:
@@ -148,12 +161,19 @@ class StepEngine:
         # at C2 (profiles/r2_side_dw_sweep.txt): cap 125 -> -2.4 %, 140/167 -> -0.8 %, 200 -> +2.6 %; bit-identical
         # results.  0 = one stream.
         self.side_dw = st.side_dw
+        self.fork_ok = forks_allowed(st)
+        if not self.fork_ok and (st.side_dw or st.side_dw_dp):
+            import warnings
+
+            warnings.warn(f"mmvae_amd.engine: HIP runtime {torch.version.hip} is not one the forked step programs were "
+                          f"validated on {FORK_VALIDATED_RUNTIMES}: single-stream programs (MMVAE_SIDE_DW_ANY=1 overrides)")
+            self.side_dw = 0
         # cap of the expert encoder's weight gradient while the shared VAE's optimiser (and the loss words, the bias
         # column sums) run beside it on the branch stream (553 items at C2: 3 rounds on 185 workgroups as on 256)
         self.side_dw2 = st.side_dw2
         # the decoder's branch inside the exchange program (data parallelism): beside the part of the backward chain that
         # lies ahead of the shared VAE's exchange point (the cut joins it); 0 = in order
-        self.side_dw_dp = st.side_dw_dp
+        self.side_dw_dp = st.side_dw_dp if self.fork_ok else 0
         self.side_dw_any = st.side_dw_any
         # adversaries without BatchNorm: both phases of all of them as seven launches (_Plan._build_adversaries_fused)
         self.adv_fused = st.adv_fused

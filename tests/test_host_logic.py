@@ -260,3 +260,16 @@ def test_conditional_layers_refuse_more_than_one_latent_sample():
 
     with pytest.raises(ValueError, match="one latent sample"):
         CLVAE.after_reparameterize(_Stub(), torch.zeros(3, 4, 8), pd.DataFrame({"a": [0] * 4}))
+
+
+def test_forked_programs_are_fenced_to_validated_runtimes():
+    """The multi-stream captured programs run only on HIP runtimes they were validated on (the hipGraphLaunch hazard of
+    DESIGN.md has no root cause); MMVAE_SIDE_DW_ANY=1 overrides."""
+    import dataclasses
+
+    from mmvae_amd.engine import EngineSettings, forks_allowed
+
+    st = EngineSettings()
+    assert forks_allowed(st, "7.0.51831")
+    assert not forks_allowed(st, "7.2.26015") and not forks_allowed(st, "")
+    assert forks_allowed(dataclasses.replace(st, side_dw_any=True), "7.2.26015")
