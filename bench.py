@@ -421,6 +421,14 @@ def main():
         model._flush_engine()  # the last step's deferred expert update belongs to the timed work (engine.defer_tail)
     sync()
     el = time.perf_counter() - t0
+    if os.environ.get("MMVAE_STAMPS") == "1" and getattr(model, "_engine", None):
+        # diagnostics: milestones of the LAST replayed step, from marker launches inside the captured program (no tracer
+        # attached; the markers cost ~2 us each: this run's ms/step is not a result)
+        plan = model._engine.last_plan
+        st = model._engine.buf("debug.stamps", (256,), torch.int64).cpu().tolist()[:len(plan.stamp_names)]
+        t_first = min(st)
+        for t, name in sorted(zip(st, plan.stamp_names)):
+            print(f"{(t - t_first) / 100.0:9.1f} us  {name}", file=sys.stderr)
     if feed is not None:
         feed.close()  # stops the feed's background threads before the interpreter shuts down
     if world > 1:

@@ -716,6 +716,9 @@ int mmvae_dw_sparse_ell_f32(int B, int G, int M, const float* dY, int64_t ldy, c
 /* Diagnostics: `workgroups` workgroups that each hold `lds_bytes` of LDS and spin for `micros` microseconds -- a stand-in
  * for a collective occupying workgroup slots beside the step (bench.py --sim-comm). */
 int mmvae_debug_occupy(int workgroups, int lds_bytes, int micros, float* sink, mmvae_stream_t stream);
+/* Diagnostics: a marker launch that writes the device's 100 MHz wall clock into buf[slot] -- milestones of a captured
+ * program as it runs without a tracer attached (MMVAE_STAMPS=1: the engine places them; tools/stamps_timeline.py). */
+int mmvae_debug_stamp(long long* buf, int slot, mmvae_stream_t stream);
 
 /* Small utilities used by the step engine: y = alpha*x (+ y), fill. */
 int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, float* y, mmvae_stream_t stream);

@@ -1113,6 +1113,16 @@ extern "C" int mmvae_cross_entropy_heads(int B, int H, int max_classes, const in
     return MMVAE_OK;
 }
 
+// Diagnostics: one wall-clock stamp (100 MHz) into buf[slot] -- a marker launch between two launches of a captured
+// program, for a timeline of the program as it runs WITHOUT a tracer attached (bench.py --stamps).
+__global__ void debug_stamp_kernel(long long* __restrict__ buf, int slot) { buf[slot] = wall_clock64(); }
+extern "C" int mmvae_debug_stamp(long long* buf, int slot, mmvae_stream_t stream) {
+    if (!buf || slot < 0) return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(debug_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, buf, slot);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
 extern "C" int mmvae_debug_occupy(int workgroups, int lds_bytes, int micros, float* sink, mmvae_stream_t stream) {
     if (workgroups <= 0 || workgroups > 256 || lds_bytes < 1024 || lds_bytes > 160 * 1024 || micros <= 0 ||
         micros > 20000)

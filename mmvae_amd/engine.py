@@ -146,6 +146,7 @@ class StepEngine:
                     opt.state_dev = view
                 self._state_slot[id(opt)] = 192 + 8 * i
         self._ptr_seen: Dict[tuple, int] = {}
+        self.stamps = os.environ.get("MMVAE_STAMPS", "0") == "1"  # diagnostics: milestone markers inside the programs
         self.eager_only = False  # measurement hook (bench.py's roofline leg): run the programs eagerly, not from their graphs
         self.klw_dev = torch.ones(1, dtype=torch.float32, device=self.device)
         self._klw_host = None
@@ -536,6 +537,7 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
         self.metric_slots: Dict[str, int] = {}
         self.segments: List = []  # list of closure lists, separated by ("allreduce", opt) markers
         self._cur: List = []
+        self.stamp_names: List[str] = []
         self._dirty: List = []          # branch streams with work the main stream has not joined yet
         self._sq_used: Dict[int, int] = {}    # per optimiser: norm-partial slots taken by fused GEMM epilogues
         self._sq_cover: Dict[int, list] = {}  # per optimiser: (offset, length) of the arena ranges they cover
@@ -570,6 +572,7 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
         B, K, R, Z, G = self.B, self.K, self.R, self.Z, self.G
         x, ldx = self.x, self.x.stride(0) if self.x.shape[0] > 1 else self.x.shape[1]
         self.eps = eng.buf("eps", (K, B, Z))
+        self._mark("step begins (behind the noise fill)")
 
         train = self.mode == "train"
         # branches beside the latency-bound sections (in-order single-rank program only; see StepEngine.side_dw)
@@ -629,6 +632,8 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             cur = self.fwd_layer(f"{self.eid}.enc{i}" if i < self.n_expert_enc else f"vae.enc{i}", l, cur, ld, B,
                                  training=train, mask_stream=i, split_job=self._next_x_split_job(l, B))
             ld = l.n_out
+            if i == 0:
+                self._mark("enc L1 forward done")
         q, HV = cur, self.enc_layers[-1].n_out
         # ---- heads + reparameterisation
         self.mu = eng.buf("mu", (B, Z))
@@ -644,6 +649,7 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             self.gemm(NT, B, Z, HV, q, HV, self.var_enc.weight, HV, self.a_raw, Z, bias=self.var_enc.bias)
         self._emit(lib.mmvae_reparam_kl_fwd, B, Z, K, _p(self.mu), _p(self.a_raw), _p(self.eps), self.var_eps,
                    _p(self.std), _p(self.z), _p(self.kl_row), _p(self.stat))
+        self._mark("reparameterised (fork point)")
         if self.mode == "embed":  # predict path: the program ends at z
             return self._finish_forward_only()
         if self.iwae:  # sampled log q(z) - log p(z) per (sample, cell)
@@ -664,6 +670,8 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             start = len(self._cur)
             if self._build_adversaries_fused(hidden):
                 adv_calls = self._take(start)
+                adv_calls = [c for c in [self._mark_call("adversaries: first launch")] if c] + adv_calls + \
+                            [c for c in [self._mark_call("adversaries: done")] if c]
                 adv_aside = bool(eng.settings.adv_aside and eng.side_stream is not None and not eng.overlap
                                  and eng.world == 1 and K == 1 and big and (measured or eng.side_dw_any)
                                  and self.cond is None)
@@ -729,6 +737,7 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             self._cur.append(recon_kpad)
         self.probe_meta["dec_l2_recon"].update(bound="mfma", cus=0, planes="",
                                                shape=f"NT {R}x{G}x{last.n_in} + reconstruction epilogue")
+        self._mark("reconstruction done")
         self.recon_row = eng.buf("recon_row", (B,))
         if self.iwae:
             self.rows3 = eng.buf("iwae.rows3", (3, B))
@@ -792,6 +801,7 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             self._probe_next = "dec_l2_dx"
             S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
             self._probe_next = None
+            self._mark("decoder dX done")
 
             def dw4_late():
                 self._probe_next = "dec_l2_dw"
@@ -848,9 +858,14 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
         if not rest:
             raise _lib.HipLibraryError("engine: decoder needs at least two layers")
         if adv_aside:  # the adversaries' branch: its reversed gradients are read from here on
+            self._mark("chain reaches the adversaries' join")
             self._join(only=eng.side_stream)
+            self._mark("adversaries joined")
             if dw4_late is not None:
                 dw4_late()
+                c = self._mark_call("decoder dW done (second branch)")
+                if c is not None:
+                    self._branch(dw_stream, [c])
             self._emit(lib.mmvae_axpby, 1, 1.0, _p(self.metrics), 1.0, self.mptr("total_loss"))
         # gradient-reversed adversary gradient on z (first sample) joins here
         zi = self.adv_grad_into.get(id(self.z))
@@ -902,6 +917,7 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             din, S = None, S_next
             if early and j == self.n_expert_enc:  # the last VAE layer is done: what remains is the expert's encoder
                 self._begin_exchange(self.opt_vae)
+        self._mark("backward chain done")
         # ---- clip + Adam (reference order: clip vae, clip expert, step vae, step expert)
         # Logged scalars: the step's metrics words (and the pre-clip gradient norms) are copied into a buffer of this
         # plan's own as the last node(s) of the captured program -- the logged tensors are views of it, valid until
@@ -944,11 +960,13 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             emit_log_copy()
         # in-order program: the log copy rides on the expert's Adam launch (its words -- losses, both norms -- are final
         # once adam_prepare has run) when the expert's norm is a state word inside the metrics buffer
+        self._mark("encoder dW done / VAE optimiser branch emitted")
         ride = (not early and self.cond is None
                 and eng._state_slot.get(id(self.opt_exp)) is not None
                 and not (eng.shard and self.opt_exp.reducer is not None))
         self.optimizer(self.opt_exp, self.clip_exp, exchange="deferred" if early else "inline",
                        tail_copy=(256, self.metrics, self.log_buf) if ride else None)
+        self._mark("expert optimiser done")
         if early:
             self.exp_norm_log = torch.zeros(1, dtype=torch.float32, device=eng.device)
         else:

@@ -26,6 +26,26 @@ class PlanEmit:
 
         self._cur.append(self._probed(probe[0], probe[1], call) if probe else call)
 
+    def _mark_call(self, name: str):
+        """Diagnostics (MMVAE_STAMPS=1): a marker launch that writes the device wall clock under `name` on whatever stream
+        is current when it is enqueued; None otherwise.  tools/stamps_timeline.py prints the milestones of a replay."""
+        if not self.eng.stamps:
+            return None
+        slot = len(self.stamp_names)
+        self.stamp_names.append(name)
+        buf = self.eng.buf("debug.stamps", (256,), torch.int64)
+        lib = self.lib
+
+        def call():
+            lib.mmvae_debug_stamp(buf.data_ptr(), slot, _s())
+
+        return call
+
+    def _mark(self, name: str):
+        c = self._mark_call(name)
+        if c is not None:
+            self._cur.append(c)
+
     def _probed(self, tag, work, call, **meta):
         """Measurement hook (bench.py's roofline leg): in an EAGER run with plan.probe set, `call` is bracketed by a
         timing event pair on the stream it launches on (e0 -> e1; e1 -> e2 is an empty pair: what one event marker costs
