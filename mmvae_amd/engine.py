@@ -819,9 +819,10 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
                 self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True,
                           planes=dw_pl)
             self._probe_next = None
+            self._mark("decoder dX done")
             if early_branch:  # behind the weight gradient on its stream: one branch, in order (probe: DESIGN.md 5)
                 self._fork()  # (the weight gradient may have stayed on the main stream)
-                self._branch(eng.side_stream, early_calls)
+                self._branch(eng.side_stream, early_calls + [c for c in [self._mark_call("decoder dW + loss words done (branch)")] if c])
         elif (eng.side_dw_dp and eng.overlap and eng.side_stream is not None and train and K == 1 and not self.has_adv
               and big and (measured or eng.side_dw_any) and self.cond is None
               and self._plan_gemm(TN, G, last.n_in, self.kpad(R)) == 1):
@@ -950,7 +951,7 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
                                      on_side=False, planes=dwp):
                 self.gemm(*dw, side=True, planes=dwp)
             self._probe_next = None
-            self._branch(eng.side_stream, calls)
+            self._branch(eng.side_stream, calls + [c for c in [self._mark_call("VAE optimiser done (branch)")] if c])
         elif dw is not None:
             dwp = getattr(self, "_deferred_dw_planes", None)
             self._probe_next = "enc_l1_dw" if big else None
