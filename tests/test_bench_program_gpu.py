@@ -95,8 +95,8 @@ def test_bench_program_matches_oracle(config):
     model._engine.close()
 
 
-def _run_c2(steps, env, attach=False, keep_engine=False):
-    """`steps` training steps of the C2 model under `env`; returns the final parameters and whether the plan forked
+def _run_c2(steps, env, attach=False, keep_engine=False, config="c2"):
+    """`steps` training steps of the C2 (or `config`) model under `env`; returns the final parameters and whether the plan forked
     (attach: gradients exchanged over the initialised process group; keep_engine: + the engine's dp_tuned record)."""
     import bench
     from mmvae_amd import synthetic
@@ -104,8 +104,8 @@ def _run_c2(steps, env, attach=False, keep_engine=False):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
-        a = argparse.Namespace(config="c2", genes="", no_engine=False)
-        cfg = dict(synthetic.CONFIGS["c2"])
+        a = argparse.Namespace(config=config, genes="", no_engine=False)
+        cfg = dict(synthetic.CONFIGS[config])
         device = torch.device("cuda", 0)
         model = bench.build_model(a, cfg, device).to(device)
         model.train()
@@ -155,6 +155,23 @@ def test_forked_program_is_bit_identical_to_the_single_stream_one():
         torch.cuda.empty_cache()
         got, f = _run_c2(8, env)
         assert f == (env.get("MMVAE_SIDE_DW") != "0")
+        bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+        assert not bad, f"{env}: {len(bad)} tensors differ, e.g. {bad[:3]}"
+
+
+def test_adversarial_program_branches_are_bit_identical():
+    """C4: the fused adversary passes on the branch stream and the decoder's weight gradient on a second branch (default,
+    MMVAE_ADV_ASIDE=2) against the passes alone on the branch (=1) and everything in order (=0): identical parameters
+    after 4 steps -- a branch that read a buffer too early or too late would show here."""
+    import gc
+
+    ref, forked = _run_c2(4, {}, config="c4")
+    assert forked, "the C4 program forks by default"
+    assert all(bool(torch.isfinite(v).all()) for v in ref.values() if v.is_floating_point())
+    for env in ({"MMVAE_ADV_ASIDE": "1"}, {"MMVAE_ADV_ASIDE": "0"}):
+        gc.collect()
+        torch.cuda.empty_cache()
+        got, _ = _run_c2(4, env, config="c4")
         bad = [k for k in ref if not torch.equal(ref[k], got[k])]
         assert not bad, f"{env}: {len(bad)} tensors differ, e.g. {bad[:3]}"
 
