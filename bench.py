@@ -410,6 +410,12 @@ def main():
     # one event behind every timed step (recorded on the launch stream, read after the run): per-step durations for the
     # median beside the mean -- the events cost ~1 us each and no synchronisation
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)] if on_gpu else []
+    prof = None
+    if os.environ.get("MMVAE_HOST_PROFILE") == "1":  # diagnostics: where the host spends a step (not a measurement run)
+        import cProfile
+
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     if marks:
         marks[0].record()
@@ -417,8 +423,14 @@ def main():
         step(n_setup + a.warmup + i)
         if marks:
             marks[i + 1].record()
+    if prof is not None:
+        import pstats
+
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(28)
     if a.mode == "train" and hasattr(model, "_flush_engine"):
-        model._flush_engine()  # the last step's deferred expert update belongs to the timed work (engine.defer_tail)
+        model._flush_engine()  # the last step's deferred expert update belongs to the timed work
+    host_el = time.perf_counter() - t0  # the host's share: enqueueing the K steps (a step time close to it is host-bound)
     sync()
     el = time.perf_counter() - t0
     if os.environ.get("MMVAE_STAMPS") == "1" and getattr(model, "_engine", None):
@@ -495,7 +507,8 @@ def main():
             "metric": {"train": "cells/sec per MMVAE train step", "validate": "cells/sec per MMVAE validation step",
                        "predict": "cells/sec per MMVAE predict step (latent embeddings)"}[a.mode], "value": cells_per_s, "unit": "cells/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
-            "ms_per_step_median": per_step[len(per_step) // 2] if per_step else None, "higher_is_better": True,
+            "ms_per_step_median": per_step[len(per_step) // 2] if per_step else None,
+            "host_ms_per_step": host_el / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if a.input != "npz" else "synthetic, streamed from npz-CSR / pkl chunk files",
             "config": {"workload": f"{a.config}: {len(eids)}-modality MMVAE train step, {G} genes each, latent 128, "
                                    f"K={K}, batch {B}/GPU, adversarial={cfg['adversarial']}"

@@ -86,6 +86,43 @@ class EngineSettings:
 FORK_VALIDATED_RUNTIMES = ("7.0.",)
 
 
+def concurrent_streams(device, n: int, pool: int = 12) -> list:
+    """Up to `n` new streams whose work was observed to run BESIDE the current stream's.  HIP maps streams onto a few
+    hardware queues, and two streams on one queue run one after the other.  The current stream runs two 0.2 ms spin
+    kernels with an event between them; the candidate waits for that event and runs a short spin: timed on the candidate
+    itself it is done after ~0.2 ms when it runs beside the second spin, after ~0.4 ms when it queues behind it."""
+    main = torch.cuda.current_stream(device)
+    spin = 400_000
+    out = []
+    for _ in range(pool):
+        c = torch.cuda.Stream(device=device)
+        torch.cuda.synchronize(device)
+        t0, t1, m0, m1 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(c):
+            t0.record()
+        m0.record(main)
+        torch.cuda._sleep(spin)
+        ev.record(main)
+        torch.cuda._sleep(spin)
+        m1.record(main)
+        with torch.cuda.stream(c):
+            c.wait_event(ev)
+            torch.cuda._sleep(2_000)
+            t1.record()
+        torch.cuda.synchronize(device)
+        side_us, both_us = t0.elapsed_time(t1) * 1e3, m0.elapsed_time(m1) * 1e3
+        if os.environ.get("MMVAE_DEBUG_STREAMS"):
+            import sys
+
+            print(f"stream {c.cuda_stream:#x}: done after {side_us:.0f} us; the two spins {both_us:.0f} us", file=sys.stderr)
+        if side_us < 0.8 * both_us:
+            out.append(c)
+            if len(out) == n:
+                break
+    return out
+
+
 def forks_allowed(settings: "EngineSettings", runtime: Optional[str] = None) -> bool:
     """May captured programs fork onto branch streams on this HIP runtime?"""
     v = (torch.version.hip or "") if runtime is None else runtime
@@ -182,7 +219,7 @@ class StepEngine:
         # adversarial programs: the first branch stream carries the adversaries' passes from the reparameterisation into
         # the backward chain, the decoder's capped weight gradient takes a second one
         self.side_stream2 = torch.cuda.Stream(device=self.device) if (self.side_dw and st.adv_aside >= 2 and st.adv_fused) else None
-        self.comm_stream = self.small_stream = None
+        self.comm_stream = self.small_stream = self.lane_stream = None
         self._configure_parallel()
         self._sig = self._signature()
         self._pending: Dict[str, torch.cuda.Event] = {}
@@ -231,8 +268,13 @@ class StepEngine:
                 if tune and self._tune is None:
                     self._tune = dict(phase="warm", kind="dynamic", steady=0, count=0, ev=None)
         if self.overlap and self.comm_stream is None:
-            self.comm_stream = torch.cuda.Stream(device=self.device)
-            self.small_stream = torch.cuda.Stream(device=self.device)
+            # streams of the exchange program: HIP maps streams onto a few hardware queues (4 by default), and two streams
+            # on one queue run one after the other -- a lane on a stream that shares the main stream's queue started when
+            # the main stream's segment ended (untraced markers), on another stream 400 us earlier.  Take streams that
+            # were SEEN to run beside the current stream.
+            got = concurrent_streams(self.device, 3)
+            self.comm_stream, self.small_stream, self.lane_stream = (got + [torch.cuda.Stream(device=self.device)
+                                                                            for _ in range(3)])[:3]
 
     def _signature(self) -> tuple:
         """Everything a captured training program freezes at build time: optimiser hyper-parameters, clip values, the
@@ -664,8 +706,29 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             hidden.append(self.z)  # first sample (rows 0..B-1)
         self.adv_grad_into: Dict[int, torch.Tensor] = {}
         adv_calls, adv_aside = None, False
-        # (under a gradient exchange the adversaries' optimisers cut the program: built in place, further down)
+        # Under a gradient exchange the adversaries' optimisers cut the program (an all-reduce of each adversary's gradients
+        # in both phases).  Their whole section -- captured segments and exchange points -- then runs as a LANE of its own
+        # on the branch stream, started by the host at this point of the program and joined where the chain reads the
+        # reversed gradients (PlanRun._run_program): its launches and the latency of its four small all-reduces leave the
+        # main stream.  (C4 on one rank with the slice of a world of 8: 1.33 -> see DESIGN section 8.)
         adv_dp = eng.overlap or any(o.reducer is not None for o in self.opt_adv)
+        adv_lane = False
+        if (self.has_adv and train and eng.adv_fused and adv_dp and eng.settings.adv_aside and eng.lane_stream is not None
+                and K == 1 and self.cond is None):
+            main_segments, main_cur = self.segments, self._cur
+            self.segments, self._cur = [], []
+            slot_before = dict(self.metric_slots)
+            self._mark("adversaries' lane: first launch")
+            built = self._build_adversaries_fused(hidden)
+            self._mark("adversaries' lane: done")
+            if built:
+                lane = [it for it in self.segments + [self._cur] if isinstance(it, tuple) or it]
+                self.segments, self._cur = main_segments, main_cur
+                self._host_marker(("lane", eng.lane_stream, lane))
+                adv_lane = True
+            else:
+                self.segments, self._cur = main_segments, main_cur
+                self.metric_slots = slot_before
         if self.has_adv and train and eng.adv_fused and not adv_dp:
             start = len(self._cur)
             if self._build_adversaries_fused(hidden):
@@ -760,6 +823,8 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
         self.dz_lat = eng.buf("dz_lat", (R, Z))
         if not self.has_adv:
             self.metric_slots["total_loss"] = 0
+        elif adv_lane:
+            pass  # (joined below, where the chain first reads the reversed gradients)
         elif adv_calls is None and eng.adv_fused and adv_dp and self._build_adversaries_fused(hidden):
             self._emit(lib.mmvae_axpby, 1, 1.0, _p(self.metrics), 1.0, self.mptr("total_loss"))
         elif adv_calls is None:  # per-layer program: the slot starts as the ELBO loss, every generator phase adds to it
@@ -858,6 +923,11 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
                            _p(self.cond.opt.arena.grad))
         if not rest:
             raise _lib.HipLibraryError("engine: decoder needs at least two layers")
+        if adv_lane:
+            self._mark("chain reaches the adversaries' join")
+            self._host_marker(("lane_join", eng.lane_stream))
+            self._mark("adversaries joined")
+            self._emit(lib.mmvae_axpby, 1, 1.0, _p(self.metrics), 1.0, self.mptr("total_loss"))
         if adv_aside:  # the adversaries' branch: its reversed gradients are read from here on
             self._mark("chain reaches the adversaries' join")
             self._join(only=eng.side_stream)

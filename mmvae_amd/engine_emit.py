@@ -76,6 +76,15 @@ class PlanEmit:
         self.segments.append(marker)
         self._cur = []
 
+    def _host_marker(self, marker):
+        """Cut the program here; `marker` -- ("lane", stream, items) or ("lane_join", stream) -- is acted on by the host
+        between two captured segments (PlanRun._run_program)."""
+        self._join()  # a captured segment may not end with work outstanding on a branch
+        if self._cur:
+            self.segments.append(self._cur)
+            self._cur = []
+        self.segments.append(marker)
+
     def slot(self, name: str) -> int:
         if name not in self.metric_slots:
             self.metric_slots[name] = 8 + sum(1 for v in self.metric_slots.values() if 8 <= v < 192)

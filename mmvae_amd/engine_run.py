@@ -88,14 +88,38 @@ class PlanRun:
 
     def _run_program(self, items, launch):
         tail = None  # once set, the rest of the program (the deferred update) runs on the communication stream
+        lane = None  # a lane whose fork point has been recorded and whose items are not enqueued yet
+
+        def enqueue_lane():
+            nonlocal lane
+            if lane is not None:
+                with torch.cuda.stream(lane[1]):
+                    self._run_program(lane[2], launch)
+                lane = None
+
         for idx, it in enumerate(items):
-            if isinstance(it, tuple):
+            if isinstance(it, tuple) and it[0] == "lane":
+                # A section of the program (segments + exchange points) as a lane of its own on a branch stream, ordered
+                # behind everything enqueued so far on the main stream.  Its items are enqueued BEHIND the main stream's
+                # next segment: the exchange programs run with the host only just ahead of the GPU (a dozen replays and
+                # eight collectives per step), and a main stream left empty while the host enqueues the lane's ~0.4 ms
+                # of launches stalls for exactly that long (untraced markers: reconstruction done 518 us behind the
+                # fork point instead of 144).
+                enqueue_lane()
+                it[1].wait_stream(torch.cuda.current_stream())
+                lane = it
+            elif isinstance(it, tuple) and it[0] == "lane_join":
+                enqueue_lane()
+                torch.cuda.current_stream().wait_stream(it[1])
+            elif isinstance(it, tuple):
                 tail = self._exchange(it, tail)
             elif tail is None:
                 launch(it)
+                enqueue_lane()
             else:
                 with torch.cuda.stream(tail):
                     launch(it)
+        enqueue_lane()
         if tail is None:
             return None
         with torch.cuda.stream(tail):
@@ -109,9 +133,14 @@ class PlanRun:
         cyclic collector would free).  A graph with forked branches owns runtime-internal streams, and a process that
         piled up dozens of such executables (a test session; plans rebuilt after every settings change) crashed inside
         hipGraphLaunch on some boxes.  The caller has synchronised the device."""
-        for g in self._graphs or []:
-            if not isinstance(g, tuple):
-                g.reset()
+        def reset(items):
+            for g in items:
+                if not isinstance(g, tuple):
+                    g.reset()
+                elif g[0] == "lane":
+                    reset(g[2])
+
+        reset(self._graphs or [])
         self._graphs = None
         self.segments = []
         self._cur = []
@@ -130,20 +159,26 @@ class PlanRun:
             return self._run_program(self.segments, self._launch_eager)
         if self._graphs is None:
             torch.cuda.synchronize()
-            graphs = []
-            for seg in self.segments:
-                if isinstance(seg, tuple):
-                    graphs.append(seg)
-                    continue
-                if not seg:  # (nothing between two exchange points)
-                    continue
-                g = torch.cuda.CUDAGraph()
-                # thread-local capture mode: a process group's watchdog thread may touch its events meanwhile
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    for call in seg:
-                        call()
-                graphs.append(g)
-            self._graphs = graphs
+            def capture(segments):
+                graphs = []
+                for seg in segments:
+                    if isinstance(seg, tuple) and seg[0] == "lane":
+                        graphs.append(("lane", seg[1], capture(seg[2])))
+                        continue
+                    if isinstance(seg, tuple):
+                        graphs.append(seg)
+                        continue
+                    if not seg:  # (nothing between two exchange points)
+                        continue
+                    g = torch.cuda.CUDAGraph()
+                    # thread-local capture mode: a process group's watchdog thread may touch its events meanwhile
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        for call in seg:
+                            call()
+                    graphs.append(g)
+                return graphs
+
+            self._graphs = capture(self.segments)
         return self._run_program(self._graphs, lambda g: g.replay())
 
     def log(self, model, eid: str):

@@ -176,6 +176,21 @@ def test_adversarial_program_branches_are_bit_identical():
         assert not bad, f"{env}: {len(bad)} tensors differ, e.g. {bad[:3]}"
 
 
+def test_exchange_program_with_the_adversaries_lane_is_bit_identical():
+    """C4 under the exchange program (MMVAE_DP_OVERLAP=1 on one rank: the program data parallelism runs, without the
+    transfers): the adversaries' section -- captured segments and exchange points -- as a lane on the branch stream
+    against the same program in order (MMVAE_ADV_ASIDE=0): identical parameters after 4 steps."""
+    import gc
+
+    ref, _ = _run_c2(4, {"MMVAE_DP_OVERLAP": "1", "MMVAE_ADV_ASIDE": "0"}, config="c4")
+    assert all(bool(torch.isfinite(v).all()) for v in ref.values() if v.is_floating_point())
+    gc.collect()
+    torch.cuda.empty_cache()
+    got, _ = _run_c2(4, {"MMVAE_DP_OVERLAP": "1"}, config="c4")
+    bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+    assert not bad, f"{len(bad)} tensors differ, e.g. {bad[:3]}"
+
+
 def test_exchange_program_with_its_side_branch_is_bit_identical():
     """The overlapped exchange program on one rank (MMVAE_DP_OVERLAP=1: the program data parallelism runs, without the
     transfers) with the decoder's weight gradient on its capped side branch (MMVAE_SIDE_DW_DP) against the same program
