@@ -208,12 +208,20 @@ def test_exchange_program_with_its_side_branch_is_bit_identical():
     assert not bad, f"{len(bad)} tensors differ, e.g. {bad[:3]}"
 
 
-def test_sharded_exchange_program_on_one_rank_with_rccl(monkeypatch):
+def test_sharded_exchange_program_on_one_rank_with_rccl():
     """The data-parallel program as N > 1 runs it, on one rank with a real RCCL communicator: reduce-scatter of the
     expert's gradient arena, clip + Adam on this rank's slice (= the whole arena), all-gather of the parameters -- against
     the all-reduce + full update (MMVAE_DP_SHARD=0): parameters to 2e-6 after 3 steps (the norm is summed in another
     order; the GEMMs are the same kernels).  Then the engine's autotuner: both GEMM kernel families timed, one kept (the
-    families tile and split K differently -- each is held to fp64 by the kernel tests, not to the other)."""
+    families tile and split K differently -- each is held to fp64 by the kernel tests, not to the other).  In a child
+    process (tests.helpers.run_in_child)."""
+    from tests.helpers import run_in_child
+
+    run_in_child("tests.test_bench_program_gpu", "_body_sharded_exchange_program",
+                 {"MMVAE_SINGLE_RANK_COLLECTIVES": "1", "MASTER_PORT": "29617", "MASTER_ADDR": "127.0.0.1"})
+
+
+def _body_sharded_exchange_program():
     import gc
 
     import torch.distributed as td
@@ -221,8 +229,6 @@ def test_sharded_exchange_program_on_one_rank_with_rccl(monkeypatch):
     from mmvae_amd import dist as mdist
     from tests.helpers import rel_l2
 
-    monkeypatch.setenv("MMVAE_SINGLE_RANK_COLLECTIVES", "1")
-    monkeypatch.setenv("MASTER_PORT", "29617")
     mdist.init_from_env()
     try:
         assert mdist.collectives_active()
@@ -241,6 +247,7 @@ def test_sharded_exchange_program_on_one_rank_with_rccl(monkeypatch):
         assert worst <= 2e-6, worst
         tuned = runs["auto"][2]
         assert tuned.get("choice") in ("dynamic", "persistent") and tuned["dynamic"] > 0 and tuned["persistent"] > 0, tuned
+        print("CHILD_CASE_OK", flush=True)
     finally:
         torch.cuda.synchronize()
         td.destroy_process_group()

@@ -40,15 +40,20 @@ def test_engine_overlapped_exchange_program_matches_reference(name, monkeypatch)
     MU.check_against_golden(case, z, results)
 
 
-def test_engine_overlapped_exchange_with_single_rank_rccl(monkeypatch):
+def test_engine_overlapped_exchange_with_single_rank_rccl():
     """Same program with a real process group (RCCL, one rank): every collective is issued, on both communicators,
-    beside the graph replays."""
+    beside the graph replays.  In a child process (tests.helpers.run_in_child)."""
+    from tests.helpers import run_in_child
+
+    run_in_child("tests.test_step_gpu", "_body_single_rank_rccl",
+                 {"MMVAE_SINGLE_RANK_COLLECTIVES": "1", "MASTER_PORT": "29611", "MASTER_ADDR": "127.0.0.1"})
+
+
+def _body_single_rank_rccl():
     import torch.distributed as td
 
     from mmvae_amd import dist as mdist
 
-    monkeypatch.setenv("MMVAE_SINGLE_RANK_COLLECTIVES", "1")
-    monkeypatch.setenv("MASTER_PORT", "29611")
     mdist.init_from_env()
     try:
         assert mdist.collectives_active()
@@ -62,6 +67,7 @@ def test_engine_overlapped_exchange_with_single_rank_rccl(monkeypatch):
         for name in ("two_mod_odd", "adversarial"):
             case, z, results = MU.replay_training(name, "cuda", use_engine=True, prepare=prepare)
             MU.check_against_golden(case, z, results)
+        print("CHILD_CASE_OK", flush=True)
     finally:
         torch.cuda.synchronize()
         td.destroy_process_group()
