@@ -101,9 +101,12 @@ class PlanAdversaries:
         for phase, gen in (("discriminator", False), ("generator", True)):
             self._cur.append(lambda ph=phase: prog.launch_pass(ph))
             self._cur.append(lambda ph=phase: prog.launch_dw(ph))
+            if dp:  # ONE exchange point per phase: every adversary's gradient arena, then their optimisers' launches
+                self._flush_sums()
+                self._cut(("ar_many", [net.opt for net in nets]))
             for i, net in enumerate(nets, start=1):
                 if dp:
-                    self.optimizer(net.opt, 0.0 if gen else self.clip_adv, step=not gen)
+                    self.optimizer(net.opt, 0.0 if gen else self.clip_adv, step=not gen, exchange="done")
                     self.log_norm(net.opt, f"grad_norms/{phase}_{i}", final=gen)
                 elif gen:
                     self.log_norm(net.opt, f"grad_norms/generator_{i}")

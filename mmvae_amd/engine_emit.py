@@ -589,7 +589,7 @@ class PlanEmit:
                                                        and opt.reducer is not None) else None
         if sh is not None:
             return self._optimizer_sharded(opt, sh, max_norm, advance, step, exchange)
-        if opt.reducer is not None or self.eng.overlap:
+        if (opt.reducer is not None or self.eng.overlap) and exchange != "done":  # ("done": the caller has cut already)
             self._cut(("ar_" + exchange, opt))
         if self.cond is not None and opt is self.opt_vae:
             # only the tensors that took part: the dense parameters + the condition blocks present in the batch, from

@@ -28,6 +28,11 @@ class PlanRun:
         """One data-parallel exchange point between two captured segments.  Returns the stream the rest of the
         program runs on (None = stay on the main stream)."""
         kind, opt = marker
+        if kind == "ar_many":  # several small arenas at one exchange point (the adversaries of a phase)
+            for o in opt:
+                if o.reducer is not None:
+                    o.reducer.reduce_here(o.arena.grad, small=True)
+            return tail
         red = opt.reducer
         eng = self.eng
         main = torch.cuda.current_stream()
