@@ -61,6 +61,7 @@ class EngineSettings:
     dp_kernels: str = "auto"     # MMVAE_DP_KERNELS: dynamic | persistent | auto (timed on the first multi-rank steps)
     dp_sim_world: int = 0        # MMVAE_DP_SIM_WORLD: timing diagnostics (bench.py --sim-world)
     dp_autotune_force: bool = False  # MMVAE_DP_AUTOTUNE_FORCE=1: run the kernel-family timing on one rank too (tests)
+    stamps: bool = False         # MMVAE_STAMPS=1: marker launches inside the captured programs (untraced timelines; bench.py prints them)
 
     @staticmethod
     def from_env() -> "EngineSettings":
@@ -76,7 +77,8 @@ class EngineSettings:
             side_dw_any=e("MMVAE_SIDE_DW_ANY", "0") != "0", adv_fused=e("MMVAE_ADV_FUSED", "1") != "0",
             adv_aside=int(e("MMVAE_ADV_ASIDE", "2")),
             dp_overlap=None if ov == "" else ov != "0", dp_shard=e("MMVAE_DP_SHARD", "1") != "0", dp_kernels=kernels,
-            dp_sim_world=int(e("MMVAE_DP_SIM_WORLD", "0")), dp_autotune_force=e("MMVAE_DP_AUTOTUNE_FORCE", "0") != "0")
+            dp_sim_world=int(e("MMVAE_DP_SIM_WORLD", "0")), dp_autotune_force=e("MMVAE_DP_AUTOTUNE_FORCE", "0") != "0",
+            stamps=e("MMVAE_STAMPS", "0") == "1")
 
 
 # HIP runtimes (prefixes of torch.version.hip) on which the multi-stream captured programs have been validated: > 10^4
@@ -112,10 +114,6 @@ def concurrent_streams(device, n: int, pool: int = 12) -> list:
             t1.record()
         torch.cuda.synchronize(device)
         side_us, both_us = t0.elapsed_time(t1) * 1e3, m0.elapsed_time(m1) * 1e3
-        if os.environ.get("MMVAE_DEBUG_STREAMS"):
-            import sys
-
-            print(f"stream {c.cuda_stream:#x}: done after {side_us:.0f} us; the two spins {both_us:.0f} us", file=sys.stderr)
         if side_us < 0.8 * both_us:
             out.append(c)
             if len(out) == n:
@@ -183,7 +181,7 @@ class StepEngine:
                     opt.state_dev = view
                 self._state_slot[id(opt)] = 192 + 8 * i
         self._ptr_seen: Dict[tuple, int] = {}
-        self.stamps = os.environ.get("MMVAE_STAMPS", "0") == "1"  # diagnostics: milestone markers inside the programs
+        self.stamps = self.settings.stamps  # diagnostics: milestone markers inside the programs
         self.eager_only = False  # measurement hook (bench.py's roofline leg): run the programs eagerly, not from their graphs
         self.klw_dev = torch.ones(1, dtype=torch.float32, device=self.device)
         self._klw_host = None
