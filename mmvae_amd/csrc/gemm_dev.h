@@ -197,7 +197,7 @@ __device__ __forceinline__ void x3_pack4_lean(f32x2 lo, f32x2 hi, uint2 (&pk)[3]
 template <int BM, int BN, int WGM, int WGN, int EPI, int TM, int TN, bool MF16 = false>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& g, int bm, int bn, int z,
                                               float* lds) {
-    static_assert(!MF16 || EPI == EPI_STD, "the 16x16 accumulator layout has the standard epilogue only");
+    static_assert(!MF16 || EPI == EPI_STD || EPI == EPI_RECON, "16x16 accumulator layout: standard and reconstruction epilogues");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -315,7 +315,112 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
     } else {
         // bias + ReLU + squared error + dP; per-cell SE reduced over the 32 lanes that share a row.
         float* rowsum = lds;  // [WGN][BM] scratch: the operand tiles are dead after the final barrier
-        if (g.c_vec) {
+        if constexpr (MF16) {
+            // 16x16x32 accumulators (16-byte path only: the launcher of the fused kernel sets c_vec).  Registers
+            // 4 gq .. 4 gq + 3 of a 32x32 block are sub-block (si, sj) = (gq >> 1, gq & 1): rows 16 si + 4 (lane >> 4) + j,
+            // column 16 sj + (lane & 15); after the quad transpose a lane holds row 16 si + 4 (lane >> 4) + q and the four
+            // columns 16 sj + (lane & 12) .. + 3.  Column groups outermost (one bias vector and one column-sum vector
+            // live at a time), the per-row squared errors of the wave's 2 TM row groups in 2 TM scalars.
+            const int q = lane & 3, lg = lane >> 4, c12 = lane & 12;
+            const bool odd = q & 1, hi = q & 2;
+            float sr[TM][2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) sr[i][0] = sr[i][1] = 0.f;
+            float* colbuf = lds + WGN * BM;  // [WGM][BN], behind the row sums
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+#pragma unroll
+                for (int sj = 0; sj < 2; ++sj) {
+                    const int cloc = wn * WTN + n * 32 + 16 * sj + c12;
+                    const int col = bn * BN + cloc;
+                    f32x4 bn4 = {0.f, 0.f, 0.f, 0.f};
+                    if (g.bias && col < g.N) {
+                        if (col + 3 < g.N) {
+                            bn4 = *reinterpret_cast<const f32x4*>(g.bias + col);
+                        } else {
+                            for (int j = 0; j < g.N - col; ++j) bn4[j] = g.bias[col + j];
+                        }
+                    }
+                    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                        for (int si = 0; si < 2; ++si) {
+                            const int gq = 2 * si + sj;
+                            const float a0 = acc[i][n][4 * gq], a1 = acc[i][n][4 * gq + 1], a2 = acc[i][n][4 * gq + 2],
+                                        a3 = acc[i][n][4 * gq + 3];
+                            const float r0 = quad_perm<1, 0, 3, 2>(odd ? a0 : a1), r1 = quad_perm<1, 0, 3, 2>(odd ? a2 : a3);
+                            const float c0 = odd ? r0 : a0, c1 = odd ? a1 : r0, c2 = odd ? r1 : a2, c3 = odd ? a3 : r1;
+                            const float t0 = quad_perm<2, 3, 0, 1>(hi ? c0 : c2), t1 = quad_perm<2, 3, 0, 1>(hi ? c1 : c3);
+                            f32x4 p;
+                            p[0] = hi ? t0 : c0;
+                            p[1] = hi ? t1 : c1;
+                            p[2] = hi ? c2 : t0;
+                            p[3] = hi ? c3 : t1;
+                            const int row = bm * BM + wm * WTM + i * 32 + 16 * si + 4 * lg + q;
+                            const int xr = row % g.x_rows;
+                            if (row < g.M && col + 3 < g.N) {
+                                p += bn4;
+                                const f32x4 xv = *reinterpret_cast<const f32x4*>(g.x + (int64_t)xr * g.ldx + col);
+                                f32x4 xh, dp;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    xh[j] = fmaxf(p[j], 0.f);
+                                    const float d = xh[j] - xv[j];
+                                    sr[i][si] += d * d;
+                                    dp[j] = (p[j] > 0.f) ? 2.f * d : 0.f;
+                                }
+                                if (g.xhat) *reinterpret_cast<f32x4*>(g.xhat + (int64_t)row * g.ldxhat + col) = xh;
+                                if (g.dP) *reinterpret_cast<f32x4*>(g.dP + (int64_t)row * g.lddp + col) = dp;
+                                if (g.dPp) {
+                                    uint2 pk[3];
+                                    x3_pack4_lean(f32x2{dp[0], dp[1]}, f32x2{dp[2], dp[3]}, pk);
+                                    unsigned short* pp = g.dPp + (int64_t)row * g.lddpp + col;
+#pragma unroll
+                                    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(pp + pl * g.dp_pstride) = pk[pl];
+                                }
+                                csum += dp;
+                            } else if (row < g.M && col < g.N) {  // G % 4 != 0: the group straddling the edge
+                                p += bn4;
+                                for (int j = 0; j < g.N - col; ++j) {
+                                    const float xhj = fmaxf(p[j], 0.f);
+                                    const float d = xhj - g.x[(int64_t)xr * g.ldx + col + j];
+                                    sr[i][si] += d * d;
+                                    const float dpj = (p[j] > 0.f) ? 2.f * d : 0.f;
+                                    if (g.xhat) g.xhat[(int64_t)row * g.ldxhat + col + j] = xhj;
+                                    if (g.dP) g.dP[(int64_t)row * g.lddp + col + j] = dpj;
+                                    csum[j] += dpj;
+                                }
+                            }
+                        }
+                    }
+                    if (g.col_part) {  // the 16 lanes that share this column group (q, lane >> 4) -> one, per wave
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float v = csum[j];
+                            v += __shfl_xor(v, 1, 64);
+                            v += __shfl_xor(v, 2, 64);
+                            v += __shfl_xor(v, 16, 64);
+                            v += __shfl_xor(v, 32, 64);
+                            csum[j] = v;
+                        }
+                        if (q == 0 && lg == 0) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) colbuf[wm * BN + cloc + j] = csum[j];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int si = 0; si < 2; ++si) {
+                    float v = sr[i][si];  // the 4 lanes of a row (lane & 12) -> one
+                    v += __shfl_xor(v, 4, 64);
+                    v += __shfl_xor(v, 8, 64);
+                    if (c12 == 0) rowsum[wn * BM + wm * WTM + i * 32 + 16 * si + 4 * lg + q] = v;
+                }
+        } else if (g.c_vec) {
             // 16-byte path (x, xhat, dP 16-byte regular): quad transpose as in the standard epilogue, so that x is
             // read and xhat / dP are written as one row x 4 genes per lane; the row's SE is then the sum over the 8
             // lanes of a half that share q = lane & 3 (strides 4, 8, 16).
@@ -1166,7 +1271,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(const GemmArgs g) {
     // address the same 16 operand rows at k-rows 8 apart -- the same banks: 108 -> 128 us; trading the two 32-byte
     // halves of a slot in every other k-octet to separate them made it 320 us (profiles/r3_mfma16.txt).
     constexpr bool IS_TN = AFORM == FORM_RC && BFORM == FORM_RC;
-    constexpr bool MF16 = MMVAE_MFMA16 && MMVAE_XW_INTERLEAVE && EPI == EPI_STD && !IS_TN;
+    constexpr bool MF16 = MMVAE_MFMA16 && MMVAE_XW_INTERLEAVE && !IS_TN;  // (both epilogues know the 16x16 layout)
     static_assert(!MF16 || TK >= 2, "the in-place reload of the kept fragments needs two kept blocks");
     static_assert(2 * IMG + XW_SCRATCH <= 160 * 1024, "two images + scratch must fit the CU's LDS");
     __shared__ __attribute__((aligned(16))) char lds[2 * IMG + XW_SCRATCH];

@@ -1396,12 +1396,13 @@ static int decoder_recon_impl(int rows, int x_rows, int G, int H, const float* h
     g.aligned = h && aligned16(h) && aligned16(W) && (ldh % 4 == 0) && (ldw % 4 == 0);
     if (g.aligned && rows % 4 == 0 && G % 4 == 0 && H % 4 == 0) g.aligned = 2;
     g.x3_vec = 1;  // both operands K-contiguous: rows are clamped one by one, no edge groups
-    // (fp32 h: the 2 x 4-wave kernel keeps this launch: its two workgroups per CU overlap one's heavy epilogue -- 160 KB
-    // of x read, 160 KB of dP written per tile -- with the other's main loop, while the wave-specialised kernel's
-    // epilogue is done by 4 of its 8 waves with the stagers idle: 1.097 against 1.067 ms per C2 step, also after its
-    // spills were cut from 63 to 9 registers; MMVAE_X3W_RECON=1 to compare)
+    // The wave-specialised kernel, now that its multipliers run 16x16x32 MFMAs with a reconstruction epilogue for that
+    // accumulator layout (r4): C2 0.967 against 0.990 ms per step, C3 3.578 against 3.62 on one box.  On 32x32x16 MFMAs
+    // it lost to the 2 x 4-wave kernel, whose two workgroups per CU overlap one's heavy epilogue -- 160 KB of x read,
+    // 160 KB of dP written per tile -- with the other's main loop (r3: 1.097 against 1.067 ms).  MMVAE_X3W_RECON=0
+    // restores the 2 x 4-wave kernel (diagnostics).
     const char* e_recon = getenv("MMVAE_X3W_RECON");
-    const bool w_recon = e_recon && e_recon[0] == '1';
+    const bool w_recon = !(e_recon && e_recon[0] == '0');
     int tile_id = !x3 ? 1 : ((H % X3_BK == 0) ? (w_recon ? x3_tile_regular(rows, G, 1, false) : x3_tile_for(rows, G, false)) : 3);
     bool h_pl = false;
     if (hp) {
