@@ -104,7 +104,7 @@ HBM_PEAK_TBS = 8.0
 # of tools/roofline_kernel.py, one counter group per run, summarised by tools/pmc_summary.py).
 FAMILY = [
     ("enc_l1_fwd", "forward GEMM of the G-wide expert encoder layer (NT, split-K 16 raw slabs)", "gemm_x3w_kernel<0, 0, 256, 128"),
-    ("dec_l2_recon", "expert decoder's last layer + reconstruction loss epilogue (NT)", "gemm_x3_kernel<0, 0, 128, 160"),
+    ("dec_l2_recon", "expert decoder's last layer + reconstruction loss epilogue (NT)", "gemm_x3w_kernel<0, 0, 256, 160, 4, 1, 1"),
     ("dec_l2_dx", "input gradient of the decoder's last layer (NN, split-K 16 raw slabs)", "gemm_x3w_kernel<0, 1, 256, 128"),
     ("dec_l2_dw", "weight gradient of the decoder's last layer (TN)", "gemm_x3w_kernel<1, 1, 160, 256"),
     ("enc_l1_dw", "weight gradient of the encoder's first layer (TN)", "gemm_x3w_kernel<1, 1, 256, 160"),
