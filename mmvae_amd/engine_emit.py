@@ -5,6 +5,7 @@ sharded under data parallelism)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -215,9 +216,10 @@ class PlanEmit:
         job = _lib.GemmJob(_p(A), _p(Bm), _p(Cm), _p(bias), lda, ldb, ldc, layout, M, N, K, float(alpha), int(flags), 0, 0)
         if not self.lib.mmvae_gemm_batch_job_ok(C.addressof(job)):
             return False
-        if layout == TN and K >= 2048 and bias is None and not (flags & ~ACC):
-            # K x B sample rows (K-sample programs: 5120): a grouped job runs its whole K in one workgroup per 64 x 64
-            # tile -- 160 k-tiles one after the other, 161 us at C3 for 2.5 GFLOP.  Slices of 512 rows as jobs of their
+        if layout == TN and K >= 1024 and bias is None and not (flags & ~ACC):
+            # K x B sample rows (K-sample programs: 5120; batches of 1024 cells): a grouped job runs its whole K in one
+            # workgroup per 64 x 64 tile -- 160 k-tiles one after the other, 161 us at C3 for 2.5 GFLOP (C5's encoder side
+            # at 1024 rows: 5.355 -> 5.326 ms).  Slices of 512 rows as jobs of their
             # own into slabs, summed by the deferred reduction that runs behind the grouped launch anyway.
             n_sl = (K + 511) // 512
             slabs = self.eng.buf(f"dwslabs.{self._next_defer_id()}", (n_sl, M, N))
