@@ -5,7 +5,6 @@ sharded under data parallelism)."""
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import Optional
 
 import torch
