@@ -19,6 +19,14 @@ cases = {
     "k3 NT [512x20000x1024] 256x160": (lambda: ops.gemm(ops.GEMM_NT, r(B, H), r(G, H), splitk=1)),
     "k1 NT slabs [512x1024x20000] 256x128": (lambda: ops.gemm_slabs(ops.GEMM_NT, r(B, G), r(H, G))),
     "k4b NN slabs [512x1024x20000] 256x128": (lambda: ops.gemm_slabs(ops.GEMM_NN, r(B, G), r(G, H))),
+    "k5 NT + reconstruction epilogue [512x20000x1024] 256x160": (
+        lambda: ops.decoder_recon(torch.relu(r(B, H)), r(G, H) * 0.03, r(G) * 0.1, torch.relu(r(B, G)), want_xhat=False,
+                                  dP=torch.empty(B, G, device=dev),
+                                  se_part=torch.empty(ops.recon_tiles(G), B, device=dev))),
+    "k5b the same over 5120 rows (K-sample programs: 10 tiles per CU)": (
+        lambda: ops.decoder_recon(torch.relu(r(10 * B, H)), r(G, H) * 0.03, r(G) * 0.1, torch.relu(r(B, G)), want_xhat=False,
+                                  dP=torch.empty(10 * B, G, device=dev),
+                                  se_part=torch.empty(ops.recon_tiles(G), 10 * B, device=dev))),
 }
 for name, fn in cases.items():
     for _ in range(3):
