@@ -31,7 +31,7 @@ import torch
 from . import _lib, dist as mdist, rng
 from .constants import REGISTRY_KEYS as RK
 from .engine_adv import PlanAdversaries
-from .engine_common import ACC, NN, NT, TN, _LayerRef, _PlaneBuf, _p, _supported_block
+from .engine_common import ACC, NN, NT, SQ_FUSED_SLOTS, TN, _LayerRef, _PlaneBuf, _p, _supported_block
 from .engine_cond import CondProgram
 from .engine_emit import PlanEmit
 from .engine_run import PlanRun
@@ -385,7 +385,7 @@ class StepEngine:
     def sq_buffer(self, opt) -> torch.Tensor:
         """Norm-partial slots of one optimiser when GEMM epilogues contribute (fused partials first, then the norm
         pass's chunk partials of the uncovered ranges)."""
-        n = int(self.lib.mmvae_sqnorm_partials(opt.arena.numel)) + 4096 + 64
+        n = int(self.lib.mmvae_sqnorm_partials(opt.arena.numel)) + SQ_FUSED_SLOTS + 64
         return self.buf(f"sqparts.{id(opt)}", (n,))
 
     def close(self) -> None:

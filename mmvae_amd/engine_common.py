@@ -15,6 +15,13 @@ RELU = _lib.GEMM_RELU
 SLACK = _lib.GEMM_OPERAND_SLACK  # every operand the engine hands to a GEMM has 16 readable bytes behind it
 
 
+# Norm-partial slots the GEMM epilogues of one optimiser may fill (mmvae_gemm_f32_sq: one per output tile).  The planning
+# call counts the tiles of the element-guarded 128 x 128 kernel when an operand's rows are not 16-byte groups -- 3 784 for
+# one weight gradient at the reference's 60 530 genes, two per expert: 4 096 slots sent the second one (and the whole
+# gradient arena: a 93 us norm pass) back to the separate norm launch.
+SQ_FUSED_SLOTS = 8192
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 

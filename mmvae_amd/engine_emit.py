@@ -10,7 +10,7 @@ from typing import Optional
 import torch
 
 from . import _lib, dist as mdist
-from .engine_common import ACC, NN, NT, RAW, RELU, SLACK, TN, _LayerRef, _NOPL, _PlaneBuf, _p, _planes_desc, _s
+from .engine_common import ACC, NN, NT, RAW, RELU, SLACK, SQ_FUSED_SLOTS, TN, _LayerRef, _NOPL, _PlaneBuf, _p, _planes_desc, _s
 from .optim import HipAdam
 
 
@@ -128,7 +128,7 @@ class PlanEmit:
             return False
         buf = eng.sq_buffer(opt)
         base = self._sq_used.get(id(opt), 0)
-        if base + n_part > 4096:
+        if base + n_part > SQ_FUSED_SLOTS:
             return False
         self._sq_used[id(opt)] = base + n_part
         self._sq_cover.setdefault(id(opt), []).append((off, M * N))
