@@ -659,6 +659,7 @@ __global__ __launch_bounds__(256) void adam_step_multi_kernel(const mmvae_adam_a
 }
 
 inline int grid_for(int64_t n, int per_block, int cap);
+constexpr int STREAM_GRID_CAP = 1 << 22;  // long streaming passes: one workgroup per block of elements (see launch_adam_step)
 static int g_adam_workgroups = 0;  // 0: the chip-filling grid of 256-thread workgroups
 
 extern "C" int mmvae_adam_set_workgroups(int workgroups) {
@@ -682,7 +683,12 @@ static int launch_adam_step(int64_t n, hipStream_t stream, Args... args) {
         MMVAE_LAUNCH(adam_step_wide_kernel, dim3(g_adam_workgroups), dim3(1024), (size_t)ADAM_WIDE_LDS, stream, n,
                      args...);
     } else {
-        MMVAE_LAUNCH(adam_step_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, stream, n, args...);
+        // One workgroup per 1024 elements, no grid-stride loop: the hardware hands out workgroups in order, so the seven
+        // streams of the pass (p, g, m, v in; p, m, v out) move through memory as one narrow window.  With the grid capped
+        // at 4096 workgroups and a loop (r1-r3), the resident half of the grid and the half that waits for it drift apart
+        // over the iterations: 42 M parameters 176-183 us against 166 (7.1 TB/s), 124 M (the reference's 60 530 genes)
+        // 729 us against 578 (tools/debug/adam_bw.py); C2 step 0.980 -> 0.960 ms, 60 530 / 52 437 genes 2.49 -> 2.36.
+        MMVAE_LAUNCH(adam_step_kernel, dim3(grid_for(n, 1024, STREAM_GRID_CAP)), dim3(256), 0, stream, n, args...);
     }
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;
@@ -1447,7 +1453,7 @@ extern "C" int mmvae_csr_spmm_wt_i32_f32(int B, int N, int G, int64_t nnz, const
 extern "C" int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, float* y, mmvae_stream_t stream) {
     if (n <= 0 || !x || !y) return MMVAE_ERR_ARG;
     if (n % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
-        MMVAE_LAUNCH(axpby4_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, n / 4,
+        MMVAE_LAUNCH(axpby4_kernel, dim3(grid_for(n / 4, 256, STREAM_GRID_CAP)), dim3(256), 0, (hipStream_t)stream, n / 4,
                            alpha, reinterpret_cast<const float4*>(x), beta, reinterpret_cast<float4*>(y));
     else
         MMVAE_LAUNCH(axpby_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, n, alpha, x,
