@@ -449,16 +449,19 @@ int mmvae_gemm_f32_sq(int layout, int M, int N, int K, float alpha, const float*
  * Plane layout: planes[p][row][col], bf16 bit patterns, row-major like the fp32 matrix (`ld` and `plane_stride` in
  * bf16 elements, both multiples of 8; base 16-byte aligned; 3 * plane_stride * 2 < 4 GiB).  Rows the consumer reads
  * beyond the matrix (the zero slack rows of a weight-gradient GEMM whose K is padded to 32) must hold zeros.
+ * A column count that is not a multiple of 8 (r5: the reference's 60 530 / 52 437 genes, human_only.yaml:90): `ld` is
+ * at least the count rounded up to 8 and the columns in between hold zeros -- mmvae_split_planes_f32 writes them --
+ * because a rows-contiguous planes operand is fetched in whole 16-byte groups.
  *
  * mmvae_gemm_planes_f32 = mmvae_gemm_f32 (sq_partials == NULL) or mmvae_gemm_f32_sq (sq_partials != NULL) with
  * optional planes per operand.  Kernels exist for TN with both operands pre-split and for NT / NN with a pre-split A;
  * an operand whose planes cannot be used (other combinations, shapes off the wave-specialised kernel: K % 32 != 0,
- * rows-contiguous extent % 8 != 0, small outputs, MMVAE_GEMM_PRECISION_F32) is read from its fp32 form when that
+ * rows-contiguous leading dimension below the extent rounded up to 8, small outputs, MMVAE_GEMM_PRECISION_F32) is read from its fp32 form when that
  * pointer is non-NULL, otherwise the call fails with MMVAE_ERR_ARG.  Results are bit-identical to mmvae_gemm_f32 on
  * the fp32 operands (same products, same order).  mmvae_gemm_planes_supported: 1 when a launch of that shape with
  * those operands pre-split would read them from planes.
  * ------------------------------------------------------------------------------------------------------------ */
-int mmvae_split_planes_f32(int rows, int cols /* % 8 == 0 */, const float* src, int64_t ld_src, uint16_t* planes,
+int mmvae_split_planes_f32(int rows, int cols, const float* src, int64_t ld_src, uint16_t* planes,
                            int64_t ld, int64_t plane_stride, mmvae_stream_t stream);
 int mmvae_gemm_planes_f32(int layout, int M, int N, int K, float alpha, const float* A, int64_t lda, const uint16_t* Ap,
                           int64_t ldap, int64_t a_plane_stride, const float* B, int64_t ldb, const uint16_t* Bp,

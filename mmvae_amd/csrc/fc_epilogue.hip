@@ -50,7 +50,7 @@ struct FwdArgs {
     const float* sp_src;
     unsigned short* sp_planes;
     int64_t sp_ld_src, sp_ld, sp_pstride;
-    int sp_rows, sp_groups;
+    int sp_rows, sp_groups, sp_cols;
 };
 
 __device__ __forceinline__ void split_rows_job(const FwdArgs& a, int wg, int nwg) {
@@ -58,7 +58,18 @@ __device__ __forceinline__ void split_rows_job(const FwdArgs& a, int wg, int nwg
     for (int64_t idx = (int64_t)wg * CT + threadIdx.x; idx < total; idx += (int64_t)nwg * CT) {
         const int row = (int)(idx / a.sp_groups), gq = (int)(idx - (int64_t)row * a.sp_groups);
         const float* sp = a.sp_src + (int64_t)row * a.sp_ld_src + 8 * gq;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        f32x4 v0, v1;
+        if (8 * gq + 8 <= a.sp_cols) {
+            v0 = *reinterpret_cast<const f32x4*>(sp);
+            v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        } else {  // a column count off a multiple of 8: the group's tail is zeros (mmvae_split_planes_f32)
+            const int left = a.sp_cols - 8 * gq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v0[j] = j < left ? sp[j] : 0.f;
+                v1[j] = 4 + j < left ? sp[4 + j] : 0.f;
+            }
+        }
         unsigned q[8][3];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -488,7 +499,7 @@ static int fc_fwd_impl(int B, int N, const float* in, int64_t ld_in, int n_slabs
                        mmvae_stream_t stream, int sp_rows = 0, int sp_cols = 0, const float* sp_src = nullptr,
                        int64_t sp_ld_src = 0, uint16_t* sp_planes = nullptr, int64_t sp_ld = 0, int64_t sp_pstride = 0) {
     if (d_planes && (!d_out || N % 2 != 0 || ldp < N || ldp % 2 != 0 || pstride < (int64_t)B * ldp)) return MMVAE_ERR_ARG;
-    if (sp_planes && (sp_rows <= 0 || sp_cols <= 0 || sp_cols % 8 != 0 || !sp_src || sp_ld_src < sp_cols || sp_ld < sp_cols ||
+    if (sp_planes && (sp_rows <= 0 || sp_cols <= 0 || !sp_src || sp_ld_src < sp_cols || sp_ld < (sp_cols + 7) / 8 * 8 ||
                       sp_ld % 8 != 0 || sp_pstride % 8 != 0 || sp_pstride < (int64_t)sp_rows * sp_ld ||
                       (reinterpret_cast<uintptr_t>(sp_planes) & 15u)))
         return MMVAE_ERR_ARG;
@@ -540,7 +551,8 @@ static int fc_fwd_impl(int B, int N, const float* in, int64_t ld_in, int n_slabs
         a.sp_ld = sp_ld;
         a.sp_pstride = sp_pstride;
         a.sp_rows = sp_rows;
-        a.sp_groups = sp_cols / 8;
+        a.sp_groups = (sp_cols + 7) / 8;
+        a.sp_cols = sp_cols;
         // ~3 workgroups per CU for the split job, as rows of the layer's own grid width
         grid_apply.y = a.RC + ceil_div_i(768, (int)grid.x);
     }

@@ -1246,7 +1246,9 @@ struct XwPlanes {
                 int b = pin % (2 * R);
                 if (R != 160) b = (((b >> 6) ^ (k & 3)) << 6) | (b & 63);
                 int col = r0 + (b >> 1);
-                if (col + 8 > Rtot) col = r0;
+                // (an extent off a multiple of 8: the planes' leading dimension is rounded up to 8 and the columns between
+                // hold zeros -- mmvae_split_planes_f32 -- so the last 16-byte group is fetched like any other)
+                if (col + 8 > ((Rtot + 7) & ~7)) col = r0;
                 off[j] = (unsigned)((plane * pstride + (int64_t)k * ld + col) * 2);
             }
         }

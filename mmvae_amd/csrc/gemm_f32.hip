@@ -1036,13 +1036,13 @@ extern "C" int mmvae_gemm_f32(int layout, int M, int N, int K, float alpha, cons
 
 // A pre-split operand the LDS-DMA stagers can address: 16-byte aligned rows, 32-bit byte offsets inside the three
 // planes, and -- for a rows-contiguous operand (A of TN along M, B of NN / TN along N), fetched in 16-byte groups of 8
-// rows -- an extent that is a multiple of 8.
+// columns -- a leading dimension that covers the extent rounded up to 8 (the columns in between hold zeros).
 static bool planes_usable(int layout, bool is_a, int M, int N, int K, const uint16_t* P, int64_t ld, int64_t pstride) {
     if (!P || !aligned16(P) || ld % 8 != 0 || pstride % 8 != 0 || K % X3_BK != 0) return false;
     const bool rc = is_a ? layout == MMVAE_GEMM_TN : layout != MMVAE_GEMM_NT;
     const int64_t rows = rc ? K : (is_a ? M : N), inner = rc ? (is_a ? M : N) : K;
     if (ld < inner || pstride < rows * ld) return false;
-    if (rc && inner % 8 != 0) return false;
+    if (rc && ld < (inner + 7) / 8 * 8) return false;  // (zero columns up to the next multiple of 8: see XwPlanes::offsets)
     return 3 * pstride * 2 < (int64_t)0xFFFFFFFF;
 }
 
@@ -1093,8 +1093,8 @@ extern "C" int mmvae_gemm_planes_supported(int layout, int M, int N, int K, int 
     if (layout < 0 || layout > 2 || M <= 0 || N <= 0 || K <= 0 || K % X3_BK != 0) return 0;
     if (g_precision != MMVAE_GEMM_PRECISION_BF16X3) return 0;
     if (!mmvae_detail::x3w_planes_combo(layout, a_planes != 0, b_planes != 0)) return 0;
-    const bool a_rc = layout == MMVAE_GEMM_TN, b_rc = layout != MMVAE_GEMM_NT;
-    if ((a_planes && a_rc && M % 8 != 0) || (b_planes && b_rc && N % 8 != 0)) return 0;
+    // (a rows-contiguous planes operand whose extent is off a multiple of 8 needs its leading dimension rounded up to 8
+    // with zero columns: checked at the launch, planes_usable)
     int tile_id, sk;
     plan(layout, M, N, K, &tile_id, &sk);
     if (splitk == 0) splitk = sk;
@@ -1125,21 +1125,14 @@ static int gemm_f32_impl(int layout, int M, int N, int K, float alpha, const flo
     if (splitk > 1 && tile_id == 1) tile_id = 0;  // split-K slices use the square tiles
     int aligned = A && B && aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     if (aligned && M % 4 == 0 && N % 4 == 0 && K % 4 == 0) aligned = 2;
-    const bool x3v = x3_vec_ok(layout, M, N, (flags & MMVAE_GEMM_OPERAND_SLACK) != 0);
+    const bool slack = (flags & MMVAE_GEMM_OPERAND_SLACK) != 0;
     flags &= ~MMVAE_GEMM_OPERAND_SLACK;
-    if (g_precision == MMVAE_GEMM_PRECISION_BF16X3 && tile_id != 2)  // chip-filling GEMMs: bf16x3 cores
-        tile_id = (x3v && K % X3_BK == 0) ? x3_tile_regular(M, N, splitk, true) : 3;
-    if (tile_id >= 6) {  // the persistent kernel's k-tile stream has no empty items: every slice must own a k-tile
-        const int kt32 = K / X3_BK, kps = ceil_div_i(kt32, splitk);
-        if ((int64_t)(splitk - 1) * kps >= kt32) tile_id = 3;
-    }
     // Pre-split operands run on the wave-specialised kernel only (whole k-tiles, chip-filling shapes); an operand whose
     // planes cannot be used falls back to its fp32 form when the caller passed one.
     bool a_pl = false, b_pl = false;
-    if (want_ap || want_bp) {
+    if ((want_ap || want_bp) && g_precision == MMVAE_GEMM_PRECISION_BF16X3) {
         a_pl = want_ap && planes_usable(layout, true, M, N, K, pl_in->Ap, pl_in->ldap, pl_in->a_pstride);
         b_pl = want_bp && planes_usable(layout, false, M, N, K, pl_in->Bp, pl_in->ldbp, pl_in->b_pstride);
-        if (tile_id < 6 || g_precision != MMVAE_GEMM_PRECISION_BF16X3) a_pl = b_pl = false;
         if (!mmvae_detail::x3w_planes_combo(layout, a_pl, b_pl)) {
             // the nearest combination with a kernel: drop what has an fp32 form
             if (a_pl && b_pl && B && mmvae_detail::x3w_planes_combo(layout, true, false))
@@ -1147,6 +1140,28 @@ static int gemm_f32_impl(int layout, int M, int N, int K, float alpha, const flo
             else
                 a_pl = b_pl = false;
         }
+    }
+    bool x3v = false;
+    const int tile_planned = tile_id;
+    // (a pre-split operand is not read in its fp32 form: only the fp32 operands' rows need the 16-byte-group conditions)
+    auto pick_tile = [&](bool apl, bool bpl) {
+        const bool a_rc = layout == MMVAE_GEMM_TN, b_rc = layout != MMVAE_GEMM_NT;
+        x3v = (!a_rc || apl || M % 4 == 0 || slack) && (!b_rc || bpl || N % 4 == 0 || slack);
+        int t = tile_planned;
+        if (g_precision == MMVAE_GEMM_PRECISION_BF16X3 && t != 2)  // chip-filling GEMMs: bf16x3 cores
+            t = (x3v && K % X3_BK == 0) ? x3_tile_regular(M, N, splitk, true) : 3;
+        if (t >= 6) {  // the persistent kernel's k-tile stream has no empty items: every slice must own a k-tile
+            const int kt32 = K / X3_BK, kps = ceil_div_i(kt32, splitk);
+            if ((int64_t)(splitk - 1) * kps >= kt32) t = 3;
+        }
+        return t;
+    };
+    tile_id = pick_tile(a_pl, b_pl);
+    if ((a_pl || b_pl) && tile_id < 6) {
+        a_pl = b_pl = false;
+        tile_id = pick_tile(false, false);
+    }
+    if (want_ap || want_bp) {
         if ((!a_pl && !A) || (!b_pl && !B)) return MMVAE_ERR_ARG;
     }
     const TileShape ts = tile_shape(layout, tile_id);

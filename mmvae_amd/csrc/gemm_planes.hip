@@ -11,8 +11,11 @@ namespace {
 
 // fp32 [rows, cols] -> planes[p][row][col] (bf16), p = 0 (top 16 bits), 1, 2 (residuals): a = p0 + p1 + p2 exactly.
 // One thread per 8 consecutive columns: two 16-byte loads, three 16-byte stores (HBM-bound: 4 B read, 6 B written per
-// element).  The arithmetic is x3_pack4_lean's -- the same split the GEMM stagers perform.
-__global__ __launch_bounds__(256) void split_planes_kernel(int rows, int groups, const float* __restrict__ src,
+// element).  The arithmetic is x3_pack4_lean's -- the same split the GEMM stagers perform.  A column count that is not a
+// multiple of 8 (the reference's 60 530 / 52 437 genes): the planes' leading dimension is rounded up to 8 and the last
+// group of a row is read element by element, its columns beyond `cols` written as zeros -- the rows-contiguous DMA of
+// the planes kernels fetches whole 16-byte groups and multiplies those zeros into columns the epilogue never stores.
+__global__ __launch_bounds__(256) void split_planes_kernel(int rows, int cols, int groups, const float* __restrict__ src,
                                                            int64_t ld_src, unsigned short* __restrict__ planes,
                                                            int64_t ld, int64_t pstride) {
     const int64_t total = (int64_t)rows * groups;
@@ -20,7 +23,18 @@ __global__ __launch_bounds__(256) void split_planes_kernel(int rows, int groups,
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int row = (int)(idx / groups), gq = (int)(idx - (int64_t)row * groups);
         const float* sp = src + (int64_t)row * ld_src + 8 * gq;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        f32x4 v0, v1;
+        if (8 * gq + 8 <= cols) {
+            v0 = *reinterpret_cast<const f32x4*>(sp);
+            v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        } else {
+            const int left = cols - 8 * gq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v0[j] = j < left ? sp[j] : 0.f;
+                v1[j] = 4 + j < left ? sp[4 + j] : 0.f;
+            }
+        }
         uint2 a[3], b[3];
         x3_pack4_lean(f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, a);
         x3_pack4_lean(f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}, b);
@@ -35,17 +49,18 @@ __global__ __launch_bounds__(256) void split_planes_kernel(int rows, int groups,
 
 extern "C" int mmvae_split_planes_f32(int rows, int cols, const float* src, int64_t ld_src, uint16_t* planes, int64_t ld,
                                       int64_t plane_stride, mmvae_stream_t stream) {
-    if (rows <= 0 || cols <= 0 || !src || !planes || cols % 8 != 0) return MMVAE_ERR_ARG;
-    if (ld_src < cols || ld < cols || ld % 8 != 0 || plane_stride % 8 != 0 || plane_stride < (int64_t)rows * ld)
+    if (rows <= 0 || cols <= 0 || !src || !planes) return MMVAE_ERR_ARG;
+    const int groups = (cols + 7) / 8;  // (the last group of a row may be partial: zero-filled up to ld)
+    if (ld_src < cols || ld < 8 * (int64_t)groups || ld % 8 != 0 || plane_stride % 8 != 0 ||
+        plane_stride < (int64_t)rows * ld)
         return MMVAE_ERR_ARG;
     if (!aligned16(planes)) return MMVAE_ERR_ARG;
-    const int groups = cols / 8;
     const int64_t total = (int64_t)rows * groups;
     // <= 3 workgroups per CU: the pass is HBM-bound long before that, and a grid that fills every wave slot starves the
     // latency-bound kernels the engine runs beside it
     int blocks = (int)((total + 255) / 256);
     if (blocks > 768) blocks = 768;
-    MMVAE_LAUNCH(split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, groups, src, ld_src,
+    MMVAE_LAUNCH(split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, cols, groups, src, ld_src,
                  reinterpret_cast<unsigned short*>(planes), ld, plane_stride);
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;

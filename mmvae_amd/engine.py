@@ -405,9 +405,19 @@ class StepEngine:
             self._pending.clear()
 
     # ------------------------------------------------------------------------------------------------- inputs
-    def _select_input(self, x: torch.Tensor, base_key: tuple):
+    def _enc_planes(self, l0_in: int, l0_out: int, has_bn: bool, B: int, K: int, train: bool, iwae: bool) -> bool:
+        """Does a program of this geometry read the operands of its first-layer weight gradient from bf16 planes?  (Then
+        nothing reads the batch in 16-byte groups across row ends or beyond its last row: _select_input.)"""
+        return bool(self.planes and train and K == 1 and not iwae and self.lib.mmvae_gemm_get_precision() == 1
+                    and l0_out % 8 == 0 and has_bn
+                    and self.lib.mmvae_gemm_planes_supported(TN, l0_out, l0_in, (B + 31) // 32 * 32, 1, 1, 1))
+
+    def _select_input(self, x: torch.Tensor, base_key: tuple, needs_slack: bool = True):
         """Plan selection: graphs are keyed by the input pointer once a pointer has been seen twice (resident
-        batches); otherwise the batch is copied into a static buffer.  Returns (plan key, the tensor the plan reads)."""
+        batches); otherwise the batch is copied into a static buffer.  Returns (plan key, the tensor the plan reads).
+        needs_slack: some kernel of the program reads the batch as a rows-contiguous fp32 GEMM operand (the first layer's
+        weight gradient without planes): 16-byte groups that reach past a row's end when the gene count is not a multiple
+        of 4, and zero rows behind a batch that is not a multiple of 32 (kpad)."""
         B = x.shape[0]
         if x.layout == torch.sparse_csr:  # CSR batch: densified by one HIP pass straight into the static input buffer
             from . import ops
@@ -421,7 +431,8 @@ class StepEngine:
         n_ptr_plans = sum(1 for k in self._plans if k[-2] != 0)
         # a caller's tensor has no slack behind it: with a gene count that is not a multiple of 4, or a batch that is
         # not a multiple of 32 (kpad reads zero rows behind the batch), it is always staged
-        if x.shape[1] % 4 == 0 and B % 32 == 0 and (pkey in self._plans or (seen >= 1 and n_ptr_plans < MAX_POINTER_PLANS)):
+        direct_ok = (x.shape[1] % 4 == 0 and B % 32 == 0) or not needs_slack
+        if direct_ok and (pkey in self._plans or (seen >= 1 and n_ptr_plans < MAX_POINTER_PLANS)):
             return pkey, x
         x_in = self.buf(f"x_static.{base_key[1]}", (B, x.shape[1]))
         if x.is_contiguous():  # own 16-byte copy kernel: the runtime's blit kernel reaches < 1 TB/s here
@@ -460,7 +471,9 @@ class StepEngine:
         enc_mod = self.model.module.vae.encoder
         explicit = enc_mod.explicit_eps is not None
         B = x.shape[0]
-        key, x_in = self._select_input(x, (mode, expert_id, B, 1, explicit))
+        # (forward-only programs read the batch through the K-contiguous forward GEMM and the reconstruction epilogue's
+        # guarded loads only: any caller's tensor serves as it is)
+        key, x_in = self._select_input(x, (mode, expert_id, B, 1, explicit), needs_slack=False)
         plan = self._plans.get(key)
         if plan is None:
             plan = _Plan(self, expert_id, B, 1, explicit, x_in, mode=mode)
@@ -498,7 +511,10 @@ class StepEngine:
             K = enc_mod.explicit_eps.shape[0]
         B = x.shape[0]
         iwae = getattr(enc_mod, "elbo_mode", "analytic") == "iwae"
-        key, x_in = self._select_input(x, ("train-iwae" if iwae else "train", expert_id, B, K, explicit))
+        l0 = expert.encoder.fc_layers[0]
+        planes = self._enc_planes(l0.lin.in_features, l0.lin.out_features, hasattr(l0, "bn"), B, K, True, iwae)
+        key, x_in = self._select_input(x, ("train-iwae" if iwae else "train", expert_id, B, K, explicit),
+                                       needs_slack=not planes)
         plan = self._plans.get(key)
         if plan is None:
             plan = _Plan(self, expert_id, B, K, explicit, x_in, iwae=iwae)
@@ -649,8 +665,8 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
         # the split pass in front of it costs 17 us for 8 us gained.)
         l0, lastl = self.enc_layers[0], self.dec_layers[-1]
         pl_on = bool(eng.planes and train and K == 1 and not self.iwae and lib.mmvae_gemm_get_precision() == 1)
-        self.pl_enc = bool(pl_on and l0.n_in % 8 == 0 and l0.n_out % 8 == 0 and l0.bn is not None
-                           and lib.mmvae_gemm_planes_supported(TN, l0.n_out, l0.n_in, self.kpad(B), 1, 1, 1))
+        # (any gene count: the planes of x get a leading dimension rounded up to 8, zero columns in between)
+        self.pl_enc = eng._enc_planes(l0.n_in, l0.n_out, l0.bn is not None, B, K, train, self.iwae)
         self.xp = _PlaneBuf(eng, f"xp.{l0.n_in}", B, l0.n_in) if self.pl_enc else None
         self.dYp = _PlaneBuf(eng, f"dYp.{l0.n_out}", B, l0.n_out) if self.pl_enc else None
         self.pl_dec_h = bool(pl_on and lastl.n_in % 8 == 0 and len(self.dec_layers) >= 2
@@ -758,7 +774,17 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             raise _lib.HipLibraryError("engine: the last decoder layer must be Linear+ReLU (fused recon epilogue)")
         last.inp, last.ld_inp, last.rows = cur, ld, R
         T = lib.mmvae_recon_tiles(G)
-        self.dP = eng.buf(f"dP.{G}", (R, G)) if train else None
+        # dP [R, G]: with a gene count off the 32-wide k-tile (60 530, 52 437, 30 000) its leading dimension is rounded up
+        # to 32 -- the columns in between are zeros nobody writes -- so that the input-gradient product dP . W runs its K
+        # over whole k-tiles instead of a tail slab on the element-guarded kernel (12 us + a launch boundary per step).
+        # The weight rows "beyond" W that those zero columns meet are the decoder bias behind it in the arena (finite).
+        Gp = (G + 31) // 32 * 32
+        if not (train and Gp != G and big and lib.mmvae_gemm_get_precision() == 1
+                and (Gp - G) * last.n_in <= last.b.numel() + 32
+                and last.b.data_ptr() == last.W.data_ptr() + 4 * last.W.numel()):
+            Gp = G
+        self.ldp = Gp
+        self.dP = eng.buf(f"dP.{G}", (R, Gp))[:, :G] if train else None
         self.se_part = eng.buf(f"se_part.{G}", (T, R))
         self.w = eng.buf("w", (R,))
         # K = 1: the decoder bias's gradient is the column sum of dP; the epilogue that stores dP leaves its per-row-tile
@@ -783,7 +809,7 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             self._sum_jobs, self._gemm_jobs = pending, pending_g
             h_in, ld_h, kpad = hpad, Kp, True
         self._emit(lib.mmvae_decoder_recon_rows_colsum_f32, R, B, G, last.n_in, _p(h_in), ld_h, _p(last.W), last.n_in,
-                   _p(last.b), _p(x), ldx, None, 0, _p(self.dP), G, _p(self.se_part), _p(self.dp_colpart),
+                   _p(last.b), _p(x), ldx, None, 0, _p(self.dP), self.ldp, _p(self.se_part), _p(self.dp_colpart),
                    probe=("dec_l2_recon", 2.0 * R * G * last.n_in))
         if kpad:  # the launch state brackets the launch
             launch = self._cur.pop()
@@ -845,7 +871,7 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             w_rows = self.w
             nch = lib.mmvae_weighted_colsum_chunks(R)
             parts = eng.buf(f"wcolsum.{G}", (nch, G))
-            self._emit(lib.mmvae_weighted_colsum_f32, R, G, _p(self.dP), G, _p(self.w), _p(parts))
+            self._emit(lib.mmvae_weighted_colsum_f32, R, G, _p(self.dP), self.ldp, _p(self.w), _p(parts))
             self._defer_sum(parts, nch, G, 1, G, G, last.gb, G)
             dw_inp = eng.buf(f"h_weighted.{last.n_in}", (R, last.n_in))
             dw_ld = last.n_in
@@ -862,24 +888,24 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             # 200.  Forked right behind the input gradient instead -- beside the adversaries' generator phase -- the
             # step is 8 % SLOWER (1.25 ms): the three lanes fight over the CUs (profiles/r4_c4_dw_aside.txt).
             self._probe_next = "dec_l2_dx"
-            S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
+            S = self.gemm_raw(NN, R, last.n_in, self.ldp, self.dP, self.ldp, last.W, last.n_in)
             self._probe_next = None
             self._mark("decoder dX done")
 
             def dw4_late():
                 self._probe_next = "dec_l2_dw"
-                if not self._fuse_sqnorm(TN, G, last.n_in, self.kpad(R), 1.0, self.dP, G, last.inp, last.ld_inp, last.gW,
+                if not self._fuse_sqnorm(TN, G, last.n_in, self.kpad(R), 1.0, self.dP, self.ldp, last.inp, last.ld_inp, last.gW,
                                          last.n_in, None, 0, side_cap=ADV_DW_CAP, planes=dw_pl, stream=dw_stream):
-                    self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in,
+                    self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, self.ldp, last.inp, last.ld_inp, last.gW, last.n_in,
                               side=True, planes=dw_pl)
                 self._probe_next = None
         elif side_dw:  # input gradient first (the chain waits for it), then the weight gradient on the side branch
             self._probe_next = "dec_l2_dx"
-            S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
+            S = self.gemm_raw(NN, R, last.n_in, self.ldp, self.dP, self.ldp, last.W, last.n_in)
             self._probe_next = "dec_l2_dw"
-            if not self._fuse_sqnorm(TN, G, last.n_in, self.kpad(R), 1.0, self.dP, G, last.inp, last.ld_inp, last.gW,
+            if not self._fuse_sqnorm(TN, G, last.n_in, self.kpad(R), 1.0, self.dP, self.ldp, last.inp, last.ld_inp, last.gW,
                                      last.n_in, None, 0, side_cap=side_dw, planes=dw_pl):
-                self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in, side=True,
+                self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, self.ldp, last.inp, last.ld_inp, last.gW, last.n_in, side=True,
                           planes=dw_pl)
             self._probe_next = None
             self._mark("decoder dX done")
@@ -892,17 +918,17 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             # exchange program: input gradient first, the weight gradient capped on the side stream beside the chain up
             # to the VAE's exchange point (the cut there joins it)
             self._probe_next = "dec_l2_dx"
-            S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
+            S = self.gemm_raw(NN, R, last.n_in, self.ldp, self.dP, self.ldp, last.W, last.n_in)
             self._probe_next = "dec_l2_dw"
-            self._side_capped_gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, last.inp, last.ld_inp, last.gW, last.n_in,
+            self._side_capped_gemm(TN, G, last.n_in, self.kpad(R), self.dP, self.ldp, last.inp, last.ld_inp, last.gW, last.n_in,
                                    eng.side_dw_dp, planes=dw_pl)
             self._probe_next = None
         else:
             self._probe_next = "dec_l2_dw" if big else None
-            self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, G, dw_inp, dw_ld, last.gW, last.n_in, side=True,
+            self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, self.ldp, dw_inp, dw_ld, last.gW, last.n_in, side=True,
                       planes=dw_pl)
             self._probe_next = "dec_l2_dx" if big else None
-            S = self.gemm_raw(NN, R, last.n_in, G, self.dP, G, last.W, last.n_in)
+            S = self.gemm_raw(NN, R, last.n_in, self.ldp, self.dP, self.ldp, last.W, last.n_in)
             self._probe_next = None
         rest = self.dec_layers[:-1]
         for j in range(len(rest) - 1, -1, -1):

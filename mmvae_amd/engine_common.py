@@ -86,13 +86,14 @@ def _supported_block(block: FCBlock) -> bool:
 
 
 class _PlaneBuf:
-    """Three bf16 planes of an engine buffer [rows, cols] (int16 [3, rows + 32, cols]); the 32 slack rows of every plane
-    stay zero: a weight-gradient GEMM runs its K over them (kpad)."""
+    """Three bf16 planes of an engine buffer [rows, cols] (int16 [3, rows + 32, ld], ld = cols rounded up to 8); the 32
+    slack rows of every plane stay zero: a weight-gradient GEMM runs its K over them (kpad).  The columns between cols
+    and ld are zeros too (written by the split kernels): a rows-contiguous planes operand is fetched in 16-byte groups."""
 
     def __init__(self, eng, name: str, rows: int, cols: int):
-        self.rows, self.cols, self.ld = rows, cols, cols
-        self.data = eng.buf(name, (3, rows + 32, cols), torch.int16)
-        self.pstride = (rows + 32) * cols
+        self.rows, self.cols, self.ld = rows, cols, (cols + 7) // 8 * 8
+        self.data = eng.buf(name, (3, rows + 32, self.ld), torch.int16)
+        self.pstride = (rows + 32) * self.ld
 
     def ptr(self) -> int:
         return self.data.data_ptr()

@@ -148,9 +148,8 @@ class Planes:
     `data` is int16 [3, rows + slack_rows, ld]; the slack rows stay zero (a weight-gradient GEMM pads its K to 32)."""
 
     def __init__(self, rows: int, cols: int, device, slack_rows: int = 32):
-        if cols % 8:
-            raise ValueError("Planes: cols must be a multiple of 8")
-        self.rows, self.cols, self.ld = rows, cols, cols
+        # (a column count off a multiple of 8: the leading dimension is rounded up, the columns in between stay zero)
+        self.rows, self.cols, self.ld = rows, cols, (cols + 7) // 8 * 8
         self.data = torch.zeros((3, rows + slack_rows, self.ld), dtype=torch.int16, device=device)
         self.plane_stride = (rows + slack_rows) * self.ld
 
@@ -159,12 +158,12 @@ class Planes:
 
     def to_float(self) -> torch.Tensor:
         """p0 + p1 + p2 as fp32 (exactly the matrix that was split; tests)."""
-        planes = (self.data[:, : self.rows].to(torch.int32) << 16).view(torch.float32)
+        planes = (self.data[:, : self.rows, : self.cols].to(torch.int32) << 16).view(torch.float32)
         return (planes[0] + planes[1]) + planes[2]
 
 
 def split_planes(src: torch.Tensor, out: Optional[Planes] = None) -> Planes:
-    """mmvae_split_planes_f32: write the three bf16 planes of `src` [rows, cols] (cols % 8 == 0)."""
+    """mmvae_split_planes_f32: write the three bf16 planes of `src` [rows, cols]."""
     lib = _lib.load()
     _chk(src, "src")
     rows, cols, ld = _mat(src, "src")
@@ -179,9 +178,11 @@ def split_planes(src: torch.Tensor, out: Optional[Planes] = None) -> Planes:
 
 def gemm_planes(layout: int, a: Optional[torch.Tensor], b: Optional[torch.Tensor], *, a_planes: Optional[Planes] = None,
                 b_planes: Optional[Planes] = None, K: Optional[int] = None, out: Optional[torch.Tensor] = None,
-                accumulate: bool = False, splitk: int = 0, raw_slabs: bool = False, want_sq: bool = False):
+                accumulate: bool = False, splitk: int = 0, raw_slabs: bool = False, want_sq: bool = False,
+                operand_slack: bool = False):
     """mmvae_gemm_planes_f32: gemm() / gemm_slabs() / gemm_sq() with optional pre-split operands (a / b may be None
-    when the planes are given).  K overrides the reduction length of a TN product (padded over the zero slack rows)."""
+    when the planes are given).  K overrides the reduction length of a TN product (padded over the zero slack rows).
+    operand_slack: the caller vouches for 16 readable bytes behind every fp32 operand (MMVAE_GEMM_OPERAND_SLACK)."""
     lib = _lib.load()
 
     def dims(t, pl):
@@ -199,7 +200,8 @@ def gemm_planes(layout: int, a: Optional[torch.Tensor], b: Optional[torch.Tensor
     dev = (a if a is not None else a_planes.data).device
     if splitk == 0 and not want_sq:
         _, splitk = gemm_plan(layout, M, N, Kk)
-    flags = (GEMM_ACCUMULATE if accumulate else 0) | (GEMM_RAW_SLABS if raw_slabs else 0)
+    flags = ((GEMM_ACCUMULATE if accumulate else 0) | (GEMM_RAW_SLABS if raw_slabs else 0)
+             | (_lib.GEMM_OPERAND_SLACK if operand_slack else 0))
     if raw_slabs:
         out = torch.empty((splitk, M, N), dtype=torch.float32, device=dev)
         ldc, ws, nbytes = N, None, 0

@@ -33,7 +33,8 @@ def padded(t, slack=32):
     return full[: t.shape[0]]
 
 
-@pytest.mark.parametrize("rows,cols", [(8, 8), (33, 64), (512, 1024), (100, 20000)])
+@pytest.mark.parametrize("rows,cols", [(8, 8), (33, 64), (512, 1024), (100, 20000), (33, 60530), (64, 52437), (100, 10001),
+                                       (5, 12)])
 def test_split_is_exact(ops, rows, cols):
     x = rnd(rows, cols, seed=rows + cols) * torch.logspace(-6, 6, cols, device="cuda")  # wide dynamic range
     # (the split is exact while the residuals stay normal numbers: |a| >= 2^-110; below that the pieces' bit patterns no
@@ -42,7 +43,12 @@ def test_split_is_exact(ops, rows, cols):
     p = ops.split_planes(x)
     assert torch.equal(p.to_float(), x)
     assert int(p.data[:, rows:].abs().max()) == 0  # slack rows untouched
-    planes = (p.data[:, :rows].to(torch.int32) << 16).view(torch.float32)
+    assert p.ld % 8 == 0 and p.ld - cols < 8
+    if p.ld > cols:  # a column count off a multiple of 8: the columns up to the leading dimension hold zeros
+        p.data[:, :, cols:] = 77
+        ops.split_planes(x, out=p)
+        assert int(p.data[:, :rows, cols:].abs().max()) == 0
+    planes = (p.data[:, :rows, :cols].to(torch.int32) << 16).view(torch.float32)
     assert torch.equal(planes[0].view(torch.int32), x.view(torch.int32) & -65536)  # plane 0 = the top 16 bits
 
 
@@ -57,6 +63,13 @@ CASES = [
     (TN, 2000, 5008, 480, "ab", False),   # ragged tiles (extents % 8 == 0 only), K padded to 512 over the slack rows
     (TN, 20000, 1024, 512, "b", False),   # the same product with only h pre-split (A = dP split in the kernel)
     (TN, 2000, 5008, 480, "b", False),
+    # gene counts off a multiple of 8 (r5; human_only.yaml:90, adversarial-conditional.yaml:107): planes with a padded ld
+    (TN, 1024, 60530, 512, "ab", False),  # dW of the first layer at the reference's human width
+    (TN, 1024, 52437, 512, "ab", False),  # ... and the mouse width (odd)
+    (TN, 1024, 10001, 500, "ab", False),  # golden case mid_odd
+    (TN, 10001, 1024, 512, "ab", False),  # the rows-contiguous A operand with an odd extent
+    (TN, 60530, 1024, 512, "b", False),   # dW of the last layer: dP fp32 (odd rows, slack behind), h pre-split
+    (TN, 2000, 5003, 480, "b", False),
     (NT, 512, 1024, 20000, "a", True),    # forward of the first layer: x pre-split, W fp32
     (NN, 512, 1024, 20000, "a", True),    # dX of the last layer: dP pre-split, W fp32
     (NT, 500, 1024, 8192, "a", True),
@@ -78,7 +91,9 @@ def test_gemm_planes_bitwise_and_fp64(ops, layout, M, N, K, pre, slabs):
            else a.double() @ b.double())
     ap = ops.split_planes(a) if "a" in pre else None
     bp = ops.split_planes(b) if "b" in pre else None
-    kw = dict(K=Kp if layout == TN else None, raw_slabs=slabs, want_sq=(layout == TN))
+    # (fp32 operands whose rows are not 16-byte groups reach the same kernel only when the caller vouches for the slack
+    # behind them: padded() provides it)
+    kw = dict(K=Kp if layout == TN else None, raw_slabs=slabs, want_sq=(layout == TN), operand_slack=(layout == TN))
     lib = __import__("mmvae_amd._lib", fromlist=["load"]).load()
     assert lib.mmvae_gemm_planes_supported(layout, M, N, Kp if layout == TN else K, 0 if slabs else 1, int("a" in pre),
                                            int("b" in pre)) == 1
