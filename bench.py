@@ -319,8 +319,12 @@ def main():
     n_res = 2  # resident batches per modality
     data = {}
     for i, (eid, G) in enumerate(cfg["experts"].items()):
-        data[eid] = [(synthetic.synthetic_counts(B, G, seed=1234 + 97 * i + 13 * j + 1000 * rank, device=device),
-                      synthetic.synthetic_metadata(B, seed=5 + j + 1000 * rank)) for j in range(n_res)]
+        if cfg["adversarial"]:  # labels (and counts) are functions of the cell: the discriminators have signal, as on real data
+            data[eid] = [synthetic.synthetic_labelled_batch(B, G, seed=1234 + 97 * i + 13 * j + 1000 * rank, device=device)
+                         for j in range(n_res)]
+        else:
+            data[eid] = [(synthetic.synthetic_counts(B, G, seed=1234 + 97 * i + 13 * j + 1000 * rank, device=device),
+                          synthetic.synthetic_metadata(B, seed=5 + j + 1000 * rank)) for j in range(n_res)]
 
     if a.input == "csr":
         data = {eid: [(x.to_sparse_csr(), m) for x, m in v] for eid, v in data.items()}
@@ -391,8 +395,6 @@ def main():
     # hipGraph on its second; a resident batch is recognised by its pointer on its second sight.  Step every resident
     # batch until its plan replays, so that neither the warm-up nor the timed steps contain plan builds.
     period = len(eids) * n_res
-    sd_initial = ({k: v.detach().clone() for k, v in model.module.state_dict().items()}
-                  if (a.config == "c4" and on_gpu and not a.no_parity) else None)
     n_setup = 4 * period if on_gpu else 0
     for i in range(n_setup):
         step(i)
@@ -477,24 +479,20 @@ def main():
         model._flush_engine()
     loss = {k: float(v.detach() if torch.is_tensor(v) else v) for k, v in model.logged.items()
             if k.startswith(("loss/", "recon_loss/", "kl_loss/"))}
+    import math
+
+    finite = {"last_losses": all(math.isfinite(v) for v in loss.values())}
+    if on_gpu:
+        opts = list(model.optimizers())
+        finite["parameters"] = all(bool(torch.isfinite(o.arena.data).all()) for o in opts)
+        finite["adam_moments"] = all(bool(torch.isfinite(o.arena.exp_avg).all()) and bool(torch.isfinite(o.arena.exp_avg_sq).all())
+                                     for o in opts)
     parity = None
     if (leg is not None and world == 1 and rank == 0 and a.config in ("c2", "c4") and a.input == "dense" and not a.genes
             and not a.hidden and not a.no_parity and not a.sim_world):
         i_par = n_setup + a.warmup + a.steps + 8
         eid_par = eids[i_par % len(eids)]
         x_par, m_par = data[eid_par][(i_par // len(eids)) % n_res]
-        if a.config == "c4":
-            # C4 on synthetic data diverges within ten steps (gradient reversal at adv_weight 25: losses of 1e11, fp32
-            # sums of squares overflow -- on the per-layer and the fused adversary programs alike): the checked step
-            # starts from the initial parameters and a warm optimiser state (Adam 100 steps in, second moments 1e8: a cold,
-            # sign-like step turns rounding noise into +-lr); the program (graphs, Philox) is the timed one
-            model._flush_engine()
-            torch.cuda.synchronize()
-            model.module.load_state_dict(sd_initial)
-            for o in model.optimizers():
-                o.arena.exp_avg.zero_()
-                o.arena.exp_avg_sq.zero_()
-                o.state_dev[0] = 0.0
         parity = parity_block(model, (x_par, m_par, eid_par, i_par))
 
     if rank == 0:
@@ -522,10 +520,17 @@ def main():
                        "path": "module" if (a.no_engine or not model._engine) else "engine(hipGraph)"},
             "rccl_ranks": torch.distributed.get_world_size() if backend_name == "nccl" else 0,
             "dist_backend": backend_name,
-            "step_flops_per_cell": synthetic.flops_per_cell(G, K, **({"h1": a.hidden} if a.hidden else {})),
-            "step_tflops": synthetic.flops_per_cell(G, K, **({"h1": a.hidden} if a.hidden else {})) * cells_per_s / world / 1e12,
+            # (algorithmic FLOPs of the program that was timed: the forward-only modes do a third / a sixth of a training step)
+            "step_flops_per_cell": synthetic.flops_per_cell(G, K, mode=a.mode, **({"h1": a.hidden} if a.hidden else {})),
+            "step_tflops": synthetic.flops_per_cell(G, K, mode=a.mode, **({"h1": a.hidden} if a.hidden else {})) * cells_per_s / world / 1e12,
             "last_losses": loss, "setup_steps": n_setup,
+            # every number above was measured on finite arithmetic: the last logged losses, the parameters and both Adam
+            # moments of every optimiser after the last step (a diverged run times degenerate operands: VERDICT r4)
+            "finite": finite,
         }
+        if not all(finite.values()):
+            out["invalid"] = "non-finite values after the timed steps: " + ", ".join(k for k, v in finite.items() if not v)
+            print("bench.py: " + out["invalid"], file=sys.stderr)
         if leg is not None:
             from mmvae_amd import _lib
 

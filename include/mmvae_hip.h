@@ -40,7 +40,7 @@ typedef void* mmvae_stream_t; /* hipStream_t */
 /* ABI version: bumped whenever an entry point is added or a signature changes (mmvae_abi_version() returns the
  * value the library was built with; bindings compare it with the header they were written against).
  *   1  round-1 surface (first 20 entry points)      2  end of round 1 (50 entry points)      3+  round 2 */
-#define MMVAE_ABI_VERSION 7
+#define MMVAE_ABI_VERSION 8
 int mmvae_abi_version(void);
 const char* mmvae_build_arch(void);
 
@@ -454,7 +454,8 @@ int mmvae_gemm_f32_sq(int layout, int M, int N, int K, float alpha, const float*
  * because a rows-contiguous planes operand is fetched in whole 16-byte groups.
  *
  * mmvae_gemm_planes_f32 = mmvae_gemm_f32 (sq_partials == NULL) or mmvae_gemm_f32_sq (sq_partials != NULL) with
- * optional planes per operand.  Kernels exist for TN with both operands pre-split and for NT / NN with a pre-split A;
+ * optional planes per operand.  Kernels exist for TN with B or both operands pre-split, for NT / NN with a pre-split A
+ * and (r5) for NN with a pre-split B (the weights) against an fp32 A;
  * an operand whose planes cannot be used (other combinations, shapes off the wave-specialised kernel: K % 32 != 0,
  * rows-contiguous leading dimension below the extent rounded up to 8, small outputs, MMVAE_GEMM_PRECISION_F32) is read from its fp32 form when that
  * pointer is non-NULL, otherwise the call fails with MMVAE_ERR_ARG.  Results are bit-identical to mmvae_gemm_f32 on
@@ -483,6 +484,17 @@ int mmvae_decoder_recon_planes_f32(int rows, int x_rows, int G, int H, const flo
                                    const float* x, int64_t ldx, float* xhat, int64_t ldxhat, float* dP, int64_t lddp,
                                    uint16_t* dP_planes, int64_t lddpp, int64_t dp_plane_stride, float* se_part,
                                    float* col_part, mmvae_stream_t stream);
+/* (r5) mmvae_decoder_recon_planes_f32 with the WEIGHTS pre-split as well (Wp [G][ldwp] planes of W; taken together with hp,
+ * otherwise W is read).  A K-sample program reads every weight tile from rows / 256 row tiles (20 at BASELINE config 3)
+ * and splits it there each time; with both operands pre-split the stagers only move planes (LDS-DMA, no vector work).
+ * The caller re-splits W after every optimiser step (mmvae_split_planes_f32, or the piggy-backed split of a layer tail).
+ * replaces: the decoder's last nn.Linear + ReLU + mse_loss(sum) of modules/vae.py:140-145 (as above).
+ * Same products in the same order as the fp32 form: bit-identical outputs. */
+int mmvae_decoder_recon_wplanes_f32(int rows, int x_rows, int G, int H, const float* h, int64_t ldh, const uint16_t* hp,
+                                    int64_t ldhp, int64_t h_plane_stride, const float* W, int64_t ldw, const uint16_t* Wp,
+                                    int64_t ldwp, int64_t w_plane_stride, const float* bias, const float* x, int64_t ldx,
+                                    float* xhat, int64_t ldxhat, float* dP, int64_t lddp, float* se_part, float* col_part,
+                                    mmvae_stream_t stream);
 /* mmvae_fc_epilogue_fwd / _bwd that also write the three bf16 planes of their output (d_out / the final dz_out; N even):
  * the layer tails that produce an operand of a G-wide weight-gradient GEMM (the decoder's last hidden activations, the
  * gradient at the expert encoder's first layer) split it on the way out. */

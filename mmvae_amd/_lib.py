@@ -125,6 +125,10 @@ PROTOTYPES = {
         _i,
         [_i, _i, _i, _i, _p, _l, _p, _l, _l, _p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _l, _l, _p, _p, _p],
     ),
+    "mmvae_decoder_recon_wplanes_f32": (
+        _i,
+        [_i, _i, _i, _i, _p, _l, _p, _l, _l, _p, _l, _p, _l, _l, _p, _p, _l, _p, _l, _p, _l, _p, _p, _p],
+    ),
     "mmvae_fc_epilogue_fwd_planes": (
         _i,
         [_i, _i, _p, _l, _i, _p, C.POINTER(BnParams), _i, _i, _p, _f, _p, _p, _p, _l, _p, _p, _p, _z, _p, _l, _l, _p],

@@ -1384,7 +1384,8 @@ extern "C" int mmvae_recon_set_h_kpad(int on) {
 }
 
 static int decoder_recon_impl(int rows, int x_rows, int G, int H, const float* h, int64_t ldh, const uint16_t* hp,
-                              int64_t ldhp, int64_t h_pstride, const float* W, int64_t ldw, const float* bias,
+                              int64_t ldhp, int64_t h_pstride, const float* W, int64_t ldw, const uint16_t* Wp,
+                              int64_t ldwp, int64_t w_pstride, const float* bias,
                               const float* x, int64_t ldx, float* xhat, int64_t ldxhat, float* dP, int64_t lddp,
                               uint16_t* dPp, int64_t lddpp, int64_t dp_pstride, float* se_part, float* col_part,
                               mmvae_stream_t stream) {
@@ -1451,7 +1452,14 @@ static int decoder_recon_impl(int rows, int x_rows, int G, int H, const float* h
         g.Ap = hp;
         g.ldap = ldhp;
         g.a_pstride = h_pstride;
-        return mmvae_detail::launch_x3w_planes(MMVAE_GEMM_NT, tile_id, true, false, EPI_RECON, g, g.mt * g.nt, x3w_slots(),
+        // (r5) W pre-split too -- only together with h: the kernel whose stagers do no vector work at all
+        const bool w_pl = Wp && planes_usable(MMVAE_GEMM_NT, false, rows, G, H, Wp, ldwp, w_pstride);
+        if (w_pl) {
+            g.Bp = Wp;
+            g.ldbp = ldwp;
+            g.b_pstride = w_pstride;
+        }
+        return mmvae_detail::launch_x3w_planes(MMVAE_GEMM_NT, tile_id, true, w_pl, EPI_RECON, g, g.mt * g.nt, x3w_slots(),
                                                (hipStream_t)stream);
     }
     return launch_gemm_forms<FORM_KC, FORM_KC, EPI_RECON>(tile_id, g, g.mt * g.nt, (hipStream_t)stream);
@@ -1461,8 +1469,8 @@ extern "C" int mmvae_decoder_recon_rows_colsum_f32(int rows, int x_rows, int G, 
                                                    const float* W, int64_t ldw, const float* bias, const float* x,
                                                    int64_t ldx, float* xhat, int64_t ldxhat, float* dP, int64_t lddp,
                                                    float* se_part, float* col_part, mmvae_stream_t stream) {
-    return decoder_recon_impl(rows, x_rows, G, H, h, ldh, nullptr, 0, 0, W, ldw, bias, x, ldx, xhat, ldxhat, dP, lddp,
-                              nullptr, 0, 0, se_part, col_part, stream);
+    return decoder_recon_impl(rows, x_rows, G, H, h, ldh, nullptr, 0, 0, W, ldw, nullptr, 0, 0, bias, x, ldx, xhat, ldxhat, dP,
+                              lddp, nullptr, 0, 0, se_part, col_part, stream);
 }
 
 extern "C" int mmvae_decoder_recon_planes_f32(int rows, int x_rows, int G, int H, const float* h, int64_t ldh,
@@ -1471,8 +1479,20 @@ extern "C" int mmvae_decoder_recon_planes_f32(int rows, int x_rows, int G, int H
                                               int64_t ldxhat, float* dP, int64_t lddp, uint16_t* dP_planes,
                                               int64_t lddpp, int64_t dp_plane_stride, float* se_part, float* col_part,
                                               mmvae_stream_t stream) {
-    return decoder_recon_impl(rows, x_rows, G, H, h, ldh, hp, ldhp, h_plane_stride, W, ldw, bias, x, ldx, xhat, ldxhat, dP,
-                              lddp, dP_planes, lddpp, dp_plane_stride, se_part, col_part, stream);
+    return decoder_recon_impl(rows, x_rows, G, H, h, ldh, hp, ldhp, h_plane_stride, W, ldw, nullptr, 0, 0, bias, x, ldx, xhat,
+                              ldxhat, dP, lddp, dP_planes, lddpp, dp_plane_stride, se_part, col_part, stream);
+}
+
+// (r5) ... with the weights pre-split as well (Wp; used together with hp, otherwise W is read): K-sample programs read
+// every weight tile from rows / 256 row tiles -- 20 at C3 -- and split it there each time
+extern "C" int mmvae_decoder_recon_wplanes_f32(int rows, int x_rows, int G, int H, const float* h, int64_t ldh,
+                                               const uint16_t* hp, int64_t ldhp, int64_t h_plane_stride, const float* W,
+                                               int64_t ldw, const uint16_t* Wp, int64_t ldwp, int64_t w_plane_stride,
+                                               const float* bias, const float* x, int64_t ldx, float* xhat, int64_t ldxhat,
+                                               float* dP, int64_t lddp, float* se_part, float* col_part,
+                                               mmvae_stream_t stream) {
+    return decoder_recon_impl(rows, x_rows, G, H, h, ldh, hp, ldhp, h_plane_stride, W, ldw, Wp, ldwp, w_plane_stride, bias, x,
+                              ldx, xhat, ldxhat, dP, lddp, nullptr, 0, 0, se_part, col_part, stream);
 }
 
 extern "C" int mmvae_decoder_recon_f32(int B, int G, int H, const float* h, int64_t ldh, const float* W, int64_t ldw,

@@ -84,15 +84,33 @@ bool x3w_planes_combo(int layout, bool a_pl, bool b_pl) {
     // (TN with only B pre-split: dW = dP^T h with the small operand h from its layer tail -- on the 160x256 tile B is
     // 256 of the 416 rows the stagers would otherwise split per k-tile)
     if (layout == MMVAE_GEMM_TN) return b_pl;
+    // (r5) NN with a pre-split B: the weights of the last decoder layer, split ONCE per step for programs whose products
+    // read them from many row tiles (K-sample programs: 20 row tiles of 256 at C3) -- dX = dP . W with dP fp32
+    if (layout == MMVAE_GEMM_NN) return a_pl != b_pl;
     return a_pl && !b_pl;
 }
 
 int launch_x3w_planes(int layout, int tile_id, bool a_pl, bool b_pl, int epi, const GemmArgs& g0, int nwork, int slots,
                       hipStream_t s) {
-    if (!x3w_planes_combo(layout, a_pl, b_pl) || tile_id < 6 || tile_id > 8 || slots <= 0) return MMVAE_ERR_ARG;
+    // (the fused reconstruction launch also exists with both operands pre-split)
+    const bool combo = epi == EPI_RECON ? (layout == MMVAE_GEMM_NT && a_pl) : x3w_planes_combo(layout, a_pl, b_pl);
+    if (!combo || tile_id < 6 || tile_id > 8 || slots <= 0) return MMVAE_ERR_ARG;
     GemmArgs g = g0;
     g.nwork = nwork;
     const int nblocks = nwork < slots ? nwork : slots;  // persistent over the work items
+    if (epi == EPI_RECON && b_pl) {  // (r5) fused last decoder layer, h AND W pre-split: the stagers only move planes
+        if (layout != MMVAE_GEMM_NT || !a_pl) return MMVAE_ERR_ARG;
+        if (tile_id == 6)
+            MMVAE_LAUNCH((gemm_x3w_kernel<FORM_KC, FORM_KC, 256, 160, 4, 1, EPI_RECON, SRC_PLANES, SRC_PLANES>), dim3(nblocks),
+                         dim3(512), 0, s, g);
+        else if (tile_id == 8)
+            MMVAE_LAUNCH((gemm_x3w_kernel<FORM_KC, FORM_KC, 256, 128, 2, 2, EPI_RECON, SRC_PLANES, SRC_PLANES>), dim3(nblocks),
+                         dim3(512), 0, s, g);
+        else
+            return MMVAE_ERR_ARG;
+        MMVAE_LAUNCH_CHECK();
+        return MMVAE_OK;
+    }
     if (epi == EPI_RECON) {  // fused last decoder layer: h pre-split, W fp32
         if (layout != MMVAE_GEMM_NT) return MMVAE_ERR_ARG;
         if (tile_id == 6)
@@ -121,8 +139,10 @@ int launch_x3w_planes(int layout, int tile_id, bool a_pl, bool b_pl, int epi, co
         XWP(FORM_RC, FORM_RC, SRC_F32, SRC_PLANES);
     else if (layout == MMVAE_GEMM_NT)
         XWP(FORM_KC, FORM_KC, SRC_PLANES, SRC_F32);
-    else
+    else if (a_pl)
         XWP(FORM_KC, FORM_RC, SRC_PLANES, SRC_F32);
+    else
+        XWP(FORM_KC, FORM_RC, SRC_F32, SRC_PLANES);
 #undef XWP
     MMVAE_LAUNCH_CHECK();
     return MMVAE_OK;

@@ -260,11 +260,16 @@ class StepEngine:
                 self.lib.mmvae_gemm_set_x3w(-1)
             else:
                 choice = self.dp_kernels if self.dp_kernels != "auto" else (self.dp_tuned.get("choice") or "dynamic")
-                self.lib.mmvae_gemm_set_x3w(1 if choice == "persistent" else 0)
                 tune = (self.dp_kernels == "auto" and "choice" not in self.dp_tuned
                         and (mdist.world_size() > 1 or st.dp_autotune_force))
                 if tune and self._tune is None:
-                    self._tune = dict(phase="warm", kind="dynamic", steady=0, count=0, ev=None)
+                    self._tune = dict(kind="dynamic", step=0, ev=None)
+                elif tune:
+                    # re-configured in the middle of a tune (a signature change dropped the plans: every rank sees it at
+                    # the same step): the family being timed stays, its window starts again
+                    self._tune.update(step=0, ev=None)
+                    choice = self._tune["kind"]
+                self.lib.mmvae_gemm_set_x3w(1 if choice == "persistent" else 0)
         if self.overlap and self.comm_stream is None:
             # streams of the exchange program: HIP maps streams onto a few hardware queues (4 by default), and two streams
             # on one queue run one after the other -- a lane on a stream that shares the main stream's queue started when
@@ -295,23 +300,28 @@ class StepEngine:
         self._plans = {k: p for k, p in self._plans.items() if not str(k[0]).startswith("train")}
         self._ptr_seen.clear()
 
-    DP_TUNE_STEADY, DP_TUNE_STEPS = 4, 12
+    DP_TUNE_WARM, DP_TUNE_STEPS = 12, 12
 
     def _dp_autotune(self, plan: "_Plan") -> None:
-        """MMVAE_DP_KERNELS=auto under a real exchange: time DP_TUNE_STEPS replayed steps with the 2 x 4-wave (hardware-
+        """MMVAE_DP_KERNELS=auto under a real exchange: time DP_TUNE_STEPS training steps with the 2 x 4-wave (hardware-
         scheduled) GEMM kernels, then with the persistent ones, take the maximum over the ranks of each and keep the
-        faster.  The steps are ordinary training steps; a switch drops the captured programs (they bake the kernel in)."""
+        faster.  The steps are ordinary training steps; a switch drops the captured programs (they bake the kernel in).
+        The schedule is a function of the number of training steps since the tune began and of nothing else (ADVICE r4:
+        keyed to how often this rank's plan had run, ranks whose allocators handed out different batch pointers could
+        leave a phase at different steps and meet the closing reduction at different places of their collective
+        streams): DP_TUNE_WARM steps untimed -- eager run, capture and the first replays of every expert's program --
+        then DP_TUNE_STEPS timed ones, per kernel family; the closing MAX over the ranks is a HOST collective (gloo) at
+        a step index every rank reaches, behind a device synchronisation: no stream collective is outstanding there."""
         t = self._tune
         st = torch.cuda.current_stream()
-        if t["phase"] == "warm":
-            t["steady"] = t["steady"] + 1 if plan._runs >= 3 else 0  # (a third run is a replay of a captured program)
-            if t["steady"] >= self.DP_TUNE_STEADY:
-                t["ev"] = torch.cuda.Event(enable_timing=True)
-                t["ev"].record(st)
-                t.update(phase="measure", count=0)
+        t["step"] += 1
+        if t["step"] < self.DP_TUNE_WARM:
             return
-        t["count"] += 1
-        if t["count"] < self.DP_TUNE_STEPS:
+        if t["step"] == self.DP_TUNE_WARM:
+            t["ev"] = torch.cuda.Event(enable_timing=True)
+            t["ev"].record(st)
+            return
+        if t["step"] < self.DP_TUNE_WARM + self.DP_TUNE_STEPS:
             return
         end = torch.cuda.Event(enable_timing=True)
         end.record(st)
@@ -320,14 +330,16 @@ class StepEngine:
         if t["kind"] == "dynamic":
             self.lib.mmvae_gemm_set_x3w(1)
             self._drop_train_plans()
-            t.update(phase="warm", kind="persistent", steady=0, count=0, ev=None)
+            t.update(kind="persistent", step=0, ev=None)
             return
-        both = torch.tensor([self.dp_tuned["dynamic"], self.dp_tuned["persistent"]], dtype=torch.float64, device=self.device)
-        if mdist.world_size() > 1:
-            import torch.distributed as tdist
+        import numpy as np
 
-            tdist.all_reduce(both, op=tdist.ReduceOp.MAX)
-        d, p = (float(v) for v in both.cpu())
+        both = np.array([int(self.dp_tuned["dynamic"] * 1e3), int(self.dp_tuned["persistent"] * 1e3)], dtype=np.int32)
+        if mdist.world_size() > 1:
+            self.flush()
+            torch.cuda.synchronize(self.device)
+            mdist.host_all_reduce_max(both)  # microseconds per step, the slowest rank's
+        d, p = float(both[0]) / 1e3, float(both[1]) / 1e3
         self.dp_tuned.update(dynamic=d, persistent=p, choice="persistent" if p <= d else "dynamic")
         if self.dp_tuned["choice"] == "dynamic":
             self.lib.mmvae_gemm_set_x3w(0)
@@ -396,6 +408,12 @@ class StepEngine:
             p.release()
         self._plans = {}
         self._ptr_seen.clear()
+        # sharded expert updates leave (world - 1) / world of the Adam moments on other ranks: gather them while the
+        # process group is alive, so that a later state_dict() -- on one rank only, or after destroy_process_group() -- is
+        # local (COLLECTIVE under data parallelism: every rank closes its engine, like every rank takes every step)
+        if mdist.collectives_active():
+            for opt in self.model.optimizers():
+                opt.sync_sharded_state()
 
     def flush(self) -> None:
         """Make the current stream wait for every deferred expert update (before parameters are read elsewhere)."""
@@ -408,7 +426,8 @@ class StepEngine:
     def _enc_planes(self, l0_in: int, l0_out: int, has_bn: bool, B: int, K: int, train: bool, iwae: bool) -> bool:
         """Does a program of this geometry read the operands of its first-layer weight gradient from bf16 planes?  (Then
         nothing reads the batch in 16-byte groups across row ends or beyond its last row: _select_input.)"""
-        return bool(self.planes and train and K == 1 and not iwae and self.lib.mmvae_gemm_get_precision() == 1
+        # (K-sample programs run the encoder once over the B cells: the same product as at K = 1)
+        return bool(self.planes and train and not iwae and self.lib.mmvae_gemm_get_precision() == 1
                     and l0_out % 8 == 0 and has_bn
                     and self.lib.mmvae_gemm_planes_supported(TN, l0_out, l0_in, (B + 31) // 32 * 32, 1, 1, 1))
 
@@ -664,7 +683,7 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
         # reconstruction epilogue -- epilogue +6 us, chain +12 us, no gain; planes of x for the first forward GEMM --
         # the split pass in front of it costs 17 us for 8 us gained.)
         l0, lastl = self.enc_layers[0], self.dec_layers[-1]
-        pl_on = bool(eng.planes and train and K == 1 and not self.iwae and lib.mmvae_gemm_get_precision() == 1)
+        pl_on = bool(eng.planes and train and not self.iwae and lib.mmvae_gemm_get_precision() == 1)
         # (any gene count: the planes of x get a leading dimension rounded up to 8, zero columns in between)
         self.pl_enc = eng._enc_planes(l0.n_in, l0.n_out, l0.bn is not None, B, K, train, self.iwae)
         self.xp = _PlaneBuf(eng, f"xp.{l0.n_in}", B, l0.n_in) if self.pl_enc else None
@@ -672,6 +691,14 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
         self.pl_dec_h = bool(pl_on and lastl.n_in % 8 == 0 and len(self.dec_layers) >= 2
                              and lib.mmvae_gemm_planes_supported(TN, G, lastl.n_in, self.kpad(R), 1, 0, 1))
         self.hp = _PlaneBuf(eng, f"hp.{lastl.n_in}", R, lastl.n_in) if self.pl_dec_h else None
+        # (r5) K-sample programs (R = K B rows, 20 row tiles of 256 at C3): the last layer's WEIGHTS pre-split once per step
+        # for the input-gradient product dP . W, whose tiles would otherwise split each weight tile R / 256 times
+        # (tools/ab_planes.py at 5120 rows: 944 -> 873 us for a 31 us split pass).  Not the reconstruction launch: with
+        # both operands DMA'd it is no faster (1 007 -> 1 034 us: its stagers are not what it waits for), and not at
+        # K = 1 (512 rows: -5 us against the 31 us pass).
+        self.pl_dec_w = bool(pl_on and R >= 2048 and lastl.n_in % 8 == 0
+                             and lib.mmvae_gemm_planes_supported(NN, R, lastl.n_in, (G + 31) // 32 * 32, 0, 0, 1))
+        self.wp = _PlaneBuf(eng, f"wp.{G}.{lastl.n_in}", G, lastl.n_in) if self.pl_dec_w else None
         if self.pl_enc:
             # The split of x is piggy-backed on the tail launches of the forward chain (extra workgroups of
             # fc_fwd_apply), a third of the rows each: those launches are latency-bound (5-13 us with the memory system
@@ -681,6 +708,11 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             xpp, xld, xps = self.xp.args()
             self._x_split_jobs = [(min(per, B - r0), l0.n_in, _p(x) + 4 * r0 * ldx, ldx, xpp + 2 * r0 * xld, xld, xps)
                                   for r0 in range(0, B, per)]
+        if self.pl_dec_w:  # the weights' split takes the tails first (82 MB at C3 against x's 41): three row ranges
+            per = (G + 2) // 3
+            wpp, wld, wps = self.wp.args()
+            self._x_split_jobs = [(min(per, G - r0), lastl.n_in, _p(lastl.W) + 4 * r0 * lastl.n_in, lastl.n_in,
+                                   wpp + 2 * r0 * wld, wld, wps) for r0 in range(0, G, per)] + getattr(self, "_x_split_jobs", [])
         # ---- forward, encoder side
         cur, ld = x, ldx
         for i, l in enumerate(self.enc_layers):
@@ -761,8 +793,8 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
         for i, l in enumerate(self.dec_layers[:-1]):
             cur = self.fwd_layer(f"{self.eid}.dec{i}.K{K}", l, cur, ld, R, training=train,
                                  mask_stream=len(self.enc_layers) + i,
-                                 planes_out=self.hp if (self.hp is not None and i == len(self.dec_layers) - 2) else None,
-                                 split_job=None if (self.hp is not None and i == len(self.dec_layers) - 2)
+                                 planes_out=self.hp if (self.hp is not None and K == 1 and i == len(self.dec_layers) - 2) else None,
+                                 split_job=None if (self.hp is not None and K == 1 and i == len(self.dec_layers) - 2)
                                  else self._next_x_split_job(l, R))
             ld = l.n_out
         for job in getattr(self, "_x_split_jobs", []):  # tails the chain did not have: passes of their own
@@ -876,6 +908,8 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             dw_inp = eng.buf(f"h_weighted.{last.n_in}", (R, last.n_in))
             dw_ld = last.n_in
             self._emit(lib.mmvae_scale_rows, R, last.n_in, _p(last.inp), last.ld_inp, _p(self.w), _p(dw_inp), dw_ld)
+            if self.hp is not None:  # B of the weight gradient as planes: of the SCALED activations (a 21 + 31 MB pass at C3)
+                self._emit(lib.mmvae_split_planes_f32, R, last.n_in, _p(dw_inp), dw_ld, *self.hp.args())
         dw_pl = (None, self.hp) if self.pl_dec_h else None
         # (adversaries on the first branch stream: the capped weight gradient beside the chain takes the second one)
         dw_stream = eng.side_stream2 if adv_aside else None
@@ -928,7 +962,8 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             self.gemm(TN, G, last.n_in, self.kpad(R), self.dP, self.ldp, dw_inp, dw_ld, last.gW, last.n_in, side=True,
                       planes=dw_pl)
             self._probe_next = "dec_l2_dx" if big else None
-            S = self.gemm_raw(NN, R, last.n_in, self.ldp, self.dP, self.ldp, last.W, last.n_in)
+            S = self.gemm_raw(NN, R, last.n_in, self.ldp, self.dP, self.ldp, last.W, last.n_in,
+                              planes=(None, self.wp) if self.pl_dec_w else None)
             self._probe_next = None
         rest = self.dec_layers[:-1]
         for j in range(len(rest) - 1, -1, -1):

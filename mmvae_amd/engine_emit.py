@@ -655,7 +655,7 @@ class PlanEmit:
         mine = self.eng.buf(f"shard.sq.{id(opt)}", (1,))
         allsq = self.eng.buf(f"shard.allsq.{id(opt)}", (W,))
         self.shard_info = dict(per=per, lo=lo, n_loc=n_loc, mine=mine, allsq=allsq, sim=sim)
-        opt.sharded = True
+        opt.sharded = not sim  # (the timing diagnostics of --sim-world exchange nothing: there is nothing to gather back)
         self._cut(("rs_" + exchange, opt))
         if n_loc > 0:
             np_loc = int(lib.mmvae_sqnorm_partials(n_loc))

@@ -82,7 +82,8 @@ class PlanRun:
                 elif kind == "ag_norm":
                     if live:
                         tdist.all_gather_into_tensor(si["allsq"], si["mine"], group=red.group)
-                    else:  # (no peers to hear from: the slice's own sum)
+                    else:  # (no peers to hear from: the slice's own sum; adam_prepare adds up all `world` words)
+                        si["allsq"].zero_()
                         si["allsq"][:1].copy_(si["mine"])
                 elif live:
                     full = a.data_full[:si["per"] * W]

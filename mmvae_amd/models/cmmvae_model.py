@@ -172,6 +172,15 @@ class CMMVAEModel(BaseModel):
         if self._engine:
             self._engine.flush()
 
+    def gather_optimizer_state(self) -> None:
+        """Under data parallelism the engine updates each expert arena sharded (this rank's slice of the Adam moments
+        only): gather them.  COLLECTIVE -- call it on EVERY rank before a checkpoint that only one rank writes
+        (`if rank == 0: torch.save(opt.state_dict())`); HipAdam.state_dict() itself is collective too once an
+        optimiser has taken sharded steps.  No-op on one rank."""
+        self._flush_engine()
+        for opt in self.optimizers():
+            opt.sync_sharded_state()
+
     def state_dict(self, *args, **kwargs):
         self._flush_engine()  # deferred expert updates must have landed before parameters are read
         return super().state_dict(*args, **kwargs)

@@ -273,6 +273,7 @@ def decoder_recon(
     h_planes: Optional["Planes"] = None,
     dP_planes: Optional["Planes"] = None,
     h_kpad: bool = False,
+    W_planes: Optional["Planes"] = None,
 ):
     """Fused last decoder layer + squared error.  h [R,H] (R = K*B rows), W [G,H], x [B,G].
     h_kpad: h is a view of a buffer whose columns H .. round_up(H, 32) - 1 are ZERO and W's rows may be read that far
@@ -298,6 +299,17 @@ def decoder_recon(
     lddp = _mat(dP, "dP")[2] if dP is not None else 0
     if col_part is not None and (tuple(col_part.shape) != (lib.mmvae_recon_row_tiles(R), G) or not col_part.is_contiguous()):
         raise ValueError(f"decoder_recon: col_part must be a contiguous [{lib.mmvae_recon_row_tiles(R)}, {G}] tensor")
+    if W_planes is not None:  # weights pre-split as well (mmvae_decoder_recon_wplanes_f32; taken together with h_planes)
+        if dP_planes is not None:
+            raise ValueError("decoder_recon: W_planes and dP_planes have no common entry point")
+        hp, wp = h_planes, W_planes
+        rc = lib.mmvae_decoder_recon_wplanes_f32(
+            R, B, G, H, _ptr(h), ldh, hp.ptr() if hp else None, hp.ld if hp else 0, hp.plane_stride if hp else 0,
+            _ptr(W), ldw, wp.ptr(), wp.ld, wp.plane_stride, _ptr(bias), _ptr(x), ldx, _ptr(xhat), ldxh, _ptr(dP), lddp,
+            _ptr(se_part), _ptr(col_part), _stream(),
+        )
+        _lib.check(rc, "mmvae_decoder_recon_wplanes_f32")
+        return xhat, dP, se_part
     if h_planes is not None or dP_planes is not None:
         hp, dpp = h_planes, dP_planes
         rc = lib.mmvae_decoder_recon_planes_f32(

@@ -168,22 +168,31 @@ class HipAdam(torch.optim.Optimizer):
             self.partials = torch.empty(max(ops.sqnorm_partials(self.arena.numel), 1), dtype=torch.float32, device=dev)
 
     def sync_sharded_state(self) -> None:
-        """All-gather the Adam moments after sharded steps (collective: every rank must call it at the same point)."""
+        """All-gather the Adam moments after sharded steps.  COLLECTIVE: every rank of the reducer's group must call it at
+        the same point of its program -- and so must state_dict() / step() of an optimiser that has taken sharded steps
+        (a rank-0-only `torch.save(opt.state_dict())` under data parallelism hangs: gather on every rank first, e.g.
+        through StepEngine.close() or CMMVAEModel.gather_optimizer_state(), then save on one).  Raises when the moments
+        are sharded and the gather cannot run any more (process group destroyed): a checkpoint written then would hold
+        stale moments for (world - 1) / world of the arena."""
         if not self.sharded:
             return
-        self.sharded = False
         if not mdist.collectives_active():
-            return
+            raise RuntimeError("HipAdam.sync_sharded_state: this optimiser took sharded data-parallel steps and the process "
+                               "group is gone -- the Adam moments of the other ranks' slices are stale here.  Gather them "
+                               "(engine.close() / sync_sharded_state() on every rank) BEFORE destroy_process_group().")
+        group = self.reducer.group if self.reducer is not None else None
+        world = torch.distributed.get_world_size(group)
+        rank = torch.distributed.get_rank(group)
         a = self.arena
-        sh = a.shard(mdist.world_size(), mdist.rank())
-        per, lo, n_loc = sh
+        per, lo, n_loc = a.shard(world, rank)
         dev = a.data.device
         for t in (a.exp_avg, a.exp_avg_sq):
-            full = torch.zeros(per * mdist.world_size(), dtype=torch.float32, device=dev)
+            full = torch.zeros(per * world, dtype=torch.float32, device=dev)
             mine = torch.zeros(per, dtype=torch.float32, device=dev)
             mine[:n_loc] = t[lo:lo + n_loc]
-            torch.distributed.all_gather_into_tensor(full, mine)
+            torch.distributed.all_gather_into_tensor(full, mine, group=group)
             t.copy_(full[:a.numel])
+        self.sharded = False
 
     # ---- Lightning-style clipping hook: remembered, applied inside step()
     def set_clip(self, max_norm: Optional[float]) -> None:

@@ -42,6 +42,31 @@ def synthetic_metadata(B: int, seed: int = 1234, classes: Optional[Dict[str, int
                          for c, n in classes.items()})
 
 
+def synthetic_labelled_batch(B: int, G: int, seed: int = 1234, device="cpu", classes: Optional[Dict[str, int]] = None,
+                             n_patterns: int = 64, effect: float = 0.75):
+    """(x [B, G], metadata) whose labels are a FUNCTION OF THE CELL (r5; the adversarial BASELINE config): every cell has a
+    donor d, the donor's expression pattern (one of `n_patterns` per-gene log-fold-change vectors, d % n_patterns) scales
+    its Poisson rates, and donor_id = d, dataset_id / assay / sex = d modulo the class counts.  The discriminators of
+    `gradient_reversal_domain_classifier` (cmmvae_model.py:103-136) then have signal to learn -- as on real data -- and
+    the game against the gradient-reversed encoder stays bounded; with labels independent of the cells
+    (synthetic_metadata) the discriminator can only memorise, the generator phase drives its loss up without limit and
+    the step runs on inf / NaN within tens of steps (profiles/r5_c4_stability.txt).  Same value distribution as
+    synthetic_counts (counts -> log1p(1e4 c / rowsum))."""
+    classes = classes or ADV_CLASSES
+    order = list(classes)
+    n_top = max(classes.values())
+    g = torch.Generator().manual_seed(seed)
+    gp = torch.Generator().manual_seed(4242 + G)  # the gene rates and the donors' patterns belong to the modality
+    lam = 0.15 * torch.exp(torch.randn(G, generator=gp))
+    patterns = torch.randn(n_patterns, G, generator=gp)
+    donors = torch.randint(0, n_top, (B,), generator=g)
+    rates = lam[None, :] * torch.exp(effect * patterns[donors % n_patterns] - 0.5 * effect * effect)
+    c = torch.poisson(rates, generator=g)
+    x = torch.log1p(1e4 * c / c.sum(1, keepdim=True).clamp_min(1.0))
+    meta = pd.DataFrame({cond: [f"{cond}_{int(d) % classes[cond]}" for d in donors] for cond in order})
+    return x.to(device), meta
+
+
 def write_label_dir(root: str, classes: Optional[Dict[str, int]] = None) -> str:
     """`<root>/human/unique_expression_<cond>.csv` files as Adversarial expects (components.py:656)."""
     classes = classes or ADV_CLASSES
@@ -84,8 +109,15 @@ def build_model(experts: Dict[str, int], *, latent_dim: int = 128, h1: int = 102
                        autograd_config=AutogradConfig(clip(), clip(), clip()), use_engine=use_engine)
 
 
-def flops_per_cell(G: int, K: int = 1, h1: int = 1024, h2: int = 512, hv: int = 256, Z: int = 128) -> float:
-    """Algorithmic FLOPs per cell of one training step: fwd + dW everywhere + dX except the input layer."""
+def flops_per_cell(G: int, K: int = 1, h1: int = 1024, h2: int = 512, hv: int = 256, Z: int = 128,
+                   mode: str = "train") -> float:
+    """Algorithmic FLOPs per cell of one step (SURVEY 8d).  train: fwd + dW everywhere + dX except the input layer;
+    validate: the forward pass alone (encoder + decoder, ONE sample: the forward-only programs draw one rsample whatever
+    K is); predict: the encoder alone (the program ends at z)."""
     E = G * h1 + h1 * h2 + h2 * hv + 2 * hv * Z
     D = Z * hv + hv * h2 + h2 * h1 + h1 * G
+    if mode == "validate":
+        return 2.0 * (E + D)
+    if mode == "predict":
+        return 2.0 * E
     return 6.0 * E - 2.0 * G * h1 + 6.0 * K * D

@@ -61,7 +61,21 @@ def recon(planes):
 
 
 cases["k3 dec-L2 fwd+recon NT"] = (lambda: recon(False), lambda: recon(True))
-splits = {"split x [BxG]": lambda: ops.split_planes(x, xp), "split dY [Bx1024]": lambda: ops.split_planes(dY1, dYp)}
+# (r5) the weights pre-split as well: the reconstruction kernel whose stagers only move planes, and dX with W4 planes
+W4p = ops.split_planes(W4)
+
+
+def recon_w():
+    cp = torch.zeros(nrt, G, device=dev)
+    _, dPo, se = ops.decoder_recon(hrelu, W4, b4, x, want_xhat=False, col_part=cp, h_planes=hrp, W_planes=W4p)
+    return dPo, se, cp
+
+
+cases["k3w recon NT h+W planes"] = (lambda: recon(False), recon_w)
+cases["k4c dec-L2 dX NN W planes"] = (lambda: ops.gemm_planes(NN, dP, W4, raw_slabs=True),
+                                      lambda: ops.gemm_planes(NN, dP, None, b_planes=W4p, raw_slabs=True))
+splits = {"split x [BxG]": lambda: ops.split_planes(x, xp), "split dY [Bx1024]": lambda: ops.split_planes(dY1, dYp),
+          "split W4 [Gx1024]": lambda: ops.split_planes(W4, W4p)}
 
 
 def flat(o):
