@@ -592,6 +592,10 @@ def main():
         if eng is not None and getattr(eng, "dp_tuned", None):
             out["dp_kernels"] = dict(eng.dp_tuned, note="ms per step of the two GEMM kernel families under the exchange, "
                                      "timed on this run's first replayed steps (max over ranks); the faster one ran the timed region")
+        if eng is not None and getattr(eng, "streams_probe", None):
+            # engine.concurrent_streams: how many of the exchange program's three streams (bulk exchange, small exchanges,
+            # the adversaries' lane) were OBSERVED to run beside the main stream on this device
+            out["dp_streams"] = eng.streams_probe
         if dp_diag is not None:
             dp_diag["ms_exposed_exchange"] = el / a.steps * 1e3 - dp_diag["ms_per_step_without_transfers"]
             out["data_parallel"] = dp_diag

@@ -276,6 +276,9 @@ class StepEngine:
             # the main stream's segment ended (untraced markers), on another stream 400 us earlier.  Take streams that
             # were SEEN to run beside the current stream.
             got = concurrent_streams(self.device, 3)
+            # (reported by bench.py: a first multi-GPU run explains itself -- fewer than 3 observed means some stream of the
+            # exchange program shares a hardware queue with the main stream and its work will run behind it, not beside it)
+            self.streams_probe = {"wanted": 3, "observed_concurrent": len(got)}
             self.comm_stream, self.small_stream, self.lane_stream = (got + [torch.cuda.Stream(device=self.device)
                                                                             for _ in range(3)])[:3]
 

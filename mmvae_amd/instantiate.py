@@ -26,13 +26,42 @@ def resolve(path: str):
     return getattr(importlib.import_module(module), name)
 
 
+def _coerce_numbers(cls, kwargs: dict) -> dict:
+    """jsonargparse converts values by the constructor's type hints; PyYAML alone leaves `warmup_steps: 1e4` (no dot: not
+    a YAML 1.1 float) a STRING -- configs/model/configV3.yaml:8-9, parallel/adversarial-conditional.yaml.  Strings that
+    arrive at a parameter annotated float / int (also Optional[...]) are converted the same way."""
+    import inspect
+    import typing
+
+    try:
+        params = inspect.signature(cls.__init__).parameters
+    except (TypeError, ValueError):
+        return kwargs
+    for name, value in kwargs.items():
+        if not isinstance(value, str) or name not in params:
+            continue
+        ann = params[name].annotation
+        if isinstance(ann, str):
+            ann = {"float": float, "int": int, "Optional[float]": float, "Optional[int]": int}.get(ann.replace("typing.", ""), ann)
+        elif typing.get_origin(ann) is typing.Union:
+            args = [a for a in typing.get_args(ann) if a is not type(None)]
+            ann = args[0] if len(args) == 1 else ann
+        if ann is float or ann is int:
+            try:
+                number = float(value)
+            except ValueError:
+                continue
+            kwargs[name] = int(number) if (ann is int and number.is_integer()) else number
+    return kwargs
+
+
 def build(node: Any, key: str = "") -> Any:
     """Recursively turn YAML nodes into objects."""
     if isinstance(node, dict):
         if "class_path" in node:
             cls = resolve(node["class_path"])
             kwargs = {k: build(v, k) for k, v in (node.get("init_args") or {}).items()}
-            return cls(**kwargs)
+            return cls(**_coerce_numbers(cls, kwargs))
         return {k: build(v, k) for k, v in node.items()}
     if isinstance(node, list):
         return [build(v, key) for v in node]

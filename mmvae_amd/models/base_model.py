@@ -18,7 +18,8 @@ from ..modules.base import KLAnnealingFn
 from ..modules.base import init as _init  # noqa: F401  (module import keeps `init` reachable like the reference)
 from ..modules.base.init import he_init_weights
 
-try:  # pragma: no cover - Lightning is not installed in the build image
+try:  # Lightning is not installed in the build image: tests/test_lightning_surface.py drives this branch through a
+    # stand-in `lightning.pytorch` (tests/fake_lightning) -- the calls the step makes, not Lightning's own machinery
     import lightning.pytorch as pl
 
     _Base = pl.LightningModule
@@ -103,30 +104,67 @@ class BaseModel(_Base):
         def manual_backward(self, loss, *args, **kwargs):
             loss.backward(*args, **kwargs)
 
-        def clip_gradients(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm=None):
-            if gradient_clip_val is None:
-                return
-            algorithm = gradient_clip_algorithm or "norm"
-            if algorithm not in ("norm", "value"):
-                raise ValueError(f"gradient_clip_algorithm {algorithm!r}: 'norm' or 'value' (config.py:8)")
-            if hasattr(optimizer, "set_clip"):  # fused into HipAdam.step()
-                if algorithm == "norm":
-                    optimizer.set_clip(float(gradient_clip_val))
-                else:
-                    optimizer.set_clip_value(float(gradient_clip_val))
-            else:
-                params = [p for g in optimizer.param_groups for p in g["params"]]
-                if algorithm == "norm":
-                    torch.nn.utils.clip_grad_norm_(params, float(gradient_clip_val))
-                else:
-                    torch.nn.utils.clip_grad_value_(params, float(gradient_clip_val))
-
         @property
         def device(self):
             try:
                 return next(self.parameters()).device
             except StopIteration:
                 return torch.device("cpu")
+
+    else:  # ------------------------------------------------------------- under a real LightningModule base
+
+        def optimizers(self, use_pl_optimizer: bool = False):
+            """The RAW optimisers, always as a list.  Lightning's default hands out LightningOptimizer wrappers that carry
+            a COPY of the optimiser's attribute dictionary and forward step() to the wrapped object: state this build sets
+            on the wrapper (the fused clip's max_grad_norm, the cached gradient norm) would never reach the HipAdam that
+            steps.  The step is manual optimisation (automatic_optimization = False), which needs nothing of the wrapper."""
+            opts = super().optimizers(use_pl_optimizer=False)
+            return list(opts) if isinstance(opts, (list, tuple)) else [opts]
+
+        @property
+        def logged(self) -> dict:
+            """name -> latest logged value, as in stand-alone mode (tests and mmvae_amd.trainer read it; Lightning's own
+            logger connector receives the same values through log / log_dict)."""
+            return self.__dict__.setdefault("_logged", {})
+
+        def log(self, name, value, **kwargs):
+            self.logged[name] = value
+            if getattr(self, "_trainer", None) is not None or getattr(self, "_fabric", None) is not None:
+                try:
+                    super().log(name, value, **kwargs)
+                except Exception:  # noqa: BLE001  (outside a Trainer loop Lightning refuses to log: the dict still has it)
+                    pass
+
+        def log_dict(self, d, **kwargs):
+            self.logged.update(d)
+            if getattr(self, "_trainer", None) is not None or getattr(self, "_fabric", None) is not None:
+                try:
+                    super().log_dict(d, **kwargs)
+                except Exception:  # noqa: BLE001
+                    pass
+
+    def clip_gradients(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm=None):
+        """`LightningModule.clip_gradients(optimizer, val, algorithm)` as the reference calls it (cmmvae_model.py:126-129,
+        203-209), for BOTH bases.  A HipAdam folds the clip into its fused update (set_clip / set_clip_value: the gradient
+        arena was gathered when its norm was logged, and step() reuses it -- clipping `p.grad` afterwards, as Lightning's
+        precision plugin would, never reaches the arena); any other optimiser gets torch's clip_grad_norm_ / _value_,
+        which is what Lightning does at precision 32."""
+        if gradient_clip_val is None:
+            return
+        algorithm = gradient_clip_algorithm or "norm"
+        if algorithm not in ("norm", "value"):
+            raise ValueError(f"gradient_clip_algorithm {algorithm!r}: 'norm' or 'value' (config.py:8)")
+        if hasattr(optimizer, "set_clip"):  # fused into HipAdam.step()
+            if algorithm == "norm":
+                optimizer.set_clip(float(gradient_clip_val))
+            else:
+                optimizer.set_clip_value(float(gradient_clip_val))
+        else:
+            params = [p for g in optimizer.param_groups for p in g["params"]]
+            if algorithm == "norm":
+                torch.nn.utils.clip_grad_norm_(params, float(gradient_clip_val))
+            else:
+                torch.nn.utils.clip_grad_value_(params, float(gradient_clip_val))
 
     # ------------------------------------------------------------------ shared helpers (same names as the reference)
     def init_weights(self):

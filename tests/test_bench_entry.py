@@ -43,6 +43,20 @@ def test_plain_launch_with_two_ranks_prints_one_line():
     assert again["last_losses"] == b["last_losses"]
 
 
+def test_plain_launch_with_eight_ranks_rehearses_the_scaling_run():
+    """The driver's N = 8 launch shape (one rank per GPU of a node), rehearsed on the gloo backend with CPU plumbing:
+    eight ranks rendezvous, exchange gradients every step, agree on the timing (max over ranks) and rank 0 alone prints
+    the line -- the world size the first real 8-GPU run will have.  Never a measurement."""
+    r = _run("--gpus", "8", "--steps", "2", "--warmup", "1", timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    (line,) = _json_lines(r.stdout)
+    assert REQUIRED <= set(line)
+    assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 128 * 8 and line["config"]["parallelism"] == "dp8"
+    assert line["dist_backend"] == "gloo" and line["rccl_ranks"] == 0 and line["scaling"] == "weak"
+    assert abs(line["value"] - 128 * 8 * 2 / (line["ms_per_step"] * 2e-3)) <= 1e-6 * line["value"]
+    assert line["finite"]["last_losses"] is True
+
+
 def test_a_failing_rank_fails_the_launch():
     r = _run("--gpus", "2", "--steps", "1", "--warmup", "0", "--config", "c9")
     assert r.returncode != 0 and not _json_lines(r.stdout)
