@@ -54,6 +54,7 @@ class EngineSettings:
     side_dw2: int = 185          # MMVAE_SIDE_DW2: cap of the encoder's weight gradient beside the shared VAE's optimiser
     side_dw_dp: int = 125        # MMVAE_SIDE_DW_DP: that branch inside the exchange (data-parallel) program; 0 = in order
     side_dw_any: bool = False    # MMVAE_SIDE_DW_ANY=1: fork outside the measured geometry too
+    prefetch: int = 128          # MMVAE_PREFETCH: workgroup cap of the NEXT step's first forward GEMM beside this step's forward chain (software pipelining across steps, needs the caller's hint); 0 = off
     adv_fused: bool = True       # MMVAE_ADV_FUSED=0: the per-layer adversary program (the path of adversaries with BatchNorm)
     adv_aside: int = 2           # MMVAE_ADV_ASIDE: 0 the fused adversary passes in order; 1 on the branch stream; 2 + the decoder's weight gradient on a second branch from where the first is joined
     dp_overlap: Optional[bool] = None  # MMVAE_DP_OVERLAP: None = overlapped exchange whenever gradients are exchanged
@@ -74,7 +75,8 @@ class EngineSettings:
             conditionals=e("MMVAE_ENGINE_CONDITIONALS", "1") != "0", graphs=e("MMVAE_NO_GRAPH", "0") == "0",
             planes=e("MMVAE_PLANES", "1") != "0", side_dw=int(e("MMVAE_SIDE_DW", "125")),
             side_dw2=int(e("MMVAE_SIDE_DW2", "185")), side_dw_dp=int(e("MMVAE_SIDE_DW_DP", "125")),
-            side_dw_any=e("MMVAE_SIDE_DW_ANY", "0") != "0", adv_fused=e("MMVAE_ADV_FUSED", "1") != "0",
+            side_dw_any=e("MMVAE_SIDE_DW_ANY", "0") != "0", prefetch=int(e("MMVAE_PREFETCH", "128")),
+            adv_fused=e("MMVAE_ADV_FUSED", "1") != "0",
             adv_aside=int(e("MMVAE_ADV_ASIDE", "2")),
             dp_overlap=None if ov == "" else ov != "0", dp_shard=e("MMVAE_DP_SHARD", "1") != "0", dp_kernels=kernels,
             dp_sim_world=int(e("MMVAE_DP_SIM_WORLD", "0")), dp_autotune_force=e("MMVAE_DP_AUTOTUNE_FORCE", "0") != "0",
@@ -221,6 +223,10 @@ class StepEngine:
         self._configure_parallel()
         self._sig = self._signature()
         self._pending: Dict[str, torch.cuda.Event] = {}
+        # software pipelining across steps: what the last training program computed ahead for the next one
+        # (training_step, "prefetch"): None or a dict(eid, ptr, shape, stride, version, w_version, slabs)
+        self._prefetched: Optional[dict] = None
+        self.prefetch_stats = {"issued": 0, "consumed": 0, "discarded": 0}
 
     def _configure_parallel(self) -> None:
         """Overlapped data parallelism (default whenever gradients are exchanged).  The active expert's parameters are
@@ -302,6 +308,7 @@ class StepEngine:
                 p.release()
         self._plans = {k: p for k, p in self._plans.items() if not str(k[0]).startswith("train")}
         self._ptr_seen.clear()
+        self._prefetched = None
 
     DP_TUNE_WARM, DP_TUNE_STEPS = 12, 12
 
@@ -521,9 +528,52 @@ class StepEngine:
         return plan.z[0].clone()
 
     # --------------------------------------------------------------------------------------------------- step
-    def training_step(self, x: torch.Tensor, metadata, expert_id: str) -> None:
+    # ------------------------------------------------------------------- software pipelining across steps (r5)
+    # The first forward GEMM of a step -- x W1^T of the active expert, 21 GFLOP at C2 -- depends on that step's batch and
+    # on weights the expert's LAST update left (modalities alternate: another expert trains in between).  When the caller
+    # says which batch comes next (CMMVAEModel.hint_next_batch; mmvae_amd.trainer and bench.py look one batch ahead), this
+    # step computes the next step's product as filler work: on the branch stream, capped to `prefetch` workgroups, beside
+    # its own forward chain -- ~125 us of latency-bound launches that leave most of the chip idle -- into split-K slabs of
+    # the next expert's own.  The next step's program then starts at its first layer's tail.  The same kernel on the same
+    # operands: results are bit-identical to the unpipelined program (tested).  Conditions: single-rank in-order program
+    # of the measured geometry (the forked C2 program), a DIFFERENT expert next (the same one's weights are about to be
+    # updated), the hinted tensor unchanged when its step comes (pointer, shape, torch version counter) and the next
+    # expert's weights not rewritten from the torch side in between (version counter: load_state_dict) -- otherwise the
+    # next step computes the product itself and the slabs are dropped.
+    def _prefetch_target(self, plan_eid: str, B: int, K: int, iwae: bool, next_batch):
+        """(expert id, tensor) this step may compute ahead for, or None."""
+        st = self.settings
+        if (next_batch is None or not st.prefetch or not self.side_dw or self.overlap or self.world != 1
+                or self.side_stream is None or K != 1 or iwae):
+            return None
+        x_n, eid_n = next_batch
+        m = self.model.module
+        if eid_n == plan_eid or eid_n not in m.experts or len(m.adversarials) > 0 or getattr(m.vae, "conditionals", None) is not None:
+            return None
+        if (not torch.is_tensor(x_n) or x_n.layout != torch.strided or not x_n.is_cuda or x_n.dtype != torch.float32
+                or x_n.dim() != 2 or x_n.stride(1) != 1):
+            return None
+        l0 = m.experts[eid_n].encoder.fc_layers[0]
+        if not hasattr(l0, "bn") or x_n.shape[1] != l0.lin.in_features:
+            return None
+        return eid_n, x_n
+
+    def _take_prefetched(self, eid: str, x: torch.Tensor):
+        """The slabs computed ahead for this step, when they are (still) the product of this batch and these weights."""
+        pf, self._prefetched = self._prefetched, None
+        if pf is None:
+            return None
+        w = self.model.module.experts[eid].encoder.fc_layers[0].lin.weight if eid in self.model.module.experts else None
+        ok = (pf["eid"] == eid and w is not None and pf["ptr"] == x.data_ptr() and pf["shape"] == tuple(x.shape)
+              and pf["stride"] == x.stride(0) and pf["version"] == x._version and pf["w_version"] == w._version)
+        self.prefetch_stats["consumed" if ok else "discarded"] += 1
+        return pf["slabs"] if ok else None
+
+    def training_step(self, x: torch.Tensor, metadata, expert_id: str, next_batch=None) -> None:
+        """next_batch: (x of the next training step, its expert id) or None -- see "software pipelining" above."""
         model = self.model
         self._check_signature()
+        x_arg = x
         x = self._dense_f32(x)
         enc_mod = model.module.vae.encoder
         expert = model.module.experts[expert_id]
@@ -535,12 +585,20 @@ class StepEngine:
         iwae = getattr(enc_mod, "elbo_mode", "analytic") == "iwae"
         l0 = expert.encoder.fc_layers[0]
         planes = self._enc_planes(l0.lin.in_features, l0.lin.out_features, hasattr(l0, "bn"), B, K, True, iwae)
-        key, x_in = self._select_input(x, ("train-iwae" if iwae else "train", expert_id, B, K, explicit),
+        ahead = self._take_prefetched(expert_id, x) if x is x_arg else None  # slabs the previous step left for this one
+        if x is not x_arg:
+            self._prefetched = None
+        target = self._prefetch_target(expert_id, B, K, iwae, next_batch)
+        tsig = (target[0], target[1].data_ptr(), tuple(target[1].shape), target[1].stride(0)) if target else None
+        key, x_in = self._select_input(x, ("train-iwae" if iwae else "train", expert_id, B, K, explicit,
+                                           ahead.data_ptr() if ahead is not None else 0, tsig),
                                        needs_slack=not planes)
         plan = self._plans.get(key)
         if plan is None:
-            plan = _Plan(self, expert_id, B, K, explicit, x_in, iwae=iwae)
+            plan = _Plan(self, expert_id, B, K, explicit, x_in, iwae=iwae, slabs_ahead=ahead, prefetch=target)
             self._plans[key] = plan
+        if target is not None and plan.prefetch_slabs is None:
+            target = None  # (the plan's geometry does not pipeline: _Plan._build)
         self._set_kl_weight()
         if explicit:
             plan.load_explicit_noise(enc_mod, expert)
@@ -555,6 +613,12 @@ class StepEngine:
         ev = plan.run()
         if ev is not None:
             self._pending[expert_id] = ev
+        if target is not None:  # this program has computed the next step's first product
+            x_n = target[1]
+            w_n = model.module.experts[target[0]].encoder.fc_layers[0].lin.weight
+            self._prefetched = dict(eid=target[0], ptr=x_n.data_ptr(), shape=tuple(x_n.shape), stride=x_n.stride(0),
+                                    version=x_n._version, w_version=w_n._version, slabs=plan.prefetch_slabs)
+            self.prefetch_stats["issued"] += 1
         if plan.cond is not None:
             plan.cond.commit()
         model.kl_annealing_fn.step()
@@ -565,9 +629,12 @@ class StepEngine:
 
 class _Plan(PlanEmit, PlanAdversaries, PlanRun):
     def __init__(self, eng: StepEngine, eid: str, B: int, K: int, explicit: bool, x: torch.Tensor, mode: str = "train",
-                 iwae: bool = False):
+                 iwae: bool = False, slabs_ahead: Optional[torch.Tensor] = None, prefetch=None):
         self.eng, self.eid, self.B, self.K, self.explicit = eng, eid, B, K, explicit
         self.mode = mode
+        # software pipelining across steps (StepEngine.training_step): slabs of this step's first forward product that
+        # the previous step computed, and the (expert id, batch) this step computes them for
+        self.slabs_ahead, self.prefetch, self.prefetch_slabs = slabs_ahead, prefetch, None
         self.iwae = bool(iwae) and mode == "train"  # opt-in full-IWAE objective (training programs only)
         self.x = x
         self.R = B * K
@@ -717,14 +784,42 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             self._x_split_jobs = [(min(per, G - r0), lastl.n_in, _p(lastl.W) + 4 * r0 * lastl.n_in, lastl.n_in,
                                    wpp + 2 * r0 * wld, wld, wps) for r0 in range(0, G, per)] + getattr(self, "_x_split_jobs", [])
         # ---- forward, encoder side
+        def emit_prefetch():
+            if self.prefetch is None or not side_dw or not train:
+                return
+            # the NEXT step's first forward product, beside this step's forward chain (joined ahead of the
+            # reconstruction launch, which wants the whole chip)
+            eid_n, x_n = self.prefetch
+            ln = _LayerRef(eng.model.module.experts[eid_n].encoder.fc_layers[0], eng.grad_of, False)
+            Bn = x_n.shape[0]
+            sk_n = self._plan_gemm(NT, Bn, ln.n_out, ln.n_in)
+            if ln.bn is None or 2.0 * Bn * ln.n_out * ln.n_in < 5e9:
+                return
+            self.prefetch_slabs = eng.buf(f"prefetch.slabs.{eid_n}", (sk_n, Bn, ln.n_out))
+            self._probe_next = "enc_l1_fwd"
+            self._side_capped_gemm(NT, Bn, ln.n_out, ln.n_in, x_n, x_n.stride(0), ln.W, ln.n_in, self.prefetch_slabs,
+                                   ln.n_out, eng.settings.prefetch, flags=_lib.GEMM_RAW_SLABS, sk=sk_n)
+            self._probe_next = None
+            self._prefetch_join = True
+
         cur, ld = x, ldx
+        if self.slabs_ahead is not None:
+            # this step's own first product exists already (the previous step computed it): the next step's starts at
+            # once and has the whole forward chain beside it; otherwise it follows this step's own first GEMM
+            emit_prefetch()
         for i, l in enumerate(self.enc_layers):
-            self._probe_next = "enc_l1_fwd" if i == 0 else None
+            ahead = self.slabs_ahead if i == 0 else None
+            if ahead is not None and tuple(ahead.shape) != (self._plan_gemm(NT, B, l.n_out, l.n_in), B, l.n_out):
+                raise _lib.HipLibraryError("engine: slabs computed ahead do not fit this step's first layer")
+            self._probe_next = "enc_l1_fwd" if (i == 0 and ahead is None) else None
             cur = self.fwd_layer(f"{self.eid}.enc{i}" if i < self.n_expert_enc else f"vae.enc{i}", l, cur, ld, B,
-                                 training=train, mask_stream=i, split_job=self._next_x_split_job(l, B))
+                                 training=train, mask_stream=i, split_job=self._next_x_split_job(l, B), slabs_from=ahead)
+            self._probe_next = None
             ld = l.n_out
             if i == 0:
                 self._mark("enc L1 forward done")
+                if self.slabs_ahead is None:
+                    emit_prefetch()
         q, HV = cur, self.enc_layers[-1].n_out
         # ---- heads + reparameterisation
         self.mu = eng.buf("mu", (B, Z))
@@ -803,6 +898,15 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
         for job in getattr(self, "_x_split_jobs", []):  # tails the chain did not have: passes of their own
             self._emit(lib.mmvae_split_planes_f32, *job)
         self._x_split_jobs = []
+        if getattr(self, "_prefetch_join", False) and os.environ.get("MMVAE_PREFETCH_JOIN", "0") == "1":
+            # (diagnostics) join the next step's product ahead of the reconstruction launch.  Default: no join here -- a
+            # cross-stream join inside the captured program costs ~30 us on this runtime; the branch stream is in order,
+            # so the decoder's weight gradient queues behind the product anyway, and the join ahead of the expert's
+            # optimiser covers it.  A product that outlasts the forward chain delays the reconstruction launch's
+            # workgroups on the CUs it still holds by its remainder, no more.
+            self._mark("forward chain done (prefetch joined)")
+            self._join()
+        self._prefetch_join = False
         last = self.dec_layers[-1]
         fused_last = last.relu and last.bn is None and last.p == 0
         if not fused_last:

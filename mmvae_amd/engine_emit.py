@@ -419,9 +419,11 @@ class PlanEmit:
     # ---- one FCBlock layer forward: cur [rows, n_in] -> l.d
     def fwd_layer(self, tag: str, l: _LayerRef, cur: torch.Tensor, ld_cur: int, rows: int, training: bool = True,
                   mask_tag: Optional[str] = None, mask_stream: Optional[int] = None, planes_out: Optional[_PlaneBuf] = None,
-                  split_job=None):
+                  split_job=None, slabs_from: Optional[torch.Tensor] = None):
         """`mask_tag`: name of the keep-mask buffer when it must differ from the layer's other buffers (the two phases
-        of an adversary share activations but draw fresh masks); `mask_stream`: its Philox stream id."""
+        of an adversary share activations but draw fresh masks); `mask_stream`: its Philox stream id.  `slabs_from`
+        [S, rows, n_out]: the layer's split-K partial products already exist there (the previous step computed them
+        beside its forward chain: StepEngine.training_step, "prefetch") -- no GEMM is emitted, the tail sums those."""
         eng = self.eng
         l.inp, l.ld_inp, l.rows = cur, ld_cur, rows
         l.d = eng.buf(f"{tag}.d", (rows, l.n_out))
@@ -442,7 +444,11 @@ class PlanEmit:
             if planes_out is not None:  # no column kernel behind this GEMM: a split pass of its own
                 self._emit(self.lib.mmvae_split_planes_f32, rows, l.n_out, _p(l.d), l.n_out, *planes_out.args())
             return l.d
-        S = self.gemm_raw(NT, rows, l.n_out, l.n_in, cur, ld_cur, l.W, l.n_in)
+        if slabs_from is not None:
+            assert tuple(slabs_from.shape) == (sk, rows, l.n_out) and slabs_from.is_contiguous()
+            S = sk
+        else:
+            S = self.gemm_raw(NT, rows, l.n_out, l.n_in, cur, ld_cur, l.W, l.n_in)
         bnp = None
         if l.bn is not None:
             bn = l.bn
@@ -452,7 +458,7 @@ class PlanEmit:
         plan = self
 
         def call():
-            args = (rows, l.n_out, plan.slab.data_ptr(), l.n_out, S, _p(l.b),
+            args = (rows, l.n_out, slabs_from.data_ptr() if slabs_from is not None else plan.slab.data_ptr(), l.n_out, S, _p(l.b),
                     C.byref(bnp) if bnp is not None else None, int(training), int(l.relu),
                     _p(l.mask), p_drop, _p(l.z), _p(l.a), _p(l.d), l.n_out, _p(l.mean), _p(l.invstd),
                     plan.fcws.data_ptr(), plan.fcws.numel() * 4)

@@ -119,8 +119,9 @@ class CMMVAEModel(BaseModel):
         x, metadata, expert_id = batch
         metadata["species"] = expert_id
         engine = self._get_engine(x)
+        hint, self._next_hint = getattr(self, "_next_hint", None), None
         if engine is not None:
-            return engine.training_step(x, metadata, expert_id)
+            return engine.training_step(x, metadata, expert_id, next_batch=hint)
         if getattr(self.module.vae.encoder, "elbo_mode", "analytic") != "analytic":
             raise NotImplementedError("elbo_mode='iwae' (the opt-in full-IWAE objective) runs in the captured engine only")
 
@@ -171,6 +172,19 @@ class CMMVAEModel(BaseModel):
     def _flush_engine(self):
         if self._engine:
             self._engine.flush()
+
+    def hint_next_batch(self, batch) -> None:
+        """Optional: tell the model which batch the NEXT training_step will receive -- `(x, metadata, expert_id)` as the
+        loader yields it, or None.  The step engine then computes that step's first forward product as filler work beside
+        this step's latency-bound forward chain (software pipelining across steps, mmvae_amd.engine: same kernels on the
+        same operands, bit-identical results; a hint that turns out wrong costs one wasted product).  The hinted tensor
+        must stay unmodified until its step.  mmvae_amd.trainer.Trainer and mmvae_amd.data.Lookahead look one batch ahead;
+        the reference's loop (no look-ahead) simply never calls this."""
+        if batch is None:
+            self._next_hint = None
+            return
+        x, _, expert_id = batch
+        self._next_hint = (x, expert_id)
 
     def gather_optimizer_state(self) -> None:
         """Under data parallelism the engine updates each expert arena sharded (this rank's slice of the Adam moments

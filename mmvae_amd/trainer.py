@@ -43,6 +43,32 @@ class MultiModalBatches:
                 order = [k for k in order if k in its]
 
 
+class Lookahead:
+    """Wraps a batch iterable and tells the model, before each batch is handed out, which batch comes AFTER it
+    (`CMMVAEModel.hint_next_batch`): the step engine then computes the next step's first forward product beside the
+    current step's forward chain (software pipelining across steps).  Works around any loop that pulls batches one at a
+    time -- this module's Trainer, or a Lightning Trainer given `Lookahead(dataloader, model)` as its train dataloader."""
+
+    def __init__(self, batches: Iterable, model):
+        self.batches, self.model = batches, model
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self) -> Iterator:
+        it = iter(self.batches)
+        try:
+            cur = next(it)
+        except StopIteration:
+            return
+        for nxt in it:
+            self.model.hint_next_batch(nxt)
+            yield cur
+            cur = nxt
+        self.model.hint_next_batch(None)
+        yield cur
+
+
 class Trainer:
     def __init__(self, max_epochs: int = 10, max_steps: int = -1, limit_train_batches: Optional[int] = None,
                  limit_val_batches: Optional[int] = None, check_val_every_n_epoch: int = 1,
@@ -73,7 +99,7 @@ class Trainer:
         for epoch in range(self.max_epochs):
             model.train()
             stub.set_stage("training")
-            for i, batch in enumerate(train_batches):
+            for i, batch in enumerate(Lookahead(train_batches, model) if hasattr(model, "hint_next_batch") else train_batches):
                 if self.limit_train_batches is not None and i >= self.limit_train_batches:
                     break
                 model.training_step(batch, i)

@@ -116,9 +116,13 @@ def _slopes(model, eid: str) -> Dict[str, torch.Tensor]:
     return slopes
 
 
-def check_step(model, eid: str, x: torch.Tensor, meta, step_index: int, strict: bool = True) -> dict:
+def check_step(model, eid: str, x: torch.Tensor, meta, step_index: int, strict: bool = True, next_batch=None) -> dict:
     """Take ONE training step of `model` on (x, meta, eid) the way the caller's loop does (captured program, Philox
-    noise) and compare it with the oracle.  Returns the measured deviations; `strict` asserts the tolerances TOL."""
+    noise) and compare it with the oracle.  Returns the measured deviations; `strict` asserts the tolerances TOL.
+    next_batch: the (x, meta, eid) the caller's loop will step next -- passed on as the loop does
+    (CMMVAEModel.hint_next_batch: the pipelined program computes that step's first product ahead, and THIS step may be
+    consuming the product the previous step computed for it; the oracle works from the snapshotted pre-step weights, so
+    a stale product would show)."""
     from mmvae_amd.modules.base.components import Adversarial
 
     spec = spec_of(model, eid)
@@ -129,6 +133,8 @@ def check_step(model, eid: str, x: torch.Tensor, meta, step_index: int, strict: 
     sd_in, opt_state, count = snapshot(model, eid)
     kl_weight = float(model.kl_annealing_fn.kl_weight)
     model.logged.clear()
+    if next_batch is not None:
+        model.hint_next_batch(next_batch)
     model.training_step((x, meta, eid), step_index)
     model._flush_engine()
     torch.cuda.synchronize()
@@ -163,9 +169,16 @@ def check_step(model, eid: str, x: torch.Tensor, meta, step_index: int, strict: 
         if n:
             rms = float(y.double().pow(2).mean().sqrt())
             worst = float(y[diff].abs().max())
-            assert worst <= 1e-4 * rms, f"{name}: a ReLU slope differs at |y| = {worst:.3e} (rms {rms:.3e}): not a kink"
+            # An adversary's encoder in the generator phase of a COLD step: the discriminator phase has just moved every
+            # adversary weight by +-lr (Adam's first step is sign-like), and a gradient entry within rounding of zero
+            # takes either sign -- the two sides' generator-phase pre-activations then differ by O(lr |h|_1), not by
+            # rounding.  Units that close to zero on that scale count as kinks there.
+            bound = 1e-2 if (count == 0 and name.startswith("adversarials.")) else 1e-4
+            assert worst <= bound * rms, f"{name}: a ReLU slope differs at |y| = {worst:.3e} (rms {rms:.3e}): not a kink"
             kinks += n
     out = {"kinks": kinks, "cold": count == 0, "replayed": bool(replayed), "adam_step": count + 1,
+           "first_product_from_previous_step": getattr(plan, "slabs_ahead", None) is not None,
+           "computes_next_first_product": getattr(plan, "prefetch_slabs", None) is not None,
            "forked": bool(getattr(plan, "_forked", False)), "philox": not plan.explicit}
     logged = {k: float(v.detach() if torch.is_tensor(v) else v) for k, v in model.logged.items()}
     for k, key in (("loss", "total_loss"), ("recon_loss", "recon_loss"), ("kl_loss", "kl_loss")):

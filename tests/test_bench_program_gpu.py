@@ -52,26 +52,55 @@ def test_bench_program_matches_oracle(config):
     first = []
     for i in range(period):
         x, meta, eid = batch(step)
-        first.append(PC.check_step(model, eid, x, meta, step))
+        # (adversarial program: inside a COLD step the discriminator phase moves every adversary weight by +-lr -- Adam's
+        # first step is sign-like -- and gradient entries within rounding of zero take either sign on the two sides, so
+        # the generator phase that follows sees adversaries that differ by O(lr), not by rounding: those first steps are
+        # recorded and held to the cold-step bounds only; the 12 warm steps below carry the strict tolerances)
+        r = PC.check_step(model, eid, x, meta, step, strict=(config == "c2"), next_batch=batch(step + 1))
+        if config != "c2" and r["cold"]:
+            assert r["loss"] <= 1e-4 and r["recon_loss"] <= 1e-4 and r["kl_loss"] <= 1e-4, r
+            assert max(v for k, v in r.items() if k.startswith("adversarial_loss_")) <= 5e-3 and r["param"] <= 1e-2, r
+        elif config != "c2":  # a warm step: the strict tolerances
+            tol = PC.TOL
+            assert max(v for k, v in r.items() if k.endswith("loss") or k.startswith("adversarial_loss_")) <= tol["loss"], r
+            assert max(v for k, v in r.items() if k.startswith("grad_norm_")) <= tol["grad_norm"], r
+            assert r["grad"] <= tol["grad"] and r["param"] <= tol["param"], r
+        first.append(r)
         step += 1
     # bench.py's set-up: step every resident batch until its plan replays from the graph.  The adversarial program then
     # takes bench.py's warm-up and timed steps as well (r5): the 12 checked steps are consecutive steps of the regime the
     # benchmark TIMES -- no reload of the initial state, no installed optimiser state (the checked step and
-    # the timed steps must live in one regime; the first steps of C4 are violent -- gradient reversal at adv_weight 25
-    # on cold, sign-like Adam steps -- and settle within tens of steps once the labels are functions of the cells).
-    for i in range(3 * period + (60 if config != "c2" else 0)):
+    # the timed steps must live in one regime).  The first ~1 500 steps of C4 are violent -- gradient reversal at
+    # adv_weight 25 against cold, sign-like Adam steps: the adversary on z drives the KL term to 1e6 .. 1e8 -- before the
+    # game settles (KL ~ 1e3, head losses near chance: profiles/r5_c4_stability.txt); bench.py runs 2 000 untimed
+    # settling steps (2 s) ahead of its warm-up for this configuration, and so does this test.
+    for i in range(3 * period + (2000 if config != "c2" else 0)):
         x, meta, eid = batch(step)
+        model.hint_next_batch(batch(step + 1))  # (bench.py's loop looks one batch ahead)
         model.training_step((x, meta, eid), step)
         step += 1
     rows = []
     for i in range(12):
         x, meta, eid = batch(step)
-        r = PC.check_step(model, eid, x, meta, step)
+        r = PC.check_step(model, eid, x, meta, step, strict=(config == "c2"), next_batch=batch(step + 1))
         assert r["replayed"] and r["philox"], r  # the program under test: a replayed graph with device noise
+        if config != "c2":
+            # The oracle runs at the slopes the step left in its buffers -- for the adversaries' encoders those of the
+            # GENERATOR phase; its discriminator phase keeps its own (the fused passes overwrite that phase's
+            # activations).  A unit within rounding of zero there flips the discriminator update on one side only and
+            # moves every gradient behind the reversal by ~2e-4 (seen once in four bench runs): a step WITH kinks is held
+            # to 1e-3 on gradients, every kink-free step to the strict tolerances, and most steps must be kink-free.
+            tol = PC.TOL
+            assert max(v for k, v in r.items() if k.endswith("loss") or k.startswith("adversarial_loss_")) <= tol["loss"], r
+            assert max(v for k, v in r.items() if k.startswith("grad_norm_")) <= (tol["grad_norm"] if not r["kinks"] else 1e-3), r
+            assert r["grad"] <= (tol["grad"] if not r["kinks"] else 1e-3) and r["param"] <= tol["param"], r
         rows.append(r)
         step += 1
+    assert sum(1 for r in rows if not r["kinks"]) >= 6, [r["kinks"] for r in rows]
     if config == "c2":
         assert any(r["forked"] for r in rows), "the bench program runs with its side branches"
+        # ... and pipelined across steps: every checked step started from the previous step's product and computed the next one's
+        assert all(r["first_product_from_previous_step"] and r["computes_next_first_product"] for r in rows), rows[0]
     else:
         assert getattr(model._engine.last_plan, "adv_prog", None) is not None, "C4 runs the fused adversary passes"
     worst = {k: max(r[k] for r in rows) for k in rows[0] if isinstance(rows[0][k], float)}
@@ -84,7 +113,7 @@ def test_bench_program_matches_oracle(config):
     model._engine.close()
 
 
-def _run_c2(steps, env, attach=False, keep_engine=False, config="c2"):
+def _run_c2(steps, env, attach=False, keep_engine=False, config="c2", hints=None):
     """`steps` training steps of the C2 (or `config`) model under `env`; returns the final parameters and whether the plan forked
     (attach: gradients exchanged over the initialised process group; keep_engine: + the engine's dp_tuned record)."""
     import bench
@@ -114,9 +143,13 @@ def _run_c2(steps, env, attach=False, keep_engine=False, config="c2"):
                 for i, (eid, G) in enumerate(cfg["experts"].items())}
         for i in range(steps):
             eid = eids[i % len(eids)]
+            if hints is not None:  # the loop's look-ahead (CMMVAEModel.hint_next_batch): hints(i) -> (x, meta, eid) | None
+                model.hint_next_batch(hints(i, data, eids))
             model.training_step((*data[eid], eid), i)
         model._flush_engine()
         torch.cuda.synchronize()
+        if hints is not None:
+            _run_c2.prefetch_stats = dict(model._engine.prefetch_stats)
         forked = bool(model._engine.last_plan._forked)
         sd = {k: v.detach().cpu().clone() for k, v in model.module.state_dict().items()}
         tuned = dict(getattr(model._engine, "dp_tuned", {}))
@@ -129,6 +162,54 @@ def _run_c2(steps, env, attach=False, keep_engine=False, config="c2"):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_pipelined_first_product_is_bit_identical_and_survives_wrong_hints():
+    """Software pipelining across steps (StepEngine.training_step, "prefetch"): with the loop's look-ahead every step
+    computes the NEXT step's first forward GEMM beside its own forward chain and starts from the slabs the previous step
+    left.  Same kernel, same operands: parameters after 9 steps are bit-identical to the unpipelined program -- also when
+    hints are wrong (another batch arrives than was announced), missing, name the SAME expert (its weights are about to
+    change: never computed ahead) or the announced tensor was modified in between (torch version counter)."""
+    import gc
+
+    ref, forked = _run_c2(9, {})
+    assert forked
+
+    def right(i, data, eids):
+        e = eids[(i + 1) % len(eids)]
+        return (*data[e], e)
+
+    def unreliable(i, data, eids):
+        if i % 4 == 1:
+            return None                                  # no look-ahead for this step
+        if i % 4 == 2:
+            e = eids[i % len(eids)]                      # the same expert again: must not be computed ahead
+            return (*data[e], e)
+        if i % 4 == 3:
+            e = eids[(i + 1) % len(eids)]                # the right expert, another tensor than the one that will arrive
+            return (data[e][0].clone(), data[e][1], e)
+        return right(i, data, eids)
+
+    def touched(i, data, eids):
+        if i > 0:  # the batch about to be stepped was announced (and its product computed) during the previous step:
+            data[eids[i % len(eids)]][0].mul_(1.0)       # an in-place write in between bumps its version -> product dropped
+        e = eids[(i + 1) % len(eids)]
+        return (*data[e], e)
+
+    for name, hints, want in (("right", right, lambda st: st["consumed"] == 8 and st["discarded"] == 0),
+                              ("unreliable", unreliable, lambda st: 0 < st["consumed"] < 8 and st["discarded"] > 0),
+                              ("touched", touched, lambda st: st["consumed"] == 0 and st["discarded"] == 8)):
+        gc.collect()
+        torch.cuda.empty_cache()
+        got, f = _run_c2(9, {}, hints=hints)
+        st = _run_c2.prefetch_stats
+        assert want(st), (name, st)
+        bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+        assert not bad, f"{name}: {len(bad)} tensors differ, e.g. {bad[:3]} ({st})"
+    gc.collect()
+    torch.cuda.empty_cache()
+    got, _ = _run_c2(9, {"MMVAE_PREFETCH": "0"}, hints=right)
+    assert _run_c2.prefetch_stats["issued"] == 0 and not [k for k in ref if not torch.equal(ref[k], got[k])]
 
 
 def test_forked_program_is_bit_identical_to_the_single_stream_one():
