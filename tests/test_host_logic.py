@@ -273,3 +273,37 @@ def test_forked_programs_are_fenced_to_validated_runtimes():
     assert forks_allowed(st, "7.0.51831")
     assert not forks_allowed(st, "7.2.26015") and not forks_allowed(st, "")
     assert forks_allowed(dataclasses.replace(st, side_dw_any=True), "7.2.26015")
+
+
+def test_lookahead_announces_the_next_batch_and_the_model_consumes_the_hint():
+    """mmvae_amd.trainer.Lookahead (the loop side of the step engine's software pipelining across steps): batches come out
+    in order and unchanged, and before each one the model is told which one follows (None behind the last)."""
+    from mmvae_amd.trainer import Lookahead
+
+    class Model:
+        def __init__(self):
+            self.seen = []
+
+        def hint_next_batch(self, b):
+            self.seen.append(b)
+
+    m = Model()
+    batches = [("x0", "m0", "human"), ("x1", "m1", "mouse"), ("x2", "m2", "human")]
+    out = []
+    for b in Lookahead(batches, m):
+        out.append((b, m.seen[-1]))
+    assert [b for b, _ in out] == batches
+    assert [h for _, h in out] == [batches[1], batches[2], None]
+    assert list(Lookahead([], m)) == [] and len(Lookahead(batches, m)) == 3
+    # CMMVAEModel keeps one hint and hands it to exactly one training step
+    from mmvae_amd.models import CMMVAEModel
+
+    class Probe(CMMVAEModel):
+        def __init__(self):  # (no module: only the hint bookkeeping is exercised)
+            pass
+
+    p = Probe()
+    p.hint_next_batch(("x", "meta", "mouse"))
+    assert p._next_hint == ("x", "mouse")
+    p.hint_next_batch(None)
+    assert p._next_hint is None
