@@ -547,7 +547,8 @@ def main():
             # (algorithmic FLOPs of the program that was timed: the forward-only modes do a third / a sixth of a training step)
             "step_flops_per_cell": synthetic.flops_per_cell(G, K, mode=a.mode, **({"h1": a.hidden} if a.hidden else {})),
             "step_tflops": synthetic.flops_per_cell(G, K, mode=a.mode, **({"h1": a.hidden} if a.hidden else {})) * cells_per_s / world / 1e12,
-            "pipelined_first_product": (dict(eng.prefetch_stats, cap=eng.settings.prefetch,
+            "pipelined_first_product": (dict(eng.prefetch_stats,
+                                             cap=eng.settings.prefetch_adv if cfg["adversarial"] else eng.settings.prefetch,
                                              note="software pipelining across steps: every step computes the NEXT step's first "
                                                   "forward GEMM (the loop's look-ahead) beside its own forward chain and starts "
                                                   "from the slabs the previous step left; one such GEMM per timed step")

@@ -54,6 +54,7 @@ class EngineSettings:
     side_dw2: int = 185          # MMVAE_SIDE_DW2: cap of the encoder's weight gradient beside the shared VAE's optimiser
     side_dw_dp: int = 125        # MMVAE_SIDE_DW_DP: that branch inside the exchange (data-parallel) program; 0 = in order
     side_dw_any: bool = False    # MMVAE_SIDE_DW_ANY=1: fork outside the measured geometry too
+    prefetch_adv: int = 86       # MMVAE_PREFETCH_ADV: its cap in adversarial programs (second branch stream, beside the adversaries' lane: 3 rounds of the 256 work items; C4 1.091 -> 1.070 ms, 128: 1.083, 64: 1.094); 0 = off
     prefetch: int = 128          # MMVAE_PREFETCH: workgroup cap of the NEXT step's first forward GEMM beside this step's forward chain (software pipelining across steps, needs the caller's hint); 0 = off
     adv_fused: bool = True       # MMVAE_ADV_FUSED=0: the per-layer adversary program (the path of adversaries with BatchNorm)
     adv_aside: int = 2           # MMVAE_ADV_ASIDE: 0 the fused adversary passes in order; 1 on the branch stream; 2 + the decoder's weight gradient on a second branch from where the first is joined
@@ -75,7 +76,7 @@ class EngineSettings:
             conditionals=e("MMVAE_ENGINE_CONDITIONALS", "1") != "0", graphs=e("MMVAE_NO_GRAPH", "0") == "0",
             planes=e("MMVAE_PLANES", "1") != "0", side_dw=int(e("MMVAE_SIDE_DW", "125")),
             side_dw2=int(e("MMVAE_SIDE_DW2", "185")), side_dw_dp=int(e("MMVAE_SIDE_DW_DP", "125")),
-            side_dw_any=e("MMVAE_SIDE_DW_ANY", "0") != "0", prefetch=int(e("MMVAE_PREFETCH", "128")),
+            side_dw_any=e("MMVAE_SIDE_DW_ANY", "0") != "0", prefetch=int(e("MMVAE_PREFETCH", "128")), prefetch_adv=int(e("MMVAE_PREFETCH_ADV", "86")),
             adv_fused=e("MMVAE_ADV_FUSED", "1") != "0",
             adv_aside=int(e("MMVAE_ADV_ASIDE", "2")),
             dp_overlap=None if ov == "" else ov != "0", dp_shard=e("MMVAE_DP_SHARD", "1") != "0", dp_kernels=kernels,
@@ -548,8 +549,10 @@ class StepEngine:
             return None
         x_n, eid_n = next_batch
         m = self.model.module
-        if eid_n == plan_eid or eid_n not in m.experts or len(m.adversarials) > 0 or getattr(m.vae, "conditionals", None) is not None:
+        if eid_n == plan_eid or eid_n not in m.experts or getattr(m.vae, "conditionals", None) is not None:
             return None
+        if len(m.adversarials) > 0 and not (st.prefetch_adv and self.side_stream2 is not None):
+            return None  # (adversarial programs: the product takes the second branch stream, free until the late branch)
         if (not torch.is_tensor(x_n) or x_n.layout != torch.strided or not x_n.is_cuda or x_n.dtype != torch.float32
                 or x_n.dim() != 2 or x_n.stride(1) != 1):
             return None
@@ -784,8 +787,13 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             self._x_split_jobs = [(min(per, G - r0), lastl.n_in, _p(lastl.W) + 4 * r0 * lastl.n_in, lastl.n_in,
                                    wpp + 2 * r0 * wld, wld, wps) for r0 in range(0, G, per)] + getattr(self, "_x_split_jobs", [])
         # ---- forward, encoder side
+        # (adversarial programs of the measured geometry fork too: the same test as `adv_aside` below)
+        adv_forks = bool(self.has_adv and train and eng.adv_fused and eng.settings.adv_aside >= 2 and eng.side_stream2 is not None
+                         and not eng.overlap and eng.world == 1 and K == 1 and big and (measured or eng.side_dw_any)
+                         and self.cond is None and not any(o.reducer is not None for o in self.opt_adv))
+
         def emit_prefetch():
-            if self.prefetch is None or not side_dw or not train:
+            if self.prefetch is None or not train or not (side_dw or adv_forks):
                 return
             # the NEXT step's first forward product, beside this step's forward chain (joined ahead of the
             # reconstruction launch, which wants the whole chip)
@@ -798,7 +806,8 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
             self.prefetch_slabs = eng.buf(f"prefetch.slabs.{eid_n}", (sk_n, Bn, ln.n_out))
             self._probe_next = "enc_l1_fwd"
             self._side_capped_gemm(NT, Bn, ln.n_out, ln.n_in, x_n, x_n.stride(0), ln.W, ln.n_in, self.prefetch_slabs,
-                                   ln.n_out, eng.settings.prefetch, flags=_lib.GEMM_RAW_SLABS, sk=sk_n)
+                                   ln.n_out, eng.settings.prefetch_adv if adv_forks else eng.settings.prefetch,
+                                   flags=_lib.GEMM_RAW_SLABS, sk=sk_n, stream=eng.side_stream2 if adv_forks else None)
             self._probe_next = None
             self._prefetch_join = True
 

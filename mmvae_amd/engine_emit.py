@@ -172,7 +172,7 @@ class PlanEmit:
         return True
 
     def _side_capped_gemm(self, layout, M, N, K, A, lda, Bm, ldb, Cm, ldc, cap: int, planes=None, flags: int = 0,
-                          sk: int = 1, fork: bool = True) -> None:
+                          sk: int = 1, fork: bool = True, stream=None) -> None:
         """Unsplit GEMM on the side stream with its persistent grid capped to `cap` workgroups (no fused norm partials:
         under a gradient exchange the clip's norm is that of the REDUCED gradients); joined by the next cut / _join()."""
         plan = self
@@ -191,9 +191,9 @@ class PlanEmit:
 
         launch = self._probed(tag, 2.0 * M * N * K, launch_gemm, bound="mfma", cus=cap, planes=_planes_desc(planes),
                               shape=f"{('NT', 'NN', 'TN')[layout]} {M}x{N}x{K}" + (f" split-K {sk}" if sk > 1 else ""))
-        side = self.eng.side_stream
+        side = stream if stream is not None else self.eng.side_stream
         if fork:
-            self._fork()
+            self._fork(side)
 
         def call():
             plan.lib.mmvae_gemm_set_workgroup_cap(cap)

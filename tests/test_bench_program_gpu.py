@@ -216,6 +216,16 @@ def test_pipelined_first_product_is_bit_identical_and_survives_wrong_hints():
     torch.cuda.empty_cache()
     got, _ = _run_c2(9, {"MMVAE_PREFETCH": "0"}, hints=right)
     assert _run_c2.prefetch_stats["issued"] == 0 and not [k for k in ref if not torch.equal(ref[k], got[k])]
+    # the adversarial program (C4): the product runs on the second branch stream beside the adversaries' lane
+    gc.collect()
+    torch.cuda.empty_cache()
+    ref4, _ = _run_c2(5, {}, config="c4")
+    gc.collect()
+    torch.cuda.empty_cache()
+    got4, _ = _run_c2(5, {}, config="c4", hints=right)
+    assert _run_c2.prefetch_stats["consumed"] == 4, _run_c2.prefetch_stats
+    bad = [k for k in ref4 if not torch.equal(ref4[k], got4[k])]
+    assert not bad, f"c4: {len(bad)} tensors differ, e.g. {bad[:3]}"
 
 
 def test_forked_program_is_bit_identical_to_the_single_stream_one():
