@@ -571,19 +571,23 @@ def main():
             # (the tracked counters are C2's: default gene counts and hidden width, dense input)
             profiled_shape = a.config == "c2" and not a.genes and not a.hidden and a.input == "dense"
             traffic = pmc_traffic() if profiled_shape else {}
-            kernels, fl_sum, t_sum, tr_sum, tr_n = [], 0.0, 0.0, 0, 0
+            kernels, fl_sum, t_sum, tr_sum, tr_n, t_held = [], 0.0, 0.0, 0, 0, 0.0
             for tag, what, sub in FAMILY:
                 if tag not in leg:
                     continue
                 tk, fl, meta = leg[tag]
                 fl_sum += fl
                 t_sum += tk
+                t_held += tk * (meta.get("cus") or 256) / 256.0
                 tr = traffic.get(sub)
                 if tr is not None:
                     tr_sum += tr
                     tr_n += 1
                 kernels.append({"name": tag, "what": what, "shape": meta.get("shape"), "us": tk * 1e6,
                                 "tflops": fl / tk / 1e12, "frac": fl / tk / (peak * 1e12),
+                                # a launch whose grid the engine caps runs BESIDE a latency-bound lane of the program on
+                                # `cus` of the 256 CUs: its rate against the ceiling of the CUs it held
+                                "frac_of_held_cus": fl / tk / (peak * 1e12) * 256.0 / (meta.get("cus") or 256),
                                 "cus": meta.get("cus") or 256, "operands": {"": "fp32, split in the kernel", "A+B": "pre-split bf16 planes (LDS-DMA)",
                                              "A": "A pre-split bf16 planes (LDS-DMA), B fp32 split in the kernel",
                                              "B": "A fp32 split in the kernel, B pre-split bf16 planes (LDS-DMA)"
@@ -600,6 +604,11 @@ def main():
                 "kernel": ("the five G-wide GEMMs of the step, time-weighted (bf16x3 MFMA: 6 bf16 products per fp32 product)"
                            if x3 else "the five G-wide GEMMs of the step, time-weighted (f32 MFMA)"),
                 "achieved": fl_sum / t_sum / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl_sum / t_sum / (peak * 1e12),
+                # three of the five launches run capped beside a latency-bound lane (the next step's first product beside the
+                # forward chain, the two weight gradients beside the backward chain / the VAE's optimiser), and the
+                # reconstruction launch starts while the first still holds CUs: `frac` prices every launch against the WHOLE
+                # chip for as long as it lasted; this one prices it against the CUs it was given
+                "frac_of_held_cus": fl_sum / t_held / (peak * 1e12),
                 "traffic": int(tr_sum / tr_n) if tr_n else None,
                 "traffic_note": (f"mean HBM bytes per launch over {tr_n} of the family's kernels, 2 x FETCH_SIZE + WRITE_SIZE "
                                  f"from {os.path.relpath(PMC_FAMILY_FILE, ROOT)} (separate rocprofv3 --pmc passes)"
