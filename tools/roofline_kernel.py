@@ -34,6 +34,10 @@ dW1, dW4 = torch.empty(H1, G, device=dev), torch.empty(G, H1, device=dev)
 sep = torch.empty(ops.recon_tiles(G), B, device=dev)
 Xp, dYp, hp = ops.split_planes(X), ops.split_planes(dY), ops.split_planes(h)
 which = sys.argv[1] if len(sys.argv) > 1 else "family"
+if os.environ.get("MMVAE_RK_CAP"):  # the persistent kernels' grid capped as the engine caps it beside a branch
+    from mmvae_amd import _lib
+
+    _lib.load().mmvae_gemm_set_workgroup_cap(int(os.environ["MMVAE_RK_CAP"]))
 for _ in range(8):
     if which in ("family", "fwd"):  # Y[B, 1024] = X . W1^T as 16 raw split-K slabs
         ops.gemm_slabs(ops.GEMM_NT, X, W1)
