@@ -40,7 +40,7 @@ typedef void* mmvae_stream_t; /* hipStream_t */
 /* ABI version: bumped whenever an entry point is added or a signature changes (mmvae_abi_version() returns the
  * value the library was built with; bindings compare it with the header they were written against).
  *   1  round-1 surface (first 20 entry points)      2  end of round 1 (50 entry points)      3+  round 2 */
-#define MMVAE_ABI_VERSION 8
+#define MMVAE_ABI_VERSION 9
 int mmvae_abi_version(void);
 const char* mmvae_build_arch(void);
 
@@ -601,6 +601,28 @@ int mmvae_cond_linear_bwd_dw(int n_chunks, const int32_t* chunk_dst, const int32
                              int64_t ldx, float* grads, const int64_t* w_off, const int64_t* b_off, int n_red,
                              const int32_t* red_cond, const int32_t* red_slot, const int32_t* red_n, float* partials,
                              mmvae_stream_t stream);
+/* (ABI 9, r5) n_pos POSITIONS of a "parallel" selection order per launch -- ConditionalLayers.forward with
+ * selection_order = ["parallel"] (components.py:586-631; configs/model/human_only.yaml:78-79): every conditional layer
+ * reads the SAME input and the outputs are concatenated, so the layers are independent of each other.  Position j's index
+ * tables start `tbl_stride` int32 elements behind position j - 1's (every pointer argument names position 0's array),
+ * its output / output gradient is the column block `y_pos_stride` / `dy_pos_stride` floats further into rows of ldy /
+ * lddy floats, its input `x_pos_stride` floats further (0: one input for all), its partial slots `part_pos_stride`
+ * floats further.  _fwd_multi / _bwd_dw_multi: the same arithmetic per position as the single-position entry points
+ * (same bits).  _bwd_dx_multi: dx[b] (+)= sum over the positions of W[c_j(b)]^T dy_j[b], one workgroup per cell, the
+ * positions added in descending order (needs no sorted `rows`). */
+int mmvae_cond_linear_fwd_multi(int n_pos, int B, int n_in, int n_out, const float* x, int64_t ldx, int64_t x_pos_stride,
+                                const float* params, const int64_t* w_off, const int64_t* b_off, const int32_t* cond,
+                                const int32_t* rows, int64_t tbl_stride, float* y, int64_t ldy, int64_t y_pos_stride,
+                                mmvae_stream_t stream);
+int mmvae_cond_linear_bwd_dx_multi(int n_pos, int B, int n_in, int n_out, const float* dy, int64_t lddy,
+                                   int64_t dy_pos_stride, const float* params, const int64_t* w_off, const int32_t* cond,
+                                   int64_t tbl_stride, float* dx, int64_t lddx, int accumulate, mmvae_stream_t stream);
+int mmvae_cond_linear_bwd_dw_multi(int n_pos, int n_chunks, const int32_t* chunk_dst, const int32_t* chunk_beg,
+                                   const int32_t* chunk_end, const int32_t* rows, int64_t tbl_stride, int n_in, int n_out,
+                                   const float* dy, int64_t lddy, int64_t dy_pos_stride, const float* x, int64_t ldx,
+                                   int64_t x_pos_stride, float* grads, const int64_t* w_off, const int64_t* b_off,
+                                   int n_red, const int32_t* red_cond, const int32_t* red_slot, const int32_t* red_n,
+                                   float* partials, int64_t part_pos_stride, mmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Row-owner adversary passes (ABI 6).  Replaces, per adversarial phase, the whole chain of

@@ -148,6 +148,10 @@ PROTOTYPES = {
     "mmvae_cond_linear_fwd": (_i, [_i, _i, _i, _p, _l, _p, _p, _p, _p, _p, _p, _l, _p]),
     "mmvae_cond_linear_bwd_dx": (_i, [_i, _i, _i, _p, _l, _p, _p, _p, _p, _p, _l, _i, _p]),
     "mmvae_cond_linear_bwd_dw": (_i, [_i, _p, _p, _p, _p, _i, _i, _p, _l, _p, _l, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
+    "mmvae_cond_linear_fwd_multi": (_i, [_i, _i, _i, _i, _p, _l, _l, _p, _p, _p, _p, _p, _l, _p, _l, _l, _p]),
+    "mmvae_cond_linear_bwd_dx_multi": (_i, [_i, _i, _i, _i, _p, _l, _l, _p, _p, _p, _l, _p, _l, _i, _p]),
+    "mmvae_cond_linear_bwd_dw_multi": (_i, [_i, _i, _p, _p, _p, _p, _l, _i, _i, _p, _l, _l, _p, _l, _l, _p, _p, _p, _i, _p,
+                                            _p, _p, _p, _l, _p]),
     "mmvae_gemm_batch_job_ok": (_i, [_p]),
     "mmvae_gemm_batch_prepare": (_i, [_i, _p, C.POINTER(_i)]),
     "mmvae_gemm_batch_f32": (_i, [_i, _p, _i, _p]),

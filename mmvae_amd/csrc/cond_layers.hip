@@ -21,6 +21,15 @@
 
 namespace {
 
+// (r5) Several POSITIONS of a "parallel" selection order in one launch (ConditionalLayers.forward with
+// selection_order = ["parallel"], components.py:586-631: every conditional layer reads the SAME input and their outputs
+// are concatenated -- the layers are independent of each other).  blockIdx.z is the position; each position has its own
+// index tables (`tbl` int32 elements apart), its own column block of the output / output gradient (`y` floats apart),
+// its own input (`x` floats apart: 0 when all positions read one input) and its own partial slots.
+struct PosStride {
+    int64_t tbl, x, y, part;
+};
+
 __global__ __launch_bounds__(256) void cond_linear_fwd_kernel(int n_in, int n_out, const float* __restrict__ x, int64_t ldx,
                                                               const float* __restrict__ params,
                                                               const int64_t* __restrict__ w_off,
@@ -59,10 +68,14 @@ __global__ __launch_bounds__(256) void cond_linear_fwd_sorted_kernel(int B, int 
                                                                      const int64_t* __restrict__ b_off,
                                                                      const int32_t* __restrict__ cond,
                                                                      const int32_t* __restrict__ rows,
-                                                                     float* __restrict__ y, int64_t ldy) {
+                                                                     float* __restrict__ y, int64_t ldy, PosStride ps) {
     extern __shared__ __attribute__((aligned(16))) float xs[];  // FW_CB input rows
     __shared__ int cell[FW_CB], cnd[FW_CB];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    cond += blockIdx.z * ps.tbl;
+    rows += blockIdx.z * ps.tbl;
+    x += blockIdx.z * ps.x;
+    y += blockIdx.z * ps.y;
     const int r0 = blockIdx.x * FW_CB, nb = min(FW_CB, B - r0);
     if (tid < nb) {
         const int b = rows[r0 + tid];
@@ -253,9 +266,17 @@ __global__ __launch_bounds__(256) void cond_dw_chunk_kernel(int n_in, int n_out,
                                                             const float* __restrict__ dy, int64_t lddy,
                                                             const float* __restrict__ x, int64_t ldx,
                                                             float* __restrict__ grads, const int64_t* __restrict__ w_off,
-                                                            const int64_t* __restrict__ b_off, float* __restrict__ partials) {
+                                                            const int64_t* __restrict__ b_off, float* __restrict__ partials,
+                                                            PosStride ps) {
     __shared__ __attribute__((aligned(16))) float sh[DW_CHUNK * 2 * DW_T];  // per cell: dy tile rows | x tile columns
     __shared__ int cells[DW_CHUNK];
+    chunk_dst += blockIdx.z * ps.tbl;
+    chunk_beg += blockIdx.z * ps.tbl;
+    chunk_end += blockIdx.z * ps.tbl;
+    rows += blockIdx.z * ps.tbl;
+    dy += blockIdx.z * ps.y;
+    x += blockIdx.z * ps.x;
+    if (partials) partials += blockIdx.z * ps.part;
     const int dst = chunk_dst[blockIdx.x];
     if (dst == -1) return;  // padding of a fixed-size launch
     const int tid = threadIdx.x;
@@ -334,7 +355,11 @@ __global__ __launch_bounds__(256) void cond_dw_reduce_kernel(int n_in, int n_out
                                                              const int32_t* __restrict__ red_n,
                                                              const float* __restrict__ partials, float* __restrict__ grads,
                                                              const int64_t* __restrict__ w_off,
-                                                             const int64_t* __restrict__ b_off) {
+                                                             const int64_t* __restrict__ b_off, PosStride ps) {
+    red_cond += blockIdx.z * ps.tbl;
+    red_slot += blockIdx.z * ps.tbl;
+    red_n += blockIdx.z * ps.tbl;
+    partials += blockIdx.z * ps.part;
     const int c = red_cond[blockIdx.x];
     if (c < 0) return;
     const int64_t n = (int64_t)n_in * n_out, tot = n + n_out;
@@ -355,6 +380,61 @@ __global__ __launch_bounds__(256) void cond_dw_reduce_kernel(int n_in, int n_out
     }
 }
 
+// dx[b] = sum over the positions j of W[c_j(b)]^T dy_j[b] (parallel selection order: one input, n_pos outputs).  One
+// workgroup per cell; per position thread (h, k) sums W[o][k] dy[o] over its half h of the output rows in ascending order
+// (DX_U loads in flight together), the halves are added through LDS and the positions' values in DESCENDING position
+// order -- the order the per-position launches accumulated in.  No sorting needed: every cell is its own workgroup.
+__global__ __launch_bounds__(256) void cond_linear_bwd_dx_multi_kernel(int n_pos, int n_in, int n_out,
+                                                                       const float* __restrict__ dy, int64_t lddy,
+                                                                       const float* __restrict__ params,
+                                                                       const int64_t* __restrict__ w_off,
+                                                                       const int32_t* __restrict__ cond,
+                                                                       float* __restrict__ dx, int64_t lddx,
+                                                                       int accumulate, PosStride ps) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];  // dy rows of every position [n_pos][n_out] | half-sums [DX_K]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float* dys = sh;
+    float* part = sh + n_pos * n_out;
+    for (int i = tid; i < n_pos * n_out; i += 256) {
+        const int j = i / n_out, o = i - j * n_out;
+        dys[i] = dy[(int64_t)b * lddy + j * ps.y + o];
+    }
+    __syncthreads();
+    const int h = tid >> 7, kk = tid & (DX_K - 1);
+    const int o_mid = (n_out + 1) / 2, o_beg = h ? o_mid : 0, o_end = h ? n_out : o_mid;
+    for (int k0 = 0; k0 < n_in; k0 += DX_K) {
+        const int k = k0 + kk;
+        float total = 0.f;
+        for (int j = n_pos - 1; j >= 0; --j) {
+            float acc = 0.f;
+            if (k < n_in) {
+                const float* wp = params + w_off[cond[j * ps.tbl + b]] + k;
+                const float* d = dys + j * n_out;
+                int o = o_beg;
+                for (; o + DX_U <= o_end; o += DX_U) {
+                    float w[DX_U];
+#pragma unroll
+                    for (int u = 0; u < DX_U; ++u) w[u] = wp[(int64_t)(o + u) * n_in];
+#pragma unroll
+                    for (int u = 0; u < DX_U; ++u) acc += w[u] * d[o + u];
+                }
+                for (; o < o_end; ++o) acc += wp[(int64_t)o * n_in] * d[o];
+            }
+            __syncthreads();  // (the previous position has finished reading `part`)
+            if (h == 1) part[kk] = acc;
+            __syncthreads();
+            if (h == 0) {
+                const float v = acc + part[kk];
+                total = (j == n_pos - 1) ? v : total + v;
+            }
+        }
+        if (h == 0 && k < n_in) {
+            float* out = dx + (int64_t)b * lddx + k;
+            *out = accumulate ? *out + total : total;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int mmvae_cond_linear_fwd(int B, int n_in, int n_out, const float* x, int64_t ldx, const float* params,
@@ -368,7 +448,7 @@ extern "C" int mmvae_cond_linear_fwd(int B, int n_in, int n_out, const float* x,
         const size_t lds = (size_t)FW_CB * n_in * sizeof(float);
 #define MMVAE_FWD_SORTED(T)                                                                                            \
     MMVAE_LAUNCH(cond_linear_fwd_sorted_kernel<T>, grid, dim3(256), lds, (hipStream_t)stream, B, n_in, n_out, x, ldx,  \
-                 params, w_off, b_off, cond, rows, y, ldy)
+                 params, w_off, b_off, cond, rows, y, ldy, PosStride{0, 0, 0, 0})
         switch ((n_in + 63) / 64) {
             case 1: MMVAE_FWD_SORTED(1); break;
             case 2: MMVAE_FWD_SORTED(2); break;
@@ -419,11 +499,80 @@ extern "C" int mmvae_cond_linear_bwd_dw(int n_chunks, const int32_t* chunk_dst, 
     const int64_t red_y = ((int64_t)n_in * n_out + n_out + 1023) / 1024;
     if (tiles > 65535 || red_y > 65535) return MMVAE_ERR_ARG;
     MMVAE_LAUNCH(cond_dw_chunk_kernel, dim3(n_chunks, (unsigned)tiles), dim3(256), 0, (hipStream_t)stream, n_in, n_out,
-                 chunk_dst, chunk_beg, chunk_end, rows, dy, lddy, x, ldx, grads, w_off, b_off, partials);
+                 chunk_dst, chunk_beg, chunk_end, rows, dy, lddy, x, ldx, grads, w_off, b_off, partials, PosStride{0, 0, 0, 0});
     MMVAE_LAUNCH_CHECK();
     if (n_red > 0) {
         MMVAE_LAUNCH(cond_dw_reduce_kernel, dim3(n_red, (unsigned)red_y), dim3(256), 0, (hipStream_t)stream, n_in, n_out,
-                     red_cond, red_slot, red_n, partials, grads, w_off, b_off);
+                     red_cond, red_slot, red_n, partials, grads, w_off, b_off, PosStride{0, 0, 0, 0});
+        MMVAE_LAUNCH_CHECK();
+    }
+    return MMVAE_OK;
+}
+
+// ---- (r5) n_pos positions of a "parallel" selection order per launch (PosStride above).  Tables of position j start
+// tbl_stride int32 elements behind those of position j - 1; outputs / output gradients are column blocks y_pos_stride
+// floats apart inside rows of ldy floats; x_pos_stride = 0 when every position reads the same input.
+extern "C" int mmvae_cond_linear_fwd_multi(int n_pos, int B, int n_in, int n_out, const float* x, int64_t ldx,
+                                           int64_t x_pos_stride, const float* params, const int64_t* w_off,
+                                           const int64_t* b_off, const int32_t* cond, const int32_t* rows,
+                                           int64_t tbl_stride, float* y, int64_t ldy, int64_t y_pos_stride,
+                                           mmvae_stream_t stream) {
+    if (n_pos <= 0 || n_pos > 64 || B <= 0 || n_in <= 0 || n_out <= 0 || n_in > 256 || !x || !params || !w_off || !b_off ||
+        !cond || !rows || !y || ldx < n_in || ldy < n_out || tbl_stride < B)
+        return MMVAE_ERR_ARG;
+    const dim3 grid((B + FW_CB - 1) / FW_CB, (n_out + FW_RO - 1) / FW_RO, n_pos);
+    const size_t lds = (size_t)FW_CB * n_in * sizeof(float);
+    const PosStride ps{tbl_stride, x_pos_stride, y_pos_stride, 0};
+#define MMVAE_FWD_SORTED(T)                                                                                            \
+    MMVAE_LAUNCH(cond_linear_fwd_sorted_kernel<T>, grid, dim3(256), lds, (hipStream_t)stream, B, n_in, n_out, x, ldx,  \
+                 params, w_off, b_off, cond, rows, y, ldy, ps)
+    switch ((n_in + 63) / 64) {
+        case 1: MMVAE_FWD_SORTED(1); break;
+        case 2: MMVAE_FWD_SORTED(2); break;
+        case 3: MMVAE_FWD_SORTED(3); break;
+        default: MMVAE_FWD_SORTED(4); break;
+    }
+#undef MMVAE_FWD_SORTED
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_cond_linear_bwd_dx_multi(int n_pos, int B, int n_in, int n_out, const float* dy, int64_t lddy,
+                                              int64_t dy_pos_stride, const float* params, const int64_t* w_off,
+                                              const int32_t* cond, int64_t tbl_stride, float* dx, int64_t lddx,
+                                              int accumulate, mmvae_stream_t stream) {
+    if (n_pos <= 0 || n_pos > 64 || B <= 0 || n_in <= 0 || n_out <= 0 || n_out > 1024 || !dy || !params || !w_off || !cond ||
+        !dx || lddy < (int64_t)(n_pos - 1) * dy_pos_stride + n_out || lddx < n_in || tbl_stride < B)
+        return MMVAE_ERR_ARG;
+    const size_t lds = ((size_t)n_pos * n_out + DX_K) * sizeof(float);
+    if (lds > 64 * 1024) return MMVAE_ERR_ARG;
+    MMVAE_LAUNCH(cond_linear_bwd_dx_multi_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, n_pos, n_in, n_out, dy, lddy,
+                 params, w_off, cond, dx, lddx, accumulate, PosStride{tbl_stride, 0, dy_pos_stride, 0});
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
+extern "C" int mmvae_cond_linear_bwd_dw_multi(int n_pos, int n_chunks, const int32_t* chunk_dst, const int32_t* chunk_beg,
+                                              const int32_t* chunk_end, const int32_t* rows, int64_t tbl_stride, int n_in,
+                                              int n_out, const float* dy, int64_t lddy, int64_t dy_pos_stride,
+                                              const float* x, int64_t ldx, int64_t x_pos_stride, float* grads,
+                                              const int64_t* w_off, const int64_t* b_off, int n_red,
+                                              const int32_t* red_cond, const int32_t* red_slot, const int32_t* red_n,
+                                              float* partials, int64_t part_pos_stride, mmvae_stream_t stream) {
+    if (n_pos <= 0 || n_pos > 64 || n_chunks <= 0 || n_in <= 0 || n_out <= 0 || !chunk_dst || !chunk_beg || !chunk_end ||
+        !rows || !dy || !x || !grads || !w_off || !b_off || lddy < n_out || ldx < n_in || n_red < 0)
+        return MMVAE_ERR_ARG;
+    if (n_red > 0 && (!red_cond || !red_slot || !red_n || !partials)) return MMVAE_ERR_ARG;
+    const int64_t tiles = (int64_t)((n_out + DW_T - 1) / DW_T) * ((n_in + DW_T - 1) / DW_T);
+    const int64_t red_y = ((int64_t)n_in * n_out + n_out + 1023) / 1024;
+    if (tiles > 65535 || red_y > 65535) return MMVAE_ERR_ARG;
+    const PosStride ps{tbl_stride, x_pos_stride, dy_pos_stride, part_pos_stride};
+    MMVAE_LAUNCH(cond_dw_chunk_kernel, dim3(n_chunks, (unsigned)tiles, n_pos), dim3(256), 0, (hipStream_t)stream, n_in, n_out,
+                 chunk_dst, chunk_beg, chunk_end, rows, dy, lddy, x, ldx, grads, w_off, b_off, partials, ps);
+    MMVAE_LAUNCH_CHECK();
+    if (n_red > 0) {
+        MMVAE_LAUNCH(cond_dw_reduce_kernel, dim3(n_red, (unsigned)red_y, n_pos), dim3(256), 0, (hipStream_t)stream, n_in,
+                     n_out, red_cond, red_slot, red_n, partials, grads, w_off, b_off, ps);
         MMVAE_LAUNCH_CHECK();
     }
     return MMVAE_OK;

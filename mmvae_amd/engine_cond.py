@@ -128,7 +128,14 @@ class CondProgram:
         self.P = cond_tables.words(R)
         self.lay = cond_tables.layout(R)
         self.n_chunks, self.n_red = cond_tables.max_chunks(R), cond_tables.max_reductions(R)
-        self.dw_partials = eng.buf("cond.dw_partials", (cond_tables.partial_slots(R) * (Z * Z + Z),)) if train else None
+        # (r5) "parallel" selection order: the positions read one input and are independent of each other -- ONE launch per
+        # kernel for all of them (mmvae_cond_linear_*_multi; LayerNorm over the [R, n_pos Z] matrices as R n_pos rows of Z)
+        # instead of n_pos launches of each in sequence (6 positions: 6 x 62 us of latency-bound launches per step)
+        import os
+
+        self.batched = bool(self.parallel and self.n_pos > 1 and Z <= 256 and os.environ.get("MMVAE_COND_BATCHED", "1") != "0")
+        self.part_stride = cond_tables.partial_slots(R) * (Z * Z + Z)
+        self.dw_partials = eng.buf("cond.dw_partials", ((self.n_pos if self.batched else 1) * self.part_stride,)) if train else None
         self.idx_words = (self.n_pos * self.P + 1) // 2 * 2
         words = self.idx_words + 6 * self.max_jobs
         self.pack_dev = eng.buf(f"cond.pack.{eid}.{int(train)}", (words,), torch.int32)
@@ -147,6 +154,11 @@ class CondProgram:
         self.invstd = [eng.buf(f"cond.invstd{j}", (R,)) for j in range(self.n_pos)] if self.ln_eps is not None else None
         self.mean = eng.buf("cond.mean", (R,)) if self.ln_eps is not None else None
         self.x_in = [None] * self.n_pos
+        if self.batched:
+            self.lin_wide = eng.buf("cond.lin_wide", (R, wide)) if self.ln_eps is not None else None
+            self.gl_wide = eng.buf("cond.gl_wide", (R, wide)) if (self.ln_eps is not None and train) else None
+            self.invstd_all = eng.buf("cond.invstd_all", (R * self.n_pos,)) if self.ln_eps is not None else None
+            self.mean_all = eng.buf("cond.mean_all", (R * self.n_pos,)) if self.ln_eps is not None else None
 
     def _ptr(self, j: int, name: str) -> int:
         """Device address of array `name` (cond_tables.layout) of position j."""
@@ -156,6 +168,18 @@ class CondProgram:
     def emit_forward(self, z: torch.Tensor):
         plan, lib, R, Z = self.plan, self.plan.lib, self.R, self.Z
         params = self.opt.arena.data
+        if self.batched:
+            n, wide = self.n_pos, self.out.shape[1]
+            lin_out = self.lin_wide if self.ln_eps is not None else self.out
+            for j in range(n):
+                self.x_in[j] = z
+                self.y[j] = (self.out[:, j * Z:(j + 1) * Z], wide)
+            plan._emit(lib.mmvae_cond_linear_fwd_multi, n, R, Z, Z, _p(z), Z, 0, _p(params), _p(self.w_off), _p(self.b_off),
+                       self._ptr(0, "cond"), self._ptr(0, "rows"), self.P, _p(lin_out), wide, Z)
+            if self.ln_eps is not None:  # row r, position j of [R, n Z] = row r n + j of [R n, Z]
+                plan._emit(lib.mmvae_layernorm_fwd, R * n, Z, _p(self.lin_wide), Z, self.ln_eps, _p(self.out), Z,
+                           _p(self.mean_all), _p(self.invstd_all))
+            return self.out, wide
         cur = z
         for j in range(self.n_pos):
             x = z if self.parallel else cur
@@ -179,6 +203,19 @@ class CondProgram:
         plan, lib, R, Z = self.plan, self.plan.lib, self.R, self.Z
         a = self.opt.arena
         g, ldg = self.d_out, self.d_out.shape[1]
+        if self.batched:
+            n = self.n_pos
+            gl = g
+            if self.ln_eps is not None:
+                plan._emit(lib.mmvae_layernorm_bwd, R * n, Z, _p(g), Z, _p(self.out), Z, _p(self.invstd_all), _p(self.gl_wide), Z)
+                gl = self.gl_wide
+            plan._emit(lib.mmvae_cond_linear_bwd_dw_multi, n, self.n_chunks, self._ptr(0, "chunk_dst"), self._ptr(0, "chunk_beg"),
+                       self._ptr(0, "chunk_end"), self._ptr(0, "rows"), self.P, Z, Z, _p(gl), ldg, Z, _p(self.x_in[0]), Z, 0,
+                       _p(a.grad), _p(self.w_off), _p(self.b_off), self.n_red, self._ptr(0, "red_cond"),
+                       self._ptr(0, "red_slot"), self._ptr(0, "red_n"), _p(self.dw_partials), self.part_stride)
+            plan._emit(lib.mmvae_cond_linear_bwd_dx_multi, n, R, Z, Z, _p(gl), ldg, Z, _p(a.data), _p(self.w_off),
+                       self._ptr(0, "cond"), self.P, _p(dz), Z, 0)
+            return
         for j in range(self.n_pos - 1, -1, -1):
             y, ldy = self.y[j]
             gj = g[:, j * Z:(j + 1) * Z] if self.parallel else g

@@ -858,6 +858,98 @@ def test_cond_linear_fwd_bwd(ops, B, n_in, n_out, C):
     assert bool((Gc[~touched] == 7.0).all()), "gradients of absent conditions (and the gaps) must not be written"
 
 
+@pytest.mark.parametrize("B,Z,counts", [(512, 128, [8, 2, 273, 4644, 4, 1]), (100, 24, [3, 1, 7]), (33, 8, [5, 2])])
+def test_cond_linear_multi_positions_match_single_launches(ops, B, Z, counts):
+    """mmvae_cond_linear_{fwd,bwd_dw,bwd_dx}_multi (ABI 9): the positions of a "parallel" selection order in ONE launch
+    each (ConditionalLayers.forward, components.py:586-631) against one launch per position of the single-position entry
+    points: forward and weight / bias gradients bit for bit, dx (another summation tree) to 1e-6 and against fp64."""
+    import ctypes as C  # noqa: F401
+
+    from mmvae_amd import _lib, cond_tables as CT
+
+    lib = _lib.load()
+    n_pos = len(counts)
+    g = torch.Generator().manual_seed(B + Z)
+    x = torch.randn(B, Z, generator=g).cuda()
+    dy = torch.randn(B, n_pos * Z, generator=g).cuda()          # [B, n_pos Z]: position j owns columns j Z .. (j + 1) Z
+    # one arena with every position's blocks; global block index = base_j + local index
+    w_off, b_off, pos, bases = [], [], 8, []
+    for c in counts:
+        bases.append(len(w_off))
+        for _ in range(c):
+            w_off.append(pos)
+            pos += Z * Z + 4
+        for _ in range(c):
+            b_off.append(pos)
+            pos += Z + 4
+    params = (torch.randn(pos, generator=g) * 0.3).cuda()
+    wo, bo = torch.tensor(w_off, dtype=torch.int64).cuda(), torch.tensor(b_off, dtype=torch.int64).cuda()
+    P = CT.words(B)
+    lay = CT.layout(B)
+    pack = np.zeros(n_pos * P, dtype=np.int32)
+    conds = []
+    for j, c in enumerate(counts):
+        local = torch.randint(0, c, (B,), generator=g).numpy().astype("int32")
+        conds.append(local)
+        CT.fill_padded(pack[j * P:(j + 1) * P], CT.group_tables(local, bases[j]), B)
+    tbl = torch.from_numpy(pack).cuda()
+    ptr = lambda j, name: tbl.data_ptr() + 4 * (j * P + lay[name])
+    st = torch.cuda.current_stream().cuda_stream
+    n_chunks, n_red = CT.max_chunks(B), CT.max_reductions(B)
+    slot = CT.partial_slots(B) * (Z * Z + Z)
+    # ---- one launch per position
+    y1 = torch.zeros(B, n_pos * Z, device="cuda")
+    G1 = torch.full((pos,), 7.0, device="cuda")
+    dx1 = torch.zeros(B, Z, device="cuda")
+    part = torch.zeros(n_pos * slot, device="cuda")
+    for j in range(n_pos):
+        assert lib.mmvae_cond_linear_fwd(B, Z, Z, x.data_ptr(), Z, params.data_ptr(), wo.data_ptr(), bo.data_ptr(),
+                                         ptr(j, "cond"), ptr(j, "rows"), y1.data_ptr() + 4 * j * Z, n_pos * Z, st) == 0
+    for j in range(n_pos - 1, -1, -1):
+        assert lib.mmvae_cond_linear_bwd_dw(n_chunks, ptr(j, "chunk_dst"), ptr(j, "chunk_beg"), ptr(j, "chunk_end"),
+                                            ptr(j, "rows"), Z, Z, dy.data_ptr() + 4 * j * Z, n_pos * Z, x.data_ptr(), Z,
+                                            G1.data_ptr(), wo.data_ptr(), bo.data_ptr(), n_red, ptr(j, "red_cond"),
+                                            ptr(j, "red_slot"), ptr(j, "red_n"), part.data_ptr(), st) == 0
+        assert lib.mmvae_cond_linear_bwd_dx(B, Z, Z, dy.data_ptr() + 4 * j * Z, n_pos * Z, params.data_ptr(), wo.data_ptr(),
+                                            ptr(j, "cond"), ptr(j, "rows"), dx1.data_ptr(), Z, int(j != n_pos - 1), st) == 0
+    # ---- all positions per launch
+    y2 = torch.zeros(B, n_pos * Z, device="cuda")
+    G2 = torch.full((pos,), 7.0, device="cuda")
+    dx2 = torch.zeros(B, Z, device="cuda")
+    assert lib.mmvae_cond_linear_fwd_multi(n_pos, B, Z, Z, x.data_ptr(), Z, 0, params.data_ptr(), wo.data_ptr(), bo.data_ptr(),
+                                           ptr(0, "cond"), ptr(0, "rows"), P, y2.data_ptr(), n_pos * Z, Z, st) == 0
+    assert lib.mmvae_cond_linear_bwd_dw_multi(n_pos, n_chunks, ptr(0, "chunk_dst"), ptr(0, "chunk_beg"), ptr(0, "chunk_end"),
+                                              ptr(0, "rows"), P, Z, Z, dy.data_ptr(), n_pos * Z, Z, x.data_ptr(), Z, 0,
+                                              G2.data_ptr(), wo.data_ptr(), bo.data_ptr(), n_red, ptr(0, "red_cond"),
+                                              ptr(0, "red_slot"), ptr(0, "red_n"), part.data_ptr(), slot, st) == 0
+    assert lib.mmvae_cond_linear_bwd_dx_multi(n_pos, B, Z, Z, dy.data_ptr(), n_pos * Z, Z, params.data_ptr(), wo.data_ptr(),
+                                              ptr(0, "cond"), P, dx2.data_ptr(), Z, 0, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2) and torch.equal(G1, G2)
+    assert rel_l2(dx2, dx1) < 1e-6
+    # fp64 reference of y and dx
+    Pd = params.double().cpu()
+    y_ref = torch.zeros(B, n_pos * Z, dtype=torch.float64)
+    dx_ref = torch.zeros(B, Z, dtype=torch.float64)
+    for j in range(n_pos):
+        for b in range(0, B, max(1, B // 16)):  # a sample of the cells
+            c = bases[j] + int(conds[j][b])
+            W = Pd[w_off[c]:w_off[c] + Z * Z].view(Z, Z)
+            y_ref[b, j * Z:(j + 1) * Z] = W @ x[b].double().cpu() + Pd[b_off[c]:b_off[c] + Z]
+    rows = list(range(0, B, max(1, B // 16)))
+    assert rel_l2(y2.cpu()[rows], y_ref[rows]) < 1e-5
+    for b in rows:
+        for j in range(n_pos):
+            c = bases[j] + int(conds[j][b])
+            dx_ref[b] += Pd[w_off[c]:w_off[c] + Z * Z].view(Z, Z).t() @ dy[b, j * Z:(j + 1) * Z].double().cpu()
+    assert rel_l2(dx2.cpu()[rows], dx_ref[rows]) < 1e-5
+    # accumulate flag of the multi dx
+    assert lib.mmvae_cond_linear_bwd_dx_multi(n_pos, B, Z, Z, dy.data_ptr(), n_pos * Z, Z, params.data_ptr(), wo.data_ptr(),
+                                              ptr(0, "cond"), P, dx2.data_ptr(), Z, 1, st) == 0
+    torch.cuda.synchronize()
+    assert rel_l2(dx2, 2 * dx1) < 1e-6
+
+
 def test_cross_entropy_heads_one_launch(ops):
     """mmvae_cross_entropy_heads: all heads of an adversary on one packed logits matrix == one launch per head."""
     from mmvae_amd import _lib

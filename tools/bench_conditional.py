@@ -22,7 +22,7 @@ SIZES = {"assay": 8, "sex": 2, "dataset_id": 273, "donor_id": 4644}
 FULL_GENES = {"human": 60530, "mouse": 52437}  # configs/model/compare/adversarial-conditional.yaml:85,101
 
 
-def build(root, G=20000, Z=128, use_engine=False, full=False):
+def build(root, G=20000, Z=128, use_engine=False, full=False, parallel=False):
     """full: the reference's adversarial-conditional model at its real size -- 60 530 / 52 437 genes, conditional layers
     assay / dataset_id / donor_id / tissue (per species) / species, two adversaries (on h1 [256,128,64] and on z [128,64], human_only.yaml:
     103-157) with heads for the four conditions whose class counts ship with the reference."""
@@ -56,9 +56,13 @@ def build(root, G=20000, Z=128, use_engine=False, full=False):
         base.Adversarial.labels.clear()
         advs = [base.Adversarial(encoder=cfg(enc), heads=cfg([enc[-1]], relu=False), conditions=list(SIZES),
                                  labels_dir=os.path.join(root, "labels")) for enc in ([256, 128, 64], [Z, 64])]
+    # parallel: the reference's default (human_only.yaml:78-79) -- every layer reads z, the outputs are concatenated and a
+    # Linear(n_keys * Z, Z) + ReLU in front of the decoder takes them in (clvae.py:55-79)
+    extra = dict(concat_config=base.ConcatBlockConfig(dropout_rate=0.0, use_batch_norm=False, use_layer_norm=False,
+                                                      activation_fn=nn.ReLU)) if parallel else {}
     vae = CLVAE(latent_dim=Z, encoder_config=cfg([512, 256], bn=True, hidden=True), decoder_config=cfg([Z, 256, 512]),
                 conditional_config=cfg([Z], relu=False, ln=True), conditionals_directory=root, conditionals=list(keys),
-                selection_order=list(keys), hidden_z=full)
+                selection_order=["parallel"] if parallel else list(keys), hidden_z=full, **extra)
     clip = lambda: GradientClipConfig(val=10, algorithm="norm")
     torch.manual_seed(0)
     return CMMVAEModel(CMMVAE(vae, base.Experts(experts), advs), adv_weight=25 if full else None,
@@ -72,13 +76,13 @@ def metadata(B, eid, seed):
     return pd.DataFrame(md)
 
 
-def run_engine(steps=60, warm=12, B=512, G=20000, full=False):
+def run_engine(steps=60, warm=12, B=512, G=20000, full=False, parallel=False):
     """The same model through the captured engine (conditional layers inside the program); no host read-back inside the
     timed region, metadata frames prepared beforehand (the feed's job)."""
     from mmvae_amd import synthetic
 
     with tempfile.TemporaryDirectory() as d:
-        model = build(d, G, use_engine=True, full=full)
+        model = build(d, G, use_engine=True, full=full, parallel=parallel)
         model.train()
         model.trainer.set_stage("training")
         if full:
@@ -136,6 +140,14 @@ if __name__ == "__main__":
         ms_f, first_f, last_f = run_engine(full=True)
         print(f"reference's adversarial-conditional model, 60530 / 52437 genes, B = 512, captured engine: "
               f"{ms_f:8.2f} ms / step = {512 / ms_f * 1e3:,.0f} cells/s   losses {first_f} ... {last_f:.1f}")
+        sys.exit(0)
+    if "--parallel" in sys.argv:  # the reference's default selection order; MMVAE_COND_BATCHED=0: one launch per position
+        import random
+
+        random.seed(0)
+        ms_p, first_p, last_p = run_engine(parallel=True)
+        print(f"captured engine, selection order 'parallel' (MMVAE_COND_BATCHED={os.environ.get('MMVAE_COND_BATCHED', '1')}): "
+              f"{ms_p:8.2f} ms / step   losses {first_p} ... {last_p:.1f}")
         sys.exit(0)
     ms_e, first_e, last_e = run_engine()
     print(f"captured engine     : {ms_e:8.2f} ms / step   losses {first_e} ... {last_e:.1f} (device Philox noise)")
