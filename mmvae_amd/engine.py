@@ -549,7 +549,12 @@ class StepEngine:
             return None
         x_n, eid_n = next_batch
         m = self.model.module
-        if eid_n == plan_eid or eid_n not in m.experts or getattr(m.vae, "conditionals", None) is not None:
+        if eid_n == plan_eid or eid_n not in m.experts:
+            return None
+        if getattr(m.vae, "conditionals", None) is not None:
+            # (measured, r5: the conditional programs get SLOWER with it -- 1.50 -> 2.2-2.4 ms: they run with the host only
+            # just ahead of the device (index tables derived from the metadata and uploaded before every replay), and a
+            # graph that forks at its head takes the host longer to hand over)
             return None
         if len(m.adversarials) > 0 and not (st.prefetch_adv and self.side_stream2 is not None):
             return None  # (adversarial programs: the product takes the second branch stream, free until the late branch)

@@ -101,6 +101,9 @@ def run_engine(steps=60, warm=12, B=512, G=20000, full=False, parallel=False):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
             eid = ("human", "mouse")[i % 2]
+            if i + 1 < steps and os.environ.get("MMVAE_BENCH_LOOKAHEAD", "1") != "0":  # the loop's look-ahead (trainer.Lookahead)
+                nxt = ("human", "mouse")[(i + 1) % 2]
+                model.hint_next_batch((xs[nxt], mds[i + 1], nxt))
             model.training_step((xs[eid], mds[i], eid), i)
             if i < 3:
                 first.append(float(model.logged[f"loss/training/{eid}"]))
