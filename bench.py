@@ -381,13 +381,20 @@ def main():
         x, meta = data[eid][(i // len(eids)) % n_res]
         return x, meta, eid
 
+    pending = []
+
     def step(i):
         if sim is not None:
             lib_, side_, cus_, lds_, us_ = sim
             side_.wait_stream(torch.cuda.current_stream())
             _l.check(lib_.mmvae_debug_occupy(cus_, lds_, us_, None, side_.cuda_stream), "mmvae_debug_occupy")
-        if feed is not None:
-            x, meta, eid = next(feed)
+        if feed is not None:  # streamed batches: one batch of look-ahead, like mmvae_amd.trainer.Lookahead
+            if not pending:
+                pending.append(next(feed))
+            x, meta, eid = pending.pop()
+            pending.append(next(feed))
+            if a.mode == "train" and not a.no_lookahead:
+                model.hint_next_batch(pending[0])
         else:
             x, meta, eid = batch_of(i)
         if a.mode == "train":

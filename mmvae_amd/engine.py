@@ -227,7 +227,9 @@ class StepEngine:
         # software pipelining across steps: what the last training program computed ahead for the next one
         # (training_step, "prefetch"): None or a dict(eid, ptr, shape, stride, version, w_version, slabs)
         self._prefetched: Optional[dict] = None
-        self.prefetch_stats = {"issued": 0, "consumed": 0, "discarded": 0}
+        self.prefetch_stats = {"issued": 0, "consumed": 0, "discarded": 0, "staged_ahead": 0}
+        self._next_seen: Dict[tuple, int] = {}   # announced batches by (expert, pointer, stride, shape): resident or streamed?
+        self._staged: Dict[str, tuple] = {}      # expert -> (pointer, shape, stride, version) of the batch in its static input buffer
 
     def _configure_parallel(self) -> None:
         """Overlapped data parallelism (default whenever gradients are exchanged).  The active expert's parameters are
@@ -453,7 +455,8 @@ class StepEngine:
             from . import ops
 
             x_in = self.buf(f"x_static.{base_key[1]}", (B, x.shape[1]))
-            ops.csr_to_dense(x, out=x_in)
+            if self._staged.pop(base_key[1], None) != self._batch_sig(x):  # (else: densified when it was announced)
+                ops.csr_to_dense(x, out=x_in)
             return base_key + (0, 0), x_in
         pkey = base_key + (x.data_ptr(), x.stride(0))
         seen = self._ptr_seen.get(pkey, 0)
@@ -465,7 +468,9 @@ class StepEngine:
         if direct_ok and (pkey in self._plans or (seen >= 1 and n_ptr_plans < MAX_POINTER_PLANS)):
             return pkey, x
         x_in = self.buf(f"x_static.{base_key[1]}", (B, x.shape[1]))
-        if x.is_contiguous():  # own 16-byte copy kernel: the runtime's blit kernel reaches < 1 TB/s here
+        if self._staged.pop(base_key[1], None) == self._batch_sig(x):
+            pass  # the previous step staged this very batch when it was announced (_stage_next)
+        elif x.is_contiguous():  # own 16-byte copy kernel: the runtime's blit kernel reaches < 1 TB/s here
             from . import ops
 
             ops.axpby(1.0, x, 0.0, x_in)
@@ -558,13 +563,49 @@ class StepEngine:
             return None
         if len(m.adversarials) > 0 and not (st.prefetch_adv and self.side_stream2 is not None):
             return None  # (adversarial programs: the product takes the second branch stream, free until the late branch)
-        if (not torch.is_tensor(x_n) or x_n.layout != torch.strided or not x_n.is_cuda or x_n.dtype != torch.float32
-                or x_n.dim() != 2 or x_n.stride(1) != 1):
+        if not torch.is_tensor(x_n) or not x_n.is_cuda or x_n.dtype != torch.float32 or x_n.dim() != 2:
+            return None
+        if x_n.layout != torch.sparse_csr and (x_n.layout != torch.strided or x_n.stride(1) != 1):
             return None
         l0 = m.experts[eid_n].encoder.fc_layers[0]
         if not hasattr(l0, "bn") or x_n.shape[1] != l0.lin.in_features:
             return None
         return eid_n, x_n
+
+    @staticmethod
+    def _batch_sig(x: torch.Tensor) -> tuple:
+        """What a batch tensor is recognised by one step later: storage pointer(s), shape, stride, torch version counter."""
+        if x.layout == torch.sparse_csr:
+            v, c = x.values(), x.crow_indices()
+            return ("csr", v.data_ptr(), c.data_ptr(), x.col_indices().data_ptr(), tuple(x.shape), v._version, c._version)
+        return (x.data_ptr(), tuple(x.shape), x.stride(0), x._version)
+
+    def _stage_next(self, eid_n: str, x_n: torch.Tensor) -> torch.Tensor:
+        """The tensor this step's program reads the announced batch from.  A resident batch (its pointer has been announced
+        before) is read in place.  A streamed one -- a new tensor every step -- is copied into the next expert's static
+        input buffer NOW: that is the staging copy its own step would make at its start (_select_input), made one step
+        earlier, so the program's pointers stay the same from step to step (no plan per batch) and the next step finds its
+        input in place (`_staged`)."""
+        from . import ops
+
+        buf = self.buf(f"x_static.{eid_n}", tuple(x_n.shape))
+        if x_n.layout == torch.sparse_csr:  # a CSR batch is densified into that buffer by its own step anyway: one step early
+            ops.csr_to_dense(x_n, out=buf)
+        else:
+            k = (eid_n, x_n.data_ptr(), x_n.stride(0), tuple(x_n.shape))
+            seen = self._next_seen.get(k, 0)
+            if len(self._next_seen) > 4096:
+                self._next_seen.clear()
+            self._next_seen[k] = seen + 1
+            if seen >= 2:
+                return x_n
+            if x_n.is_contiguous():
+                ops.axpby(1.0, x_n, 0.0, buf)
+            else:
+                buf.copy_(x_n)
+        self._staged[eid_n] = self._batch_sig(x_n)
+        self.prefetch_stats["staged_ahead"] += 1
+        return buf
 
     def _take_prefetched(self, eid: str, x: torch.Tensor):
         """The slabs computed ahead for this step, when they are (still) the product of this batch and these weights."""
@@ -572,8 +613,7 @@ class StepEngine:
         if pf is None:
             return None
         w = self.model.module.experts[eid].encoder.fc_layers[0].lin.weight if eid in self.model.module.experts else None
-        ok = (pf["eid"] == eid and w is not None and pf["ptr"] == x.data_ptr() and pf["shape"] == tuple(x.shape)
-              and pf["stride"] == x.stride(0) and pf["version"] == x._version and pf["w_version"] == w._version)
+        ok = pf["eid"] == eid and w is not None and pf["sig"] == self._batch_sig(x) and pf["w_version"] == w._version
         self.prefetch_stats["consumed" if ok else "discarded"] += 1
         return pf["slabs"] if ok else None
 
@@ -597,6 +637,9 @@ class StepEngine:
         if x is not x_arg:
             self._prefetched = None
         target = self._prefetch_target(expert_id, B, K, iwae, next_batch)
+        hinted = target[1] if target else None  # the caller's tensor: what the next step will be recognised by
+        if target is not None:
+            target = (target[0], self._stage_next(*target))
         tsig = (target[0], target[1].data_ptr(), tuple(target[1].shape), target[1].stride(0)) if target else None
         key, x_in = self._select_input(x, ("train-iwae" if iwae else "train", expert_id, B, K, explicit,
                                            ahead.data_ptr() if ahead is not None else 0, tsig),
@@ -622,10 +665,9 @@ class StepEngine:
         if ev is not None:
             self._pending[expert_id] = ev
         if target is not None:  # this program has computed the next step's first product
-            x_n = target[1]
+            x_n = hinted
             w_n = model.module.experts[target[0]].encoder.fc_layers[0].lin.weight
-            self._prefetched = dict(eid=target[0], ptr=x_n.data_ptr(), shape=tuple(x_n.shape), stride=x_n.stride(0),
-                                    version=x_n._version, w_version=w_n._version, slabs=plan.prefetch_slabs)
+            self._prefetched = dict(eid=target[0], sig=self._batch_sig(x_n), w_version=w_n._version, slabs=plan.prefetch_slabs)
             self.prefetch_stats["issued"] += 1
         if plan.cond is not None:
             plan.cond.commit()

@@ -147,15 +147,27 @@ def _run_c2(steps, env, attach=False, keep_engine=False, config="c2", hints=None
         eids = list(cfg["experts"].keys())
         data = {eid: (synthetic.synthetic_counts(B, G, seed=77 + i, device=device), synthetic.synthetic_metadata(B, seed=5))
                 for i, (eid, G) in enumerate(cfg["experts"].items())}
-        for i in range(steps):
-            eid = eids[i % len(eids)]
-            if hints is not None:  # the loop's look-ahead (CMMVAEModel.hint_next_batch): hints(i) -> (x, meta, eid) | None
-                model.hint_next_batch(hints(i, data, eids))
-            model.training_step((*data[eid], eid), i)
+        if hints == "streamed":
+            # a loader that yields a NEW tensor every step (streamed data), wrapped in the trainer's Lookahead
+            from mmvae_amd.trainer import Lookahead
+
+            def loader():
+                for i in range(steps):
+                    e = eids[i % len(eids)]
+                    yield data[e][0].clone(), data[e][1], e
+
+            for i, batch in enumerate(Lookahead(loader(), model)):
+                model.training_step(batch, i)
+        else:
+            for i in range(steps):
+                eid = eids[i % len(eids)]
+                if hints is not None:  # the loop's look-ahead (CMMVAEModel.hint_next_batch): hints(i) -> (x, meta, eid) | None
+                    model.hint_next_batch(hints(i, data, eids))
+                model.training_step((*data[eid], eid), i)
         model._flush_engine()
         torch.cuda.synchronize()
         if hints is not None:
-            _run_c2.prefetch_stats = dict(model._engine.prefetch_stats)
+            _run_c2.prefetch_stats = dict(model._engine.prefetch_stats, plans=len(model._engine._plans))
         forked = bool(model._engine.last_plan._forked)
         sd = {k: v.detach().cpu().clone() for k, v in model.module.state_dict().items()}
         tuned = dict(getattr(model._engine, "dp_tuned", {}))
@@ -216,6 +228,16 @@ def test_pipelined_first_product_is_bit_identical_and_survives_wrong_hints():
     torch.cuda.empty_cache()
     got, _ = _run_c2(9, {"MMVAE_PREFETCH": "0"}, hints=right)
     assert _run_c2.prefetch_stats["issued"] == 0 and not [k for k in ref if not torch.equal(ref[k], got[k])]
+    # streamed data: a new tensor every step -- the announced batch is staged into the next expert's static input buffer one
+    # step early (no plan per batch: the programs' pointers stay put), its own step then finds it in place
+    gc.collect()
+    torch.cuda.empty_cache()
+    got, _ = _run_c2(13, {}, hints="streamed")
+    st = _run_c2.prefetch_stats
+    assert st["consumed"] == 12 and st["discarded"] == 0 and st["staged_ahead"] == 12 and st["plans"] <= 9, st  # (not one per batch)
+    ref13, _ = _run_c2(13, {})
+    bad = [k for k in ref13 if not torch.equal(ref13[k], got[k])]
+    assert not bad, f"streamed: {len(bad)} tensors differ, e.g. {bad[:3]} ({st})"
     # the adversarial program (C4): the product runs on the second branch stream beside the adversaries' lane
     gc.collect()
     torch.cuda.empty_cache()
