@@ -55,6 +55,8 @@ class EngineSettings:
     side_dw_dp: int = 125        # MMVAE_SIDE_DW_DP: that branch inside the exchange (data-parallel) program; 0 = in order
     side_dw_any: bool = False    # MMVAE_SIDE_DW_ANY=1: fork outside the measured geometry too
     prefetch_adv: int = 86       # MMVAE_PREFETCH_ADV: its cap in adversarial programs (second branch stream, beside the adversaries' lane: 3 rounds of the 256 work items; C4 1.091 -> 1.070 ms, 128: 1.083, 64: 1.094); 0 = off
+    prefetch_join: bool = False  # MMVAE_PREFETCH_JOIN=1: join that product ahead of the reconstruction launch (diagnostics)
+    cond_batched: bool = True    # MMVAE_COND_BATCHED=0: conditional layers of a "parallel" selection order one launch per position
     prefetch: int = 128          # MMVAE_PREFETCH: workgroup cap of the NEXT step's first forward GEMM beside this step's forward chain (software pipelining across steps, needs the caller's hint); 0 = off
     adv_fused: bool = True       # MMVAE_ADV_FUSED=0: the per-layer adversary program (the path of adversaries with BatchNorm)
     adv_aside: int = 2           # MMVAE_ADV_ASIDE: 0 the fused adversary passes in order; 1 on the branch stream; 2 + the decoder's weight gradient on a second branch from where the first is joined
@@ -76,7 +78,8 @@ class EngineSettings:
             conditionals=e("MMVAE_ENGINE_CONDITIONALS", "1") != "0", graphs=e("MMVAE_NO_GRAPH", "0") == "0",
             planes=e("MMVAE_PLANES", "1") != "0", side_dw=int(e("MMVAE_SIDE_DW", "125")),
             side_dw2=int(e("MMVAE_SIDE_DW2", "185")), side_dw_dp=int(e("MMVAE_SIDE_DW_DP", "125")),
-            side_dw_any=e("MMVAE_SIDE_DW_ANY", "0") != "0", prefetch=int(e("MMVAE_PREFETCH", "128")), prefetch_adv=int(e("MMVAE_PREFETCH_ADV", "86")),
+            side_dw_any=e("MMVAE_SIDE_DW_ANY", "0") != "0", prefetch=int(e("MMVAE_PREFETCH", "128")), prefetch_join=e("MMVAE_PREFETCH_JOIN", "0") == "1",
+            cond_batched=e("MMVAE_COND_BATCHED", "1") != "0", prefetch_adv=int(e("MMVAE_PREFETCH_ADV", "86")),
             adv_fused=e("MMVAE_ADV_FUSED", "1") != "0",
             adv_aside=int(e("MMVAE_ADV_ASIDE", "2")),
             dp_overlap=None if ov == "" else ov != "0", dp_shard=e("MMVAE_DP_SHARD", "1") != "0", dp_kernels=kernels,
@@ -954,7 +957,7 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
         for job in getattr(self, "_x_split_jobs", []):  # tails the chain did not have: passes of their own
             self._emit(lib.mmvae_split_planes_f32, *job)
         self._x_split_jobs = []
-        if getattr(self, "_prefetch_join", False) and os.environ.get("MMVAE_PREFETCH_JOIN", "0") == "1":
+        if getattr(self, "_prefetch_join", False) and eng.settings.prefetch_join:
             # (diagnostics) join the next step's product ahead of the reconstruction launch.  Default: no join here -- a
             # cross-stream join inside the captured program costs ~30 us on this runtime; the branch stream is in order,
             # so the decoder's weight gradient queues behind the product anyway, and the join ahead of the expert's

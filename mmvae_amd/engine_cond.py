@@ -131,9 +131,7 @@ class CondProgram:
         # (r5) "parallel" selection order: the positions read one input and are independent of each other -- ONE launch per
         # kernel for all of them (mmvae_cond_linear_*_multi; LayerNorm over the [R, n_pos Z] matrices as R n_pos rows of Z)
         # instead of n_pos launches of each in sequence (6 positions: 6 x 62 us of latency-bound launches per step)
-        import os
-
-        self.batched = bool(self.parallel and self.n_pos > 1 and Z <= 256 and os.environ.get("MMVAE_COND_BATCHED", "1") != "0")
+        self.batched = bool(self.parallel and self.n_pos > 1 and Z <= 256 and eng.settings.cond_batched)
         self.part_stride = cond_tables.partial_slots(R) * (Z * Z + Z)
         self.dw_partials = eng.buf("cond.dw_partials", ((self.n_pos if self.batched else 1) * self.part_stride,)) if train else None
         self.idx_words = (self.n_pos * self.P + 1) // 2 * 2
