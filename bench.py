@@ -77,6 +77,10 @@ def spawn_ranks(argv, n: int) -> int:
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        if "cpu" in [a_ for i_, a_ in enumerate(argv) if i_ > 0 and argv[i_ - 1] == "--device"]:
+            # a CPU rehearsal never opens a GPU, also on a box that has one (such boxes bound the number of processes per
+            # GPU: eight rehearsal ranks that merely asked torch whether a device exists were killed by the pool's guard)
+            env.update(HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
     code = 0
     try:
@@ -436,6 +440,16 @@ def main():
         for _ in range(period):
             step(n_setup)
             n_setup += 1
+    # ... and until a whole period of steps has REPLAYED its program (a plan is built on its first run, captured on its
+    # second; with the look-ahead a resident batch is staged on its first two announcements and read in place from the third,
+    # which changes the program's key once more): no plan build may fall into the warm-up or the timed steps
+    eng_any = getattr(model, "_engine", None)
+    replayed = 0
+    while eng_any and replayed < period and n_setup < 400:
+        step(n_setup)
+        n_setup += 1
+        plan = getattr(eng_any, "last_plan", None) if a.mode == "train" else None
+        replayed = replayed + 1 if (plan is None or (plan._graphs is not None and plan._runs >= 3)) else 0
     sync()
     for i in range(a.warmup):
         step(n_setup + i)
