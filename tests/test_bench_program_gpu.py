@@ -147,14 +147,15 @@ def _run_c2(steps, env, attach=False, keep_engine=False, config="c2", hints=None
         eids = list(cfg["experts"].keys())
         data = {eid: (synthetic.synthetic_counts(B, G, seed=77 + i, device=device), synthetic.synthetic_metadata(B, seed=5))
                 for i, (eid, G) in enumerate(cfg["experts"].items())}
-        if hints == "streamed":
+        if hints in ("streamed", "streamed_csr"):
             # a loader that yields a NEW tensor every step (streamed data), wrapped in the trainer's Lookahead
             from mmvae_amd.trainer import Lookahead
 
             def loader():
                 for i in range(steps):
                     e = eids[i % len(eids)]
-                    yield data[e][0].clone(), data[e][1], e
+                    x = data[e][0].clone()
+                    yield (x.to_sparse_csr() if hints == "streamed_csr" else x), data[e][1], e
 
             for i, batch in enumerate(Lookahead(loader(), model)):
                 model.training_step(batch, i)
@@ -238,6 +239,14 @@ def test_pipelined_first_product_is_bit_identical_and_survives_wrong_hints():
     ref13, _ = _run_c2(13, {})
     bad = [k for k in ref13 if not torch.equal(ref13[k], got[k])]
     assert not bad, f"streamed: {len(bad)} tensors differ, e.g. {bad[:3]} ({st})"
+    # ... and CSR batches (the datapipe's format, cellxgene_datapipe.py:178-183): densified one step early into the same buffer
+    gc.collect()
+    torch.cuda.empty_cache()
+    got, _ = _run_c2(13, {}, hints="streamed_csr")
+    st = _run_c2.prefetch_stats
+    assert st["consumed"] == 12 and st["discarded"] == 0 and st["staged_ahead"] == 12, st
+    bad = [k for k in ref13 if not torch.equal(ref13[k], got[k])]
+    assert not bad, f"streamed CSR: {len(bad)} tensors differ, e.g. {bad[:3]} ({st})"
     # the adversarial program (C4): the product runs on the second branch stream beside the adversaries' lane
     gc.collect()
     torch.cuda.empty_cache()
