@@ -845,8 +845,8 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
         def emit_prefetch():
             if self.prefetch is None or not train or not (side_dw or adv_forks):
                 return
-            # the NEXT step's first forward product, beside this step's forward chain (joined ahead of the
-            # reconstruction launch, which wants the whole chip)
+            # the NEXT step's first forward product, beside this step's forward chain (no join of its own: the branch
+            # stream is in order and joined ahead of the expert's optimiser -- see the note ahead of the reconstruction launch)
             eid_n, x_n = self.prefetch
             ln = _LayerRef(eng.model.module.experts[eid_n].encoder.fc_layers[0], eng.grad_of, False)
             Bn = x_n.shape[0]
