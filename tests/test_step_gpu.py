@@ -1,10 +1,13 @@
 """Whole-step parity on the GPU: CMMVAEModel.training_step (module path and graph-captured engine) through the HIP
 library vs the golden vectors produced by the reference's own modules.  Tolerances (fp32, stated): scalar losses
 rtol 2e-5; gradient norms rtol 5e-5; post-Adam parameters rel-L2 <= 1e-4; integer buffers exact."""
+import os
+
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from tests import helpers as H  # noqa: E402
 from tests import mirror_utils as MU  # noqa: E402
@@ -381,3 +384,49 @@ def test_ln_dist_module_path_trajectory_without_resync():
             key = f"step{t}/sd/{n}"
             if key in z.files and n not in skip and v.is_floating_point() and not n.endswith("running_mean"):
                 assert H.rel_l2(v, z[key]) < 1e-3, (t, n, H.rel_l2(v, z[key]))
+
+
+def test_parallel_conditional_layers_batched_per_launch_match_one_launch_per_position(monkeypatch):
+    """SURVEY 8 f2 at the reference's scale: CLVAE with selection_order = ["parallel"] (human_only.yaml:78-79), Z = 128, the
+    conditionals assay (8) / sex (2) / dataset_id (273) / donor_id (4 644) + tissue + species -- through the captured engine
+    with all positions per launch (mmvae_cond_linear_*_multi, the default) against one launch per position
+    (MMVAE_COND_BATCHED=0): same Philox noise, same shuffled concatenation order, the same initial parameters.  One step
+    (from identical state: later steps start from parameters a cold, sign-like Adam step has moved by +-lr on rounding
+    noise): the loss to 1e-7, the gradients the step left in the shared VAE's and the expert's arenas to 1e-5 -- forward and
+    the blocks' weight gradients are the same kernels' arithmetic, the input gradient sums the positions in another tree."""
+    import importlib.util
+    import random
+    import tempfile
+
+    from mmvae_amd import rng, synthetic
+    from tests.helpers import rel_l2
+
+    spec = importlib.util.spec_from_file_location("bench_conditional", os.path.join(ROOT, "tools", "bench_conditional.py"))
+    BC = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(BC)
+    G, B = 2048, 512
+    runs = {}
+    for batched in ("1", "0"):
+        monkeypatch.setenv("MMVAE_COND_BATCHED", batched)
+        with tempfile.TemporaryDirectory() as d:
+            torch.manual_seed(0)
+            model = BC.build(d, G, use_engine=True, parallel=True)
+            model.train()
+            model.trainer.set_stage("training")
+            rng.state(torch.device("cuda", 0))
+            rng.reseed(4321)
+            random.seed(7)
+            x = synthetic.synthetic_counts(B, G, seed=3, device="cuda")
+            model.training_step((x, BC.metadata(B, "human", 0), "human"), 0)
+            model._flush_engine()
+            torch.cuda.synchronize()
+            plans = [p for p in model._engine._plans.values() if p.cond is not None]
+            assert plans and all(p.cond.batched == (batched == "1") and p.cond.parallel for p in plans)
+            opts = model.get_optimizers()
+            runs[batched] = (float(model.logged["loss/training/human"]), opts["vae"].arena.grad.detach().cpu().clone(),
+                             opts["experts"]["human"].arena.grad.detach().cpu().clone())
+            model._engine.close()
+    (la, va, ea), (lb, vb, eb) = runs["1"], runs["0"]
+    assert abs(la - lb) <= 1e-7 * abs(lb), (la, lb)
+    assert rel_l2(va.double(), vb.double()) <= 1e-5 and rel_l2(ea.double(), eb.double()) <= 1e-5
+    assert float(va.abs().max()) > 0 and float(ea.abs().max()) > 0
