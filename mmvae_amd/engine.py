@@ -227,6 +227,11 @@ class StepEngine:
         self._configure_parallel()
         self._sig = self._signature()
         self._pending: Dict[str, torch.cuda.Event] = {}
+        import weakref
+
+        me = weakref.ref(self)
+        for opt in opts_list:  # torch-side readers of the moments / parameters wait for updates left on another stream
+            opt.settle = lambda me=me: me() is not None and me().flush()
         # software pipelining across steps: what the last training program computed ahead for the next one
         # (training_step, "prefetch"): None or a dict(eid, ptr, shape, stride, version, w_version, slabs)
         self._prefetched: Optional[dict] = None
@@ -433,10 +438,13 @@ class StepEngine:
 
     def flush(self) -> None:
         """Make the current stream wait for every deferred expert update (before parameters are read elsewhere)."""
+        cur = torch.cuda.current_stream()
         if self.comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
-            torch.cuda.current_stream().wait_stream(self.small_stream)
-            self._pending.clear()
+            cur.wait_stream(self.comm_stream)
+            cur.wait_stream(self.small_stream)
+        for ev in self._pending.values():
+            cur.wait_event(ev)
+        self._pending.clear()
 
     # ------------------------------------------------------------------------------------------------- inputs
     def _enc_planes(self, l0_in: int, l0_out: int, has_bn: bool, B: int, K: int, train: bool, iwae: bool) -> bool:

@@ -122,6 +122,7 @@ class CMMVAEModel(BaseModel):
         hint, self._next_hint = getattr(self, "_next_hint", None), None
         if engine is not None:
             return engine.training_step(x, metadata, expert_id, next_batch=hint)
+        self._flush_engine()  # (a step on the module path behind engine steps: their deferred updates land first)
         if getattr(self.module.vae.encoder, "elbo_mode", "analytic") != "analytic":
             raise NotImplementedError("elbo_mode='iwae' (the opt-in full-IWAE objective) runs in the captured engine only")
 

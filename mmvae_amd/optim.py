@@ -153,6 +153,9 @@ class HipAdam(torch.optim.Optimizer):
         # on the slice -> all-gather of the parameters): the Adam moments of the other slices are then stale here until
         # sync_sharded_state() gathers them (checkpoints, a switch to the module path).
         self.sharded = False
+        # A step engine that leaves part of an update running on another stream (deferred expert updates) points this at
+        # its flush(): called before the moments / parameters are read or rewritten from the torch side.
+        self.settle = None
         self._hip = self.arena.device.type == "cuda"
         if not self._hip and not backend.cpu_plumbing_enabled():
             raise RuntimeError("HipAdam needs device parameters (or caller-enabled backend.cpu_plumbing())")
@@ -284,6 +287,7 @@ class HipAdam(torch.optim.Optimizer):
         if closure is not None:
             raise NotImplementedError("closures are not used by the MMVAE trainer")
         a = self.arena
+        self._settle()
         self.sync_sharded_state()
         reuse = getattr(self, "_norm_valid", False)
         if not reuse:
@@ -420,8 +424,13 @@ class HipAdam(torch.optim.Optimizer):
         a.data.addcdiv_(a.exp_avg, denom, value=-g["lr"] / bc1)
 
     # ---- checkpoint surface compatible with torch.optim.Adam's per-parameter state
+    def _settle(self) -> None:
+        if self.settle is not None:
+            self.settle()
+
     def state_dict(self):
         a = self.arena
+        self._settle()
         self.sync_sharded_state()
         step_of = (lambda i: torch.tensor(float(self._steps[i]))) if self._steps is not None else (
             lambda i: self.state_dev[0].detach().clone().cpu())
@@ -432,6 +441,7 @@ class HipAdam(torch.optim.Optimizer):
 
     def load_state_dict(self, sd):
         a = self.arena
+        self._settle()
         steps = {}
         for i, s in sd["state"].items():
             i = int(i)
