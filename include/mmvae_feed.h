@@ -45,6 +45,19 @@ int mmvae_feed_gather_rows_i32(const void* indptr, const void* indices, int inde
                                int64_t n_chunk_rows, const int64_t* rows, int64_t n_rows, int32_t* out_crow,
                                int32_t* out_col, float* out_val, int64_t capacity, int n_threads, int64_t* out_nnz);
 
+/* Index tables of the conditional layers for one step (reference ConditionalLayer.forward, components.py:
+ * 365-413, groups the cells of a batch by condition with Python masks): from the per-cell block index of each of n_pos
+ * layer applications -- local [n_pos][R], >= 0 -- the padded table set the kernels of csrc/cond_layers.hip read
+ * (mmvae_amd/cond_tables.py documents it and holds the numpy statement of the same function: group_tables +
+ * fill_padded, tested equal).  Position j writes seg + j * seg_stride, in this order:
+ *   cond [R] (block + base[j]), rows [R] (cells sorted by block, stable), chunk_dst / chunk_beg / chunk_end [nc],
+ *   red_cond / red_slot / red_n [nr],   nc = R + R / 32 + 1, nr = R / 33 + 1   (unused slots: dst / cond -1, else 0);
+ * a block's cells are cut into pieces of at most 32; a block of several pieces gets scratch slots (dst = -2 - slot) and
+ * one reduction entry.  present [n_pos][R]: the local indices of the blocks that took part, ascending, n_present[j] of
+ * them.  seg_stride >= 2 R + 3 nc + 3 nr words. */
+int mmvae_feed_cond_tables(int n_pos, int R, const int32_t* local, const int32_t* base, int32_t* seg, int64_t seg_stride,
+                           int32_t* present, int32_t* n_present);
+
 #ifdef __cplusplus
 }
 #endif

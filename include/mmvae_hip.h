@@ -40,7 +40,7 @@ typedef void* mmvae_stream_t; /* hipStream_t */
 /* ABI version: bumped whenever an entry point is added or a signature changes (mmvae_abi_version() returns the
  * value the library was built with; bindings compare it with the header they were written against).
  *   1  round-1 surface (first 20 entry points)      2  end of round 1 (50 entry points)      3+  round 2 */
-#define MMVAE_ABI_VERSION 9
+#define MMVAE_ABI_VERSION 10
 int mmvae_abi_version(void);
 const char* mmvae_build_arch(void);
 
@@ -756,6 +756,13 @@ int mmvae_debug_occupy(int workgroups, int lds_bytes, int micros, float* sink, m
 /* Diagnostics: a marker launch that writes the device's 100 MHz wall clock into buf[slot] -- milestones of a captured
  * program as it runs without a tracer attached (MMVAE_STAMPS=1: the engine places them; tools/stamps_timeline.py). */
 int mmvae_debug_stamp(long long* buf, int slot, mmvae_stream_t stream);
+
+/* (ABI 10) Per-step host tables into device memory by a kernel: dst[0..n_words) = host_src[0..n_words) (32-bit words),
+ * host_src PAGE-LOCKED, device-mapped host memory (hipHostMalloc; MMVAE_ERR_ARG for anything hipHostGetDevicePointer
+ * refuses), read in place over the host link.  The reference builds its per-condition masks on the host and lets torch
+ * copy them (components.py:365-413); a hipMemcpyAsync behind a captured program makes the host wait for that program on
+ * this runtime (SDMA path), a kernel launch does not.  The caller keeps host_src unchanged until the launch has run. */
+int mmvae_upload_words(int64_t n_words, const void* host_src, void* dst, mmvae_stream_t stream);
 
 /* Small utilities used by the step engine: y = alpha*x (+ y), fill. */
 int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, float* y, mmvae_stream_t stream);

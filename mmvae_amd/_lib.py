@@ -108,6 +108,7 @@ PROTOTYPES = {
     "mmvae_philox_fill_jobs": (_i, [_i, _p, _l, _p, _p]),
     "mmvae_philox_fill_jobs_advance": (_i, [_i, _p, _l, _p, C.c_uint64, _p, _p]),
     "mmvae_axpby": (_i, [_l, _f, _p, _f, _p, _p]),
+    "mmvae_upload_words": (_i, [_l, _p, _p, _p]),
     "mmvae_scale_rows": (_i, [_i, _i, _p, _l, _p, _p, _l, _p]),
     "mmvae_debug_stamp": (_i, [_p, _i, _p]),
     "mmvae_weighted_colsum_chunks": (_i, [_i]),

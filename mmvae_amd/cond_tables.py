@@ -87,3 +87,50 @@ def fill_padded(seg: np.ndarray, t: dict, R: int) -> None:
         o = lay[name]
         seg[o:o + k] = t[name]
         seg[o + k:o + cap] = fill
+
+
+def fill_all(seg: np.ndarray, stride: int, local: np.ndarray, base: np.ndarray, R: int) -> list:
+    """The padded tables of SEVERAL applications in one call: local [n, R] int32 (block index per cell and application),
+    base [n]; application j fills seg[j * stride : j * stride + words(R)].  Returns the `present` array of each.  Native
+    (libmmvae_feed.so, mmvae_feed_cond_tables: ~3 us per application where group_tables + fill_padded take ~50 us of
+    numpy calls -- the captured conditional programs are host-bound, tools/time_conditional_host.py)."""
+    from .data import feed_lib
+
+    n = local.shape[0]
+    local = np.ascontiguousarray(local, dtype=np.int32)
+    base = np.ascontiguousarray(base, dtype=np.int32)
+    if local.shape != (n, R) or seg.dtype != np.int32 or not seg.flags["C_CONTIGUOUS"] or seg.size < n * stride:
+        raise ValueError("conditional tables: bad shapes")
+    present = np.empty((n, R), dtype=np.int32)
+    n_present = np.empty(n, dtype=np.int32)
+    rc = feed_lib().mmvae_feed_cond_tables(n, R, local.ctypes.data, base.ctypes.data, seg.ctypes.data, stride,
+                                           present.ctypes.data, n_present.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"mmvae_feed_cond_tables failed with code {rc} (negative block index / tables do not fit)")
+    return [present[j, :n_present[j]] for j in range(n)]
+
+
+_LOOKUP = None
+
+
+def lookup_i32(table: dict, values: list, out: np.ndarray) -> int:
+    """out[i] = table[values[i]] (int32) through csrc/pylookup.c (CPython API under the interpreter lock: ~10 us per 512
+    values where the interpreter takes 40-60).  Returns len(values) when every value was a key, else the index of the
+    first one that was not (the caller extends `table` and calls again)."""
+    global _LOOKUP
+    if _LOOKUP is None:
+        import ctypes as C
+        import os
+        import subprocess
+
+        here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+        path = os.path.join(here, "_mmvae_pylookup.so")
+        if not os.path.exists(path):
+            subprocess.run(["make", "-C", here, "_mmvae_pylookup.so"], check=True, capture_output=True)
+        fn = C.PyDLL(path).mmvae_py_lookup_i32
+        fn.restype = C.c_ssize_t
+        fn.argtypes = [C.py_object, C.py_object, C.c_void_p, C.c_ssize_t]
+        _LOOKUP = fn
+    if out.dtype != np.int32 or not out.flags["C_CONTIGUOUS"] or out.size < len(values):
+        raise ValueError("lookup_i32: out must be a contiguous int32 array of at least len(values)")
+    return int(_LOOKUP(table, values, out.ctypes.data, len(values)))

@@ -1462,6 +1462,37 @@ extern "C" int mmvae_axpby(int64_t n, float alpha, const float* x, float beta, f
     return MMVAE_OK;
 }
 
+// Table upload by a KERNEL: `host_src` is page-locked host memory (hipHostMalloc / torch pin_memory) that the device reads
+// in place.  A hipMemcpyAsync of the same bytes goes to the SDMA engine, and on this runtime an SDMA copy enqueued behind a
+// captured program makes the HOST wait for that program (0.5 ms per step of the conditional programs, whose host side is
+// their limit; with HSA_ENABLE_SDMA=0 the same loop is device-bound) -- a kernel launch is just the next packet.
+__global__ __launch_bounds__(256) void upload_words_kernel(int64_t n, const int32_t* __restrict__ src,
+                                                           int32_t* __restrict__ dst, int vec) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        const int4* s4 = reinterpret_cast<const int4*>(src);
+        int4* d4 = reinterpret_cast<int4*>(dst);
+        for (int64_t i = t0; i < n / 4; i += stride) d4[i] = s4[i];
+        for (int64_t i = n / 4 * 4 + t0; i < n; i += stride) dst[i] = src[i];
+    } else {
+        for (int64_t i = t0; i < n; i += stride) dst[i] = src[i];
+    }
+}
+
+extern "C" int mmvae_upload_words(int64_t n_words, const void* host_src, void* dst, mmvae_stream_t stream) {
+    if (n_words <= 0 || !host_src || !dst) return MMVAE_ERR_ARG;
+    void* dev_src = nullptr;  // (fails for pageable memory: the caller must hand page-locked, mapped memory)
+    if (hipHostGetDevicePointer(&dev_src, const_cast<void*>(host_src), 0) != hipSuccess || !dev_src) {
+        (void)hipGetLastError();
+        return MMVAE_ERR_ARG;
+    }
+    const int vec = ((reinterpret_cast<uintptr_t>(dev_src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    MMVAE_LAUNCH(upload_words_kernel, dim3(grid_for((n_words + 3) / 4, 256, 256)), dim3(256), 0, (hipStream_t)stream,
+                 n_words, static_cast<const int32_t*>(dev_src), static_cast<int32_t*>(dst), vec);
+    MMVAE_LAUNCH_CHECK();
+    return MMVAE_OK;
+}
+
 extern "C" int mmvae_sum_parts_batch(int n_jobs, const mmvae_sum_job* jobs, int64_t max_elems, mmvae_stream_t stream) {
     if (n_jobs <= 0 || n_jobs > 65535 || !jobs || max_elems < 0) return MMVAE_ERR_ARG;
     // workgroups per job: sized for the largest job, 64 when the caller cannot say

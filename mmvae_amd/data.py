@@ -126,7 +126,12 @@ def feed_lib():
                                                C.c_void_p]
         lib.mmvae_feed_gather_rows_i32.restype = C.c_int
         lib.mmvae_feed_gather_rows_i32.argtypes = lib.mmvae_feed_gather_rows.argtypes
-        assert lib.mmvae_feed_abi_version() == 2
+        lib.mmvae_feed_cond_tables.restype = C.c_int
+        lib.mmvae_feed_cond_tables.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                               C.c_void_p]
+        if lib.mmvae_feed_abi_version() != 3:
+            raise RuntimeError(f"{path} is a stale build (ABI {lib.mmvae_feed_abi_version()}, expected 3): "
+                               "make -C mmvae_amd/csrc")
         _FEED = lib
     return _FEED
 

@@ -50,10 +50,19 @@ class _PinnedRing:
         return self.views[self.i]
 
     def upload(self, dst: torch.Tensor) -> None:
-        dst.copy_(self.slots[self.i], non_blocking=True)
-        ev = torch.cuda.Event()
+        """The current slot into `dst`, on the current stream, by a kernel that reads the page-locked slot in place
+        (mmvae_upload_words): `dst.copy_(slot, non_blocking=True)` is a hipMemcpyAsync, which this runtime hands to the
+        SDMA engine -- and an SDMA copy behind a captured program blocked the HOST for ~0.5 ms per step of the conditional
+        programs (tools/debug/cond_up_env.sh: with HSA_ENABLE_SDMA=0 the call took 9 us and the loop became device-bound)."""
+        src = self.slots[self.i]
+        n_bytes = src.numel() * src.element_size()
+        if dst.numel() * dst.element_size() != n_bytes or n_bytes % 4:
+            raise _lib.HipLibraryError("pinned ring: slot and destination differ in size")
+        _lib.check(_lib.load().mmvae_upload_words(n_bytes // 4, src.data_ptr(), dst.data_ptr(), _s()), "mmvae_upload_words")
+        ev = self.events[self.i]
+        if ev is None:
+            ev = self.events[self.i] = torch.cuda.Event()
         ev.record()
-        self.events[self.i] = ev
 
 
 class _LayerRef:

@@ -89,7 +89,7 @@ class CondProgram:
             w_idx = np.array([arena_of(l.weight)[1] for l in lins], dtype=np.int64)
             b_idx = np.array([arena_of(l.bias)[1] for l in lins], dtype=np.int64)
             ent = dict(base=len(w_off), w_idx=w_idx, b_idx=b_idx, layer=layer if isinstance(layer, ConditionalLayer) else None,
-                       raw_index={})
+                       raw_index={}, cat_maps={})
             if ent["layer"] is not None:
                 ent["index"] = {k: i for i, k in enumerate(layer.conditions.keys())}
             w_off += [a.offsets[i] for i in w_idx]
@@ -139,6 +139,8 @@ class CondProgram:
         self.pack_dev = eng.buf(f"cond.pack.{eid}.{int(train)}", (words,), torch.int32)
         self.ring = _PinnedRing(words)
         self._scratch = np.zeros(words, dtype=np.int32)
+        self._local = np.zeros((self.n_pos, R), dtype=np.int32)  # per step: block index of every cell at every position
+        self._bases = np.zeros(self.n_pos, dtype=np.int32)
         self.jobs_ptr = self.pack_dev.data_ptr() + 4 * self.idx_words
         self.partials = eng.buf(f"cond.sqparts.{eid}", (max(self.max_jobs, 1),)) if train else None
         self._active = None
@@ -236,19 +238,43 @@ class CondProgram:
                 g, ldg = dx, Z
 
     # ------------------------------------------------------------------------------------------------ per step
-    def _local_indices(self, ent, key, metadata):
-        np = self.np
-        B = len(metadata)
+    def _local_indices(self, ent, key, metadata, out):
+        """out[:] = block index (inside the layer's bank) of every cell, from the layer's metadata column."""
         if ent["layer"] is None:  # the species block: every cell goes through the one block of this expert
-            return np.zeros(B, dtype=np.int32)
+            out[:] = 0
+            return
         raw_index, layer = ent["raw_index"], ent["layer"]
-        values = metadata[layer.batch_key].tolist()
-        try:
-            return np.fromiter((raw_index[v] for v in values), dtype=np.int32, count=B)
-        except KeyError:
-            for v in set(values) - raw_index.keys():
-                raw_index[v] = ent["index"][layer.format_condition_key(str(v))]  # KeyError: unknown condition
-            return np.fromiter((raw_index[v] for v in values), dtype=np.int32, count=B)
+        col = metadata[layer.batch_key]
+        cat = getattr(col, "cat", None) if str(col.dtype) == "category" else None
+        if cat is not None:
+            # categorical column (what obs frames of the census hold; row slices of one chunk share the categories object):
+            # category -> block once per categories object, then one gather per step -- the look-ups below cost ~0.1 ms per
+            # layer and step on freshly unpickled strings (a cache miss per cell) in a program whose host side is the limit
+            cats = cat.categories
+            hit = ent["cat_maps"].get(id(cats))
+            if hit is None or hit[0] is not cats:
+                if len(ent["cat_maps"]) > 16:
+                    ent["cat_maps"].clear()
+                to_block = self.np.full(len(cats) + 1, -1, dtype=self.np.int32)  # (last entry: code -1 = missing value)
+                for i, v in enumerate(cats.tolist()):
+                    k = layer.format_condition_key(str(v))
+                    if k in ent["index"]:
+                        to_block[i] = ent["index"][k]
+                hit = ent["cat_maps"][id(cats)] = (cats, to_block)
+            codes = cat.codes.to_numpy()
+            self.np.take(hit[1], codes, out=out, mode="wrap")  # (code -1 wraps to the last entry)
+            if (out < 0).any():
+                bad = col.iloc[int(self.np.flatnonzero(out < 0)[0])]
+                raise KeyError(f"{layer.batch_key}: {bad!r} is not a condition of this layer")
+            return
+        values = col.tolist()
+        n = len(values)
+        while True:
+            hit = cond_tables.lookup_i32(raw_index, values, out)
+            if hit == n:
+                return
+            v = values[hit]  # first sight of this raw value: its block (KeyError: unknown condition)
+            raw_index[v] = ent["index"][layer.format_condition_key(str(v))]
 
     def load(self, metadata) -> None:
         import random
@@ -263,15 +289,19 @@ class CondProgram:
         pack = self._scratch
         pack[self.idx_words:] = 0  # unused job slots: empty jobs
         active = [self.dense]
+        if len(metadata) != R:
+            raise _lib.HipLibraryError(f"engine: metadata has {len(metadata)} rows, the batch {R}")
+        local, bases = self._local, self._bases
         for j, key in enumerate(order):
             ent = self.entries[key]
-            local = self._local_indices(ent, key, metadata)
-            if len(local) != R:
-                raise _lib.HipLibraryError(f"engine: metadata has {len(local)} rows, the batch {R}")
-            t = cond_tables.group_tables(local, ent["base"])
-            cond_tables.fill_padded(pack[j * P:(j + 1) * P], t, R)
-            active.append(ent["w_idx"][t["present"]])
-            active.append(ent["b_idx"][t["present"]])
+            self._local_indices(ent, key, metadata, local[j])
+            bases[j] = ent["base"]
+        # every position's padded table set in one native call (cond_tables.fill_all; the numpy statement of the same
+        # tables, group_tables + fill_padded, took 47 us per position of a host-bound program)
+        for key, present in zip(order, cond_tables.fill_all(pack, P, local, bases, R)):
+            ent = self.entries[key]
+            active.append(ent["w_idx"][present])
+            active.append(ent["b_idx"][present])
         if self.train:
             act = np.concatenate(active)
             b1, b2 = self.opt.param_groups[0]["betas"]
@@ -326,9 +356,32 @@ class CondProgram:
             pack[self.idx_words:self.idx_words + 6 * len(jobs)] = jobs.view(np.int32)
             self._active = act
         self.ring.take()[:] = pack
-        self.ring.upload(self.pack_dev)
+        cs = self.eng.table_stream
+        if cs is None:
+            self.ring.upload(self.pack_dev)
+            return
+        # On the engine's table stream: a host-to-device copy enqueued on the stream a captured program has just been
+        # launched on blocks the HOST until that program has (all but) finished on the device -- measured, tools/debug/
+        # cond_launch_cost.py: 0.46 ms per iteration for the replay alone, 0.59 with the copy on another stream, 0.86 with
+        # it on the same one -- and the conditional programs are host-bound.  Ordering: the copy waits for the last
+        # replay that read this table buffer (commit records it; plans of one expert share the buffer), the main stream
+        # waits for the copy.
+        done = self.eng._table_read.get(self.pack_dev.data_ptr())
+        with torch.cuda.stream(cs):
+            if done is not None:
+                cs.wait_event(done)
+            self.ring.upload(self.pack_dev)
+        torch.cuda.current_stream().wait_event(self.ring.events[self.ring.i])
 
     def commit(self) -> None:
         """The step ran: the tensors of its job table have taken one more step."""
+        if self.eng.table_stream is not None:
+            key = self.pack_dev.data_ptr()
+            ev = self.eng._table_read.get(key)
+            if ev is None:
+                ev = self.eng._table_read[key] = torch.cuda.Event()
+            ev.record()  # (behind the replay: the next upload into this buffer waits for it)
+        if not self.train:
+            return
         steps = self.opt.host_steps()
         steps[self._active] += 1

@@ -239,6 +239,60 @@ def test_cond_tables_cover_every_cell_once_in_batch_order(B, C):
     assert not (seg == 12345).any(), "every word of the padded set is written"
 
 
+@pytest.mark.parametrize("R", [512, 1, 7, 33, 64, 1000])
+def test_native_cond_tables_equal_the_numpy_statement(R):
+    """libmmvae_feed.so's mmvae_feed_cond_tables (what the captured conditional programs build their per-step tables
+    with: cond_tables.fill_all, every position in one call) writes exactly the words of group_tables + fill_padded, for
+    dense banks (counting sort), one-block banks, and huge sparse indices (comparison sort)."""
+    from mmvae_amd import cond_tables as CT
+
+    rng = np.random.default_rng(R)
+    sizes = [8, 2, 273, 4644, 4, 1]
+    base = np.cumsum([0] + sizes[:-1]).astype(np.int32)
+    P = CT.words(R)
+    for trial in range(6):
+        local = np.stack([rng.integers(0, s, R) for s in sizes]).astype(np.int32)
+        if trial == 1:
+            local[3] = rng.integers(0, 2**30, R)
+        if trial == 2:
+            local[2] = 5
+        stride = P + trial % 2 * 3
+        seg = np.full(len(sizes) * stride + 5, 12345, dtype=np.int32)
+        present = CT.fill_all(seg, stride, local, base, R)
+        for j in range(len(sizes)):
+            t = CT.group_tables(local[j], int(base[j]))
+            ref = np.zeros(P, dtype=np.int32)
+            CT.fill_padded(ref, t, R)
+            assert np.array_equal(seg[j * stride:j * stride + P], ref), (trial, j)
+            assert np.array_equal(present[j], t["present"])
+        assert (seg[len(sizes) * stride:] == 12345).all()
+    with pytest.raises(ValueError):
+        CT.fill_all(np.zeros(P, dtype=np.int32), P, -np.ones((1, R), dtype=np.int32), base[:1], R)
+
+
+def test_metadata_lookup_helper_matches_the_interpreter():
+    """csrc/pylookup.c (CPython API, ctypes.PyDLL): table[value] for a list of metadata values into an int32 array; the
+    index of the first unknown value instead of an exception; wrong argument types raise."""
+    from mmvae_amd import cond_tables as CT
+
+    rng = np.random.default_rng(0)
+    keys = [f"donor_{i}" for i in range(300)] + [7, 7.5, ("a", 1)]
+    table = {k: i for i, k in enumerate(keys)}
+    values = [keys[i] for i in rng.integers(0, len(keys), 512)]
+    out = np.full(600, -5, dtype=np.int32)
+    assert CT.lookup_i32(table, values, out) == 512
+    assert out[:512].tolist() == [table[v] for v in values] and (out[512:] == -5).all()
+    values[100] = "never seen"
+    assert CT.lookup_i32(table, values, out) == 100
+    assert CT.lookup_i32(table, [], out) == 0
+    with pytest.raises(TypeError):
+        CT.lookup_i32(table, [[1, 2]], out)  # unhashable
+    with pytest.raises(OverflowError):
+        CT.lookup_i32({"a": 2**40}, ["a"], out)
+    with pytest.raises(ValueError):
+        CT.lookup_i32(table, values, np.zeros(3, dtype=np.int32))
+
+
 def test_graft_entry_build_passes():
     """`__graft_entry__.build()` is the driver's "does it build" check: compile both libraries (a no-op when they are up
     to date), load them, verify ABI versions and the target architecture."""

@@ -974,3 +974,26 @@ def test_cross_entropy_heads_one_launch(ops):
                                                           reduction="none") for h, (c0, w) in enumerate(zip(cols, widths))])
     assert rel_l2(rows, want) < 1e-6 and rel_l2(rows, rows_ref) < 1e-6 and rel_l2(d, d_ref) < 1e-6
     assert torch.equal(rows[3], rows_ref[3]) and torch.equal(d[:, cols[3]:], d_ref[:, cols[3]:])  # wide head: same kernel body
+
+
+def test_upload_words_reads_page_locked_host_memory_in_place():
+    """mmvae_upload_words (ABI 10): per-step host tables into device memory by a kernel reading the page-locked source over
+    the host link -- bit-exact for every length / alignment (16-byte groups + tail, element path), in stream order with
+    the kernels that read the table; pageable memory is refused (MMVAE_ERR_ARG), never read."""
+    from mmvae_amd import _lib
+
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    for n in (1, 3, 4, 5, 1023, 4096, 131075):
+        src = torch.randint(-2**31, 2**31 - 1, (n + 4,), dtype=torch.int64).to(torch.int32).pin_memory()
+        for off in (0, 1):  # 16-byte aligned and not
+            dst = torch.full((n + 8,), 7, dtype=torch.int32, device="cuda")
+            rc = lib.mmvae_upload_words(n, src.data_ptr() + 4 * off, dst.data_ptr() + 4 * off, stream)
+            assert rc == 0
+            torch.cuda.synchronize()
+            assert torch.equal(dst[off:off + n].cpu(), src[off:off + n])
+            assert (dst[:off] == 7).all() and (dst[off + n:] == 7).all()
+    pageable = torch.zeros(64, dtype=torch.int32)
+    dst = torch.zeros(64, dtype=torch.int32, device="cuda")
+    assert lib.mmvae_upload_words(64, pageable.data_ptr(), dst.data_ptr(), stream) == _lib.ERR_ARG
+    assert lib.mmvae_upload_words(0, pageable.data_ptr(), dst.data_ptr(), stream) == _lib.ERR_ARG

@@ -430,3 +430,57 @@ def test_parallel_conditional_layers_batched_per_launch_match_one_launch_per_pos
     assert abs(la - lb) <= 1e-7 * abs(lb), (la, lb)
     assert rel_l2(va.double(), vb.double()) <= 1e-5 and rel_l2(ea.double(), eb.double()) <= 1e-5
     assert float(va.abs().max()) > 0 and float(ea.abs().max()) > 0
+
+
+def test_categorical_metadata_columns_give_the_same_conditional_step():
+    """The conditional programs' host side maps each cell's metadata value to a condition block: str columns through
+    dictionary look-ups (csrc/pylookup.c), `category` columns (what the census' obs frames hold) through one category ->
+    block table per categories object and a gather of the codes.  Both must build the same index tables: two steps (one per
+    expert; sequential selection order, shuffled) with the same frames as str and as categorical columns -- bit-identical
+    losses and gradient arenas.  A categorical value no layer knows is refused like a str one."""
+    import importlib.util
+    import random
+    import tempfile
+
+    import pandas as pd
+
+    from mmvae_amd import rng, synthetic
+
+    spec = importlib.util.spec_from_file_location("bench_conditional", os.path.join(ROOT, "tools", "bench_conditional.py"))
+    BC = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(BC)
+    G, B = 2048, 256
+    runs = {}
+    for kind in ("str", "category"):
+        with tempfile.TemporaryDirectory() as d:
+            torch.manual_seed(0)
+            model = BC.build(d, G, use_engine=True)
+            model.train()
+            model.trainer.set_stage("training")
+            rng.state(torch.device("cuda", 0))
+            rng.reseed(99)
+            random.seed(3)
+            out = []
+            for i, eid in enumerate(("human", "mouse")):
+                md = BC.metadata(B, eid, i)
+                if kind == "category":  # categories: every label of the key (more than the batch holds), in another order
+                    for k, n in BC.SIZES.items():
+                        md[k] = pd.Categorical(md[k], categories=[f"{k}_{j}" for j in reversed(range(n))])
+                    md["tissue"] = md["tissue"].astype("category")
+                x = synthetic.synthetic_counts(B, G, seed=3 + i, device="cuda")
+                model.training_step((x, md, eid), i)
+                model._flush_engine()
+                torch.cuda.synchronize()
+                opts = model.get_optimizers()
+                out.append((float(model.logged[f"loss/training/{eid}"]), opts["vae"].arena.grad.detach().cpu().clone(),
+                            opts["experts"][eid].arena.grad.detach().cpu().clone()))
+            if kind == "category":
+                bad = BC.metadata(B, "human", 5)
+                bad["assay"] = pd.Categorical(["assay_0"] * (B - 1) + ["unheard of"])
+                with pytest.raises(KeyError):
+                    model.training_step((x, bad, "human"), 2)
+            runs[kind] = out
+            model._engine.close()
+    for (la, va, ea), (lb, vb, eb) in zip(runs["str"], runs["category"]):
+        assert la == lb and torch.equal(va, vb) and torch.equal(ea, eb)
+        assert float(va.abs().max()) > 0

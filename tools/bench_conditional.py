@@ -69,11 +69,23 @@ def build(root, G=20000, Z=128, use_engine=False, full=False, parallel=False):
                        autograd_config=AutogradConfig(clip(), clip(), clip()), use_engine=use_engine).cuda()
 
 
-def metadata(B, eid, seed):
+_CATS = {}
+
+
+def metadata(B, eid, seed, categorical=False):
+    """categorical: `category` columns whose categories are all labels of the key and are SHARED by every frame -- what
+    row slices of one chunk's obs frame look like (census obs frames hold categorical columns); default: str columns."""
     rng = np.random.default_rng(seed)
     md = {k: [f"{k}_{i}" for i in rng.integers(0, n, B)] for k, n in SIZES.items()}
     md["tissue"] = [f"t_{eid}_{i}" for i in rng.integers(0, 4, B)]
-    return pd.DataFrame(md)
+    md = pd.DataFrame(md)
+    if categorical:
+        for k in md.columns:
+            if k not in _CATS:
+                labels = [f"{k}_{i}" for i in range(SIZES[k])] if k in SIZES else [f"t_{e}_{i}" for e in ("human", "mouse") for i in range(4)]
+                _CATS[k] = pd.CategoricalDtype(labels)
+            md[k] = md[k].astype(_CATS[k])
+    return md
 
 
 def run_engine(steps=60, warm=12, B=512, G=20000, full=False, parallel=False):
@@ -94,7 +106,7 @@ def run_engine(steps=60, warm=12, B=512, G=20000, full=False, parallel=False):
                     g["lr"] = 1e-5
         genes = FULL_GENES if full else {"human": G, "mouse": G}
         xs = {e: synthetic.synthetic_counts(B, g, seed=3 + i, device="cuda") for i, (e, g) in enumerate(genes.items())}
-        mds = [metadata(B, ("human", "mouse")[i % 2], i) for i in range(steps)]
+        mds = [metadata(B, ("human", "mouse")[i % 2], i, categorical="--categorical" in sys.argv) for i in range(steps)]
         first = []
         for i in range(steps):
             if i == warm:
@@ -149,7 +161,8 @@ if __name__ == "__main__":
 
         random.seed(0)
         ms_p, first_p, last_p = run_engine(parallel=True)
-        print(f"captured engine, selection order 'parallel' (MMVAE_COND_BATCHED={os.environ.get('MMVAE_COND_BATCHED', '1')}): "
+        print(f"captured engine, selection order 'parallel' (MMVAE_COND_BATCHED={os.environ.get('MMVAE_COND_BATCHED', '1')}"
+              f"{', categorical metadata' if '--categorical' in sys.argv else ''}): "
               f"{ms_p:8.2f} ms / step   losses {first_p} ... {last_p:.1f}")
         sys.exit(0)
     ms_e, first_e, last_e = run_engine()
