@@ -56,7 +56,6 @@ class EngineSettings:
     side_dw_any: bool = False    # MMVAE_SIDE_DW_ANY=1: fork outside the measured geometry too
     prefetch_adv: int = 86       # MMVAE_PREFETCH_ADV: its cap in adversarial programs (second branch stream, beside the adversaries' lane: 3 rounds of the 256 work items; C4 1.091 -> 1.070 ms, 128: 1.083, 64: 1.094); 0 = off
     prefetch_join: bool = False  # MMVAE_PREFETCH_JOIN=1: join that product ahead of the reconstruction launch (diagnostics)
-    cond_table_stream: bool = True  # MMVAE_COND_TABLE_STREAM=0: the conditional programs' per-step tables are uploaded on the main stream
     cond_batched: bool = True    # MMVAE_COND_BATCHED=0: conditional layers of a "parallel" selection order one launch per position
     prefetch: int = 128          # MMVAE_PREFETCH: workgroup cap of the NEXT step's first forward GEMM beside this step's forward chain (software pipelining across steps, needs the caller's hint); 0 = off
     adv_fused: bool = True       # MMVAE_ADV_FUSED=0: the per-layer adversary program (the path of adversaries with BatchNorm)
@@ -80,7 +79,7 @@ class EngineSettings:
             planes=e("MMVAE_PLANES", "1") != "0", side_dw=int(e("MMVAE_SIDE_DW", "125")),
             side_dw2=int(e("MMVAE_SIDE_DW2", "185")), side_dw_dp=int(e("MMVAE_SIDE_DW_DP", "125")),
             side_dw_any=e("MMVAE_SIDE_DW_ANY", "0") != "0", prefetch=int(e("MMVAE_PREFETCH", "128")), prefetch_join=e("MMVAE_PREFETCH_JOIN", "0") == "1",
-            cond_batched=e("MMVAE_COND_BATCHED", "1") != "0", cond_table_stream=e("MMVAE_COND_TABLE_STREAM", "1") != "0", prefetch_adv=int(e("MMVAE_PREFETCH_ADV", "86")),
+            cond_batched=e("MMVAE_COND_BATCHED", "1") != "0", prefetch_adv=int(e("MMVAE_PREFETCH_ADV", "86")),
             adv_fused=e("MMVAE_ADV_FUSED", "1") != "0",
             adv_aside=int(e("MMVAE_ADV_ASIDE", "2")),
             dp_overlap=None if ov == "" else ov != "0", dp_shard=e("MMVAE_DP_SHARD", "1") != "0", dp_kernels=kernels,
@@ -252,14 +251,6 @@ class StepEngine:
         self.world = mdist.world_size()
         st = self.settings
         self.overlap = mdist.collectives_active() if st.dp_overlap is None else bool(st.dp_overlap)
-        # the per-step index / job tables of conditional-layer programs are uploaded on a stream of their own
-        # (CondProgram.load says why); under a gradient exchange the tables are also read between the captured segments:
-        # the upload stays on the main stream there
-        if mdist.collectives_active() or not st.cond_table_stream:
-            self.table_stream = None
-        elif getattr(self, "table_stream", None) is None:
-            self.table_stream = torch.cuda.Stream(device=self.device)
-        self._table_read: Dict[int, torch.cuda.Event] = {}
         # sharded expert update under data parallelism: reduce-scatter of the gradient arena, clip + Adam on this rank's
         # 1 / world of it, all-gather of the parameters -- the same bytes on the wire as the all-reduce, the 1.2 GB
         # Adam pass world times shorter (MMVAE_DP_SHARD=0: all-reduce + the full update on every rank)
@@ -579,9 +570,9 @@ class StepEngine:
         if eid_n == plan_eid or eid_n not in m.experts:
             return None
         if getattr(m.vae, "conditionals", None) is not None:
-            # (measured, r5: the conditional programs get SLOWER with it -- 1.50 -> 2.2-2.4 ms: they run with the host only
-            # just ahead of the device (index tables derived from the metadata and uploaded before every replay), and a
-            # graph that forks at its head takes the host longer to hand over)
+            # (measured twice, r5: the conditional programs get SLOWER with it -- 1.50 -> 2.2-2.4 ms while their host side
+            # was the limit, 1.20 -> 1.87 ms after it no longer was; the device program itself gains 30 us: the chain's
+            # gather-bound conditional kernels stretch beside the capped GEMM -- profiles/HISTORY.md)
             return None
         if len(m.adversarials) > 0 and not (st.prefetch_adv and self.side_stream2 is not None):
             return None  # (adversarial programs: the product takes the second branch stream, free until the late branch)

@@ -356,31 +356,10 @@ class CondProgram:
             pack[self.idx_words:self.idx_words + 6 * len(jobs)] = jobs.view(np.int32)
             self._active = act
         self.ring.take()[:] = pack
-        cs = self.eng.table_stream
-        if cs is None:
-            self.ring.upload(self.pack_dev)
-            return
-        # On the engine's table stream: a host-to-device copy enqueued on the stream a captured program has just been
-        # launched on blocks the HOST until that program has (all but) finished on the device -- measured, tools/debug/
-        # cond_launch_cost.py: 0.46 ms per iteration for the replay alone, 0.59 with the copy on another stream, 0.86 with
-        # it on the same one -- and the conditional programs are host-bound.  Ordering: the copy waits for the last
-        # replay that read this table buffer (commit records it; plans of one expert share the buffer), the main stream
-        # waits for the copy.
-        done = self.eng._table_read.get(self.pack_dev.data_ptr())
-        with torch.cuda.stream(cs):
-            if done is not None:
-                cs.wait_event(done)
-            self.ring.upload(self.pack_dev)
-        torch.cuda.current_stream().wait_event(self.ring.events[self.ring.i])
+        self.ring.upload(self.pack_dev)
 
     def commit(self) -> None:
         """The step ran: the tensors of its job table have taken one more step."""
-        if self.eng.table_stream is not None:
-            key = self.pack_dev.data_ptr()
-            ev = self.eng._table_read.get(key)
-            if ev is None:
-                ev = self.eng._table_read[key] = torch.cuda.Event()
-            ev.record()  # (behind the replay: the next upload into this buffer waits for it)
         if not self.train:
             return
         steps = self.opt.host_steps()

@@ -15,8 +15,13 @@ python3 bench.py --genes 60530,52437 --no-cpu-baseline --no-parity > gpurun_out/
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_refgenes -o b -- python3 bench.py --genes 60530,52437 --steps 30 --warmup 6 --no-cpu-baseline --no-parity > /dev/null 2>> gpurun_out/${tag}_bench_refgenes.err || exit 1
 cp $(find gpurun_out/prof_${tag}_refgenes -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_kernel_stats_refgenes.csv
 rm -rf gpurun_out/prof_${tag}_refgenes
-python3 tools/bench_conditional.py --engine-only > gpurun_out/${tag}_conditional.txt 2> gpurun_out/${tag}_conditional.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_cond -o b -- python3 tools/bench_conditional.py --engine-only > /dev/null 2>> gpurun_out/${tag}_conditional.err || exit 1
+# the conditional model: sequential selection order, then the reference's default ("parallel") with str and with categorical metadata
+python3 tools/bench_conditional.py --engine-only 2> gpurun_out/${tag}_conditional.err | tail -1 > gpurun_out/${tag}_conditional.txt || exit 1
+python3 tools/bench_conditional.py --parallel 2>> gpurun_out/${tag}_conditional.err | tail -1 >> gpurun_out/${tag}_conditional.txt || exit 1
+python3 tools/bench_conditional.py --parallel --categorical 2>> gpurun_out/${tag}_conditional.err | tail -1 >> gpurun_out/${tag}_conditional.txt || exit 1
+python3 tools/time_conditional_host.py --parallel 2>> gpurun_out/${tag}_conditional.err | tail -2 >> gpurun_out/${tag}_conditional.txt || exit 1
+python3 tools/time_conditional_host.py --parallel --categorical 2>> gpurun_out/${tag}_conditional.err | tail -2 >> gpurun_out/${tag}_conditional.txt || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_cond -o b -- python3 tools/bench_conditional.py --parallel > /dev/null 2>> gpurun_out/${tag}_conditional.err || exit 1
 cp $(find gpurun_out/prof_${tag}_cond -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_kernel_stats_conditional.csv
 rm -rf gpurun_out/prof_${tag}_cond
 bash tools/bench_all_configs.sh > gpurun_out/${tag}_configs.jsonl
