@@ -243,7 +243,7 @@ class SpeciesChunks:
                 yield item
         finally:
             stop.set()
-            if (stop, thread) in _LIVE_PRODUCERS:
+            if _LIVE_PRODUCERS is not None and (stop, thread) in _LIVE_PRODUCERS:
                 _LIVE_PRODUCERS.remove((stop, thread))
 
     # ---- one batch: native gather into a staging slot (worker thread), tensors + H2D (consumer thread)
@@ -427,7 +427,7 @@ class Prefetcher:
                 yield item
         finally:
             stop.set()
-            if entry in _LIVE_PRODUCERS:
+            if _LIVE_PRODUCERS is not None and entry in _LIVE_PRODUCERS:  # (None: the interpreter is shutting down)
                 _LIVE_PRODUCERS.remove(entry)
 
 
