@@ -14,9 +14,12 @@ feeds = {}
 for i, eid in enumerate(("human", "mouse")):
     rows = torch.cat([synthetic.synthetic_counts(B, G, seed=77 + 31 * i + j, device="cpu") for j in range(8)])
     meta = pd.concat([synthetic.synthetic_metadata(B, seed=9 + j) for j in range(8)], ignore_index=True)
-    mdata.write_chunks(os.path.join(tmp, eid), eid, sp.csr_matrix(rows.numpy()), meta, chunk_rows=4 * B, compressed=False)
+    REP = int(os.environ.get("FEED_REP", "1"))  # chunk = 4 * REP batches
+    mdata.write_chunks(os.path.join(tmp, eid), eid, sp.vstack([sp.csr_matrix(rows.numpy())] * REP, format="csr"),
+                       pd.concat([meta] * REP, ignore_index=True), chunk_rows=4 * REP * B, compressed=False)
     feeds[eid] = mdata.SpeciesChunks(os.path.join(tmp, eid), f"{eid}_train_counts_*.npz", f"{eid}_train_metadata_*.pkl", B, eid,
-                                     seed=i, device=dev)
+                                     seed=i, device=dev, workers=int(os.environ.get("FEED_WORKERS", "3")),
+                                     gather_threads=int(os.environ.get("FEED_GT", "2")))
 T = {}
 def timed(owner, name, tag):
     orig = getattr(owner, name)
@@ -31,6 +34,10 @@ timed(mdata.SpeciesChunks, "_tensor", "tensor+h2d")
 timed(mdata.SpeciesChunks, "_gather", "gather(worker)")
 timed(mdata, "load_chunk", "load_chunk(thread)")
 timed(torch, "sparse_csr_tensor", "sparse_csr_tensor")
+import concurrent.futures as _cf
+timed(_cf.Future, "result", "wait for gather")
+timed(_cf.ThreadPoolExecutor, "submit", "submit")
+timed(torch.cuda.Event, "synchronize", "slot event sync")
 _iloc_cls = type(pd.DataFrame({"a": [1]}).iloc)
 timed(_iloc_cls, "__getitem__", "iloc")
 orig_iloc = pd.DataFrame.reset_index
