@@ -132,8 +132,13 @@ class CondProgram:
         # kernel for all of them (mmvae_cond_linear_*_multi; LayerNorm over the [R, n_pos Z] matrices as R n_pos rows of Z)
         # instead of n_pos launches of each in sequence (6 positions: 6 x 62 us of latency-bound launches per step)
         self.batched = bool(self.parallel and self.n_pos > 1 and Z <= 256 and eng.settings.cond_batched)
+        # (r5) sequential order: a position's forward and input gradient depend on the previous position, its WEIGHT
+        # gradient on nothing downstream -- the chain keeps LayerNorm backward + dx per position, the weight gradients of
+        # positions 1 .. n-1 (inputs: the previous positions' outputs, one strided buffer) are ONE batched launch behind
+        # the chain, position 0's (input: z) one more: 2 x 2 launches instead of n x 2 on the critical path
+        self.defer_dw = bool(not self.parallel and self.n_pos > 2 and Z <= 256 and eng.settings.cond_batched and train)
         self.part_stride = cond_tables.partial_slots(R) * (Z * Z + Z)
-        self.dw_partials = eng.buf("cond.dw_partials", ((self.n_pos if self.batched else 1) * self.part_stride,)) if train else None
+        self.dw_partials = eng.buf("cond.dw_partials", ((self.n_pos if (self.batched or self.defer_dw) else 1) * self.part_stride,)) if train else None
         self.idx_words = (self.n_pos * self.P + 1) // 2 * 2
         words = self.idx_words + 6 * self.max_jobs
         self.pack_dev = eng.buf(f"cond.pack.{eid}.{int(train)}", (words,), torch.int32)
@@ -181,11 +186,14 @@ class CondProgram:
                            _p(self.mean_all), _p(self.invstd_all))
             return self.out, wide
         cur = z
+        y_all = self.eng.buf("cond.y_all", (self.n_pos, R, Z)) if self.defer_dw else None
         for j in range(self.n_pos):
             x = z if self.parallel else cur
             self.x_in[j] = x
             if self.parallel:
                 y, ldy = self.out[:, j * Z:(j + 1) * Z], self.out.shape[1]
+            elif y_all is not None:  # one buffer: position j + 1 reads its input at y_all[j] (uniform stride for the batched dW)
+                y, ldy = y_all[j], Z
             else:
                 y, ldy = self.eng.buf(f"cond.y{j}", (R, Z)), Z
             self.y[j] = (y, ldy)
@@ -216,18 +224,25 @@ class CondProgram:
             plan._emit(lib.mmvae_cond_linear_bwd_dx_multi, n, R, Z, Z, _p(gl), ldg, Z, _p(a.data), _p(self.w_off),
                        self._ptr(0, "cond"), self.P, _p(dz), Z, 0)
             return
+        n = self.n_pos
+        gl_all = self.eng.buf("cond.gl_all", (n, R, Z)) if self.defer_dw else None  # every position's pre-LayerNorm gradient
         for j in range(self.n_pos - 1, -1, -1):
             y, ldy = self.y[j]
             gj = g[:, j * Z:(j + 1) * Z] if self.parallel else g
             if self.ln_eps is not None:
-                plan._emit(lib.mmvae_layernorm_bwd, R, Z, _p(gj), ldg, _p(y), ldy, _p(self.invstd[j]), _p(self.gl), Z)
-                gl, ldgl = self.gl, Z
+                gl_j = gl_all[j] if gl_all is not None else self.gl
+                plan._emit(lib.mmvae_layernorm_bwd, R, Z, _p(gj), ldg, _p(y), ldy, _p(self.invstd[j]), _p(gl_j), Z)
+                gl, ldgl = gl_j, Z
+            elif gl_all is not None:  # (no LayerNorm: the incoming gradient is kept for the batched dW below)
+                plan._emit(lib.mmvae_axpby, R * Z, 1.0, _p(gj), 0.0, _p(gl_all[j]))
+                gl, ldgl = gl_all[j], Z
             else:
                 gl, ldgl = gj, ldg
-            plan._emit(lib.mmvae_cond_linear_bwd_dw, self.n_chunks, self._ptr(j, "chunk_dst"), self._ptr(j, "chunk_beg"),
-                       self._ptr(j, "chunk_end"), self._ptr(j, "rows"), Z, Z, _p(gl), ldgl, _p(self.x_in[j]), Z, _p(a.grad),
-                       _p(self.w_off), _p(self.b_off), self.n_red, self._ptr(j, "red_cond"), self._ptr(j, "red_slot"),
-                       self._ptr(j, "red_n"), _p(self.dw_partials))
+            if gl_all is None:
+                plan._emit(lib.mmvae_cond_linear_bwd_dw, self.n_chunks, self._ptr(j, "chunk_dst"), self._ptr(j, "chunk_beg"),
+                           self._ptr(j, "chunk_end"), self._ptr(j, "rows"), Z, Z, _p(gl), ldgl, _p(self.x_in[j]), Z, _p(a.grad),
+                           _p(self.w_off), _p(self.b_off), self.n_red, self._ptr(j, "red_cond"), self._ptr(j, "red_slot"),
+                           self._ptr(j, "red_n"), _p(self.dw_partials))
             if self.parallel:
                 plan._emit(lib.mmvae_cond_linear_bwd_dx, R, Z, Z, _p(gl), ldgl, _p(a.data), _p(self.w_off),
                            self._ptr(j, "cond"), self._ptr(j, "rows"), _p(dz), Z, int(j != self.n_pos - 1))
@@ -236,6 +251,17 @@ class CondProgram:
                 plan._emit(lib.mmvae_cond_linear_bwd_dx, R, Z, Z, _p(gl), ldgl, _p(a.data), _p(self.w_off),
                            self._ptr(j, "cond"), self._ptr(j, "rows"), _p(dx), Z, 0)
                 g, ldg = dx, Z
+        if gl_all is not None:
+            # positions 1 .. n-1: input = the previous position's output (y_all[j - 1]); then position 0 (input z)
+            plan._emit(lib.mmvae_cond_linear_bwd_dw_multi, n - 1, self.n_chunks, self._ptr(1, "chunk_dst"),
+                       self._ptr(1, "chunk_beg"), self._ptr(1, "chunk_end"), self._ptr(1, "rows"), self.P, Z, Z,
+                       _p(gl_all[1]), Z, R * Z, self.y[0][0].data_ptr(), Z, R * Z, _p(a.grad), _p(self.w_off), _p(self.b_off),
+                       self.n_red, self._ptr(1, "red_cond"), self._ptr(1, "red_slot"), self._ptr(1, "red_n"),
+                       self.dw_partials.data_ptr() + 4 * self.part_stride, self.part_stride)
+            plan._emit(lib.mmvae_cond_linear_bwd_dw, self.n_chunks, self._ptr(0, "chunk_dst"), self._ptr(0, "chunk_beg"),
+                       self._ptr(0, "chunk_end"), self._ptr(0, "rows"), Z, Z, _p(gl_all[0]), Z, _p(self.x_in[0]), Z, _p(a.grad),
+                       _p(self.w_off), _p(self.b_off), self.n_red, self._ptr(0, "red_cond"), self._ptr(0, "red_slot"),
+                       self._ptr(0, "red_n"), _p(self.dw_partials))
 
     # ------------------------------------------------------------------------------------------------ per step
     def _local_indices(self, ent, key, metadata, out):

@@ -484,3 +484,44 @@ def test_categorical_metadata_columns_give_the_same_conditional_step():
     for (la, va, ea), (lb, vb, eb) in zip(runs["str"], runs["category"]):
         assert la == lb and torch.equal(va, vb) and torch.equal(ea, eb)
         assert float(va.abs().max()) > 0
+
+
+def test_sequential_conditional_layers_deferred_weight_gradients_are_bit_identical(monkeypatch):
+    """Sequential selection order (compare/conditional.yaml: selection_order null): the engine keeps LayerNorm backward +
+    input gradient per position on the chain and computes the positions' weight gradients behind it in two launches
+    (positions 1 .. n-1 batched, position 0 alone) instead of one per position inside the chain.  Same kernels on the same
+    operands: loss and both gradient arenas bit for bit those of MMVAE_COND_BATCHED=0 (a launch per position)."""
+    import importlib.util
+    import random
+    import tempfile
+
+    from mmvae_amd import rng, synthetic
+
+    spec = importlib.util.spec_from_file_location("bench_conditional", os.path.join(ROOT, "tools", "bench_conditional.py"))
+    BC = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(BC)
+    G, B = 2048, 512
+    runs = {}
+    for batched in ("1", "0"):
+        monkeypatch.setenv("MMVAE_COND_BATCHED", batched)
+        with tempfile.TemporaryDirectory() as d:
+            torch.manual_seed(0)
+            model = BC.build(d, G, use_engine=True)
+            model.train()
+            model.trainer.set_stage("training")
+            rng.state(torch.device("cuda", 0))
+            rng.reseed(77)
+            random.seed(11)
+            x = synthetic.synthetic_counts(B, G, seed=3, device="cuda")
+            model.training_step((x, BC.metadata(B, "human", 0), "human"), 0)
+            model._flush_engine()
+            torch.cuda.synchronize()
+            plans = [p for p in model._engine._plans.values() if p.cond is not None]
+            assert plans and all(p.cond.defer_dw == (batched == "1") and not p.cond.parallel for p in plans)
+            opts = model.get_optimizers()
+            runs[batched] = (float(model.logged["loss/training/human"]), opts["vae"].arena.grad.detach().cpu().clone(),
+                             opts["experts"]["human"].arena.grad.detach().cpu().clone())
+            model._engine.close()
+    (la, va, ea), (lb, vb, eb) = runs["1"], runs["0"]
+    assert la == lb and torch.equal(va, vb) and torch.equal(ea, eb)
+    assert float(va.abs().max()) > 0
