@@ -106,7 +106,8 @@ def run_engine(steps=60, warm=12, B=512, G=20000, full=False, parallel=False):
                     g["lr"] = 1e-5
         genes = FULL_GENES if full else {"human": G, "mouse": G}
         xs = {e: synthetic.synthetic_counts(B, g, seed=3 + i, device="cuda") for i, (e, g) in enumerate(genes.items())}
-        mds = [metadata(B, ("human", "mouse")[i % 2], i, categorical="--categorical" in sys.argv) for i in range(steps)]
+        n_md = min(steps, 72) // 2 * 2  # (long runs cycle through 72 frames: --steps N)
+        mds = [metadata(B, ("human", "mouse")[i % 2], i, categorical="--categorical" in sys.argv) for i in range(n_md)]
         first = []
         for i in range(steps):
             if i == warm:
@@ -115,8 +116,8 @@ def run_engine(steps=60, warm=12, B=512, G=20000, full=False, parallel=False):
             eid = ("human", "mouse")[i % 2]
             if i + 1 < steps and os.environ.get("MMVAE_BENCH_LOOKAHEAD", "1") != "0":  # the loop's look-ahead (trainer.Lookahead)
                 nxt = ("human", "mouse")[(i + 1) % 2]
-                model.hint_next_batch((xs[nxt], mds[i + 1], nxt))
-            model.training_step((xs[eid], mds[i], eid), i)
+                model.hint_next_batch((xs[nxt], mds[(i + 1) % n_md], nxt))
+            model.training_step((xs[eid], mds[i % n_md], eid), i)
             if i < 3:
                 first.append(float(model.logged[f"loss/training/{eid}"]))
         torch.cuda.synchronize()
@@ -151,8 +152,9 @@ def run(grouped: bool, steps=12, B=512, G=20000):
 
 
 if __name__ == "__main__":
+    STEPS = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 60
     if "--full" in sys.argv:
-        ms_f, first_f, last_f = run_engine(full=True)
+        ms_f, first_f, last_f = run_engine(steps=STEPS, full=True)
         print(f"reference's adversarial-conditional model, 60530 / 52437 genes, B = 512, captured engine: "
               f"{ms_f:8.2f} ms / step = {512 / ms_f * 1e3:,.0f} cells/s   losses {first_f} ... {last_f:.1f}")
         sys.exit(0)
@@ -160,12 +162,12 @@ if __name__ == "__main__":
         import random
 
         random.seed(0)
-        ms_p, first_p, last_p = run_engine(parallel=True)
+        ms_p, first_p, last_p = run_engine(steps=STEPS, parallel=True)
         print(f"captured engine, selection order 'parallel' (MMVAE_COND_BATCHED={os.environ.get('MMVAE_COND_BATCHED', '1')}"
               f"{', categorical metadata' if '--categorical' in sys.argv else ''}): "
               f"{ms_p:8.2f} ms / step   losses {first_p} ... {last_p:.1f}")
         sys.exit(0)
-    ms_e, first_e, last_e = run_engine()
+    ms_e, first_e, last_e = run_engine(steps=STEPS)
     print(f"captured engine     : {ms_e:8.2f} ms / step   losses {first_e} ... {last_e:.1f} (device Philox noise)")
     if "--engine-only" in sys.argv:
         sys.exit(0)
