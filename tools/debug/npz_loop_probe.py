@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""The npz-fed C2 training loop of bench.py --input npz, with the main thread's time per step split into: waiting for the
+feed (next), announcing the next batch, training_step (staging + replay).  FEED_REP=r: chunks of 4 r batches."""
+import os, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import pandas as pd, scipy.sparse as sp, torch
+from mmvae_amd import data as mdata, instantiate, synthetic
+from mmvae_amd.trainer import MultiModalBatches
+
+dev = torch.device("cuda", 0)
+B, G = 512, 20000
+model = instantiate.load_yaml(os.path.join(os.path.dirname(__file__), "..", "..", "configs", "model", "c2_two_modality_20k.yaml")).to(dev)
+model.train(); model.trainer.set_stage("training"); model.optimizers()
+REP = int(os.environ.get("FEED_REP", "1"))
+tmp = tempfile.mkdtemp(prefix="npz_probe_")
+feeds = {}
+for i, eid in enumerate(("human", "mouse")):
+    rows = torch.cat([synthetic.synthetic_counts(B, G, seed=77 + 31 * i + j, device="cpu") for j in range(8)])
+    meta = pd.concat([synthetic.synthetic_metadata(B, seed=9 + j) for j in range(8)], ignore_index=True)
+    mdata.write_chunks(os.path.join(tmp, eid), eid, sp.vstack([sp.csr_matrix(rows.numpy())] * REP, format="csr"),
+                       pd.concat([meta] * REP, ignore_index=True), chunk_rows=4 * REP * B, compressed=False)
+    feeds[eid] = mdata.SpeciesChunks(os.path.join(tmp, eid), f"{eid}_train_counts_*.npz", f"{eid}_train_metadata_*.pkl", B, eid,
+                                     seed=i, device=dev, workers=int(os.environ.get("FEED_WORKERS", "3")))
+
+def endless():
+    while True:
+        yield from MultiModalBatches(feeds, seed=0, round_robin=True)
+
+feed = iter(mdata.Prefetcher(endless(), depth=int(os.environ.get("FEED_DEPTH", "3")), device=dev))
+pending = [next(feed)]
+T = {"next": 0.0, "hint": 0.0, "step": 0.0}
+def step(i, timed):
+    x, meta, eid = pending.pop()
+    t0 = time.perf_counter()
+    pending.append(next(feed))
+    t1 = time.perf_counter()
+    if os.environ.get("NO_HINT", "0") != "1":
+        model.hint_next_batch(pending[0])
+    t2 = time.perf_counter()
+    model.training_step((x, meta, eid), i)
+    t3 = time.perf_counter()
+    if timed:
+        T["next"] += t1 - t0; T["hint"] += t2 - t1; T["step"] += t3 - t2
+for i in range(30):
+    step(i, False)
+torch.cuda.synchronize()
+n = 300
+t0 = time.perf_counter()
+for i in range(n):
+    step(30 + i, True)
+torch.cuda.synchronize()
+el = time.perf_counter() - t0
+print(f"rep {REP}: {1e3 * el / n:.3f} ms / step; main thread per step: " + ", ".join(f"{k} {1e3 * v / n:.3f}" for k, v in T.items()),
+      model._engine.prefetch_stats)
