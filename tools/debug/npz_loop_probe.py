@@ -7,6 +7,8 @@ import pandas as pd, scipy.sparse as sp, torch
 from mmvae_amd import data as mdata, instantiate, synthetic
 from mmvae_amd.trainer import MultiModalBatches
 
+if os.environ.get("SWITCH_US"):
+    sys.setswitchinterval(float(os.environ["SWITCH_US"]) * 1e-6)
 dev = torch.device("cuda", 0)
 B, G = 512, 20000
 model = instantiate.load_yaml(os.path.join(os.path.dirname(__file__), "..", "..", "configs", "model", "c2_two_modality_20k.yaml")).to(dev)
@@ -26,7 +28,35 @@ def endless():
     while True:
         yield from MultiModalBatches(feeds, seed=0, round_robin=True)
 
+P = {}
+def timed(owner, name, tag):
+    orig = getattr(owner, name)
+    def wrapper(*a, **k):
+        t0 = time.perf_counter()
+        try:
+            return orig(*a, **k)
+        finally:
+            P[tag] = P.get(tag, 0.0) + time.perf_counter() - t0
+    setattr(owner, name, wrapper)
+timed(mdata.SpeciesChunks, "_tensor", "tensor+h2d")
+timed(mdata.SpeciesChunks, "_gather", "gather(worker)")
+timed(mdata, "load_chunk", "load_chunk(thread)")
+timed(mdata._Workers, "submit", "submit")
+timed(mdata._Workers._Job, "result", "wait gather")
+timed(pd.DataFrame, "take", "take")
+timed(torch.cuda.Event, "synchronize", "slot event sync")
+import queue as _q
+timed(_q.Queue, "put", "queue put (producer blocked when full)")
 feed = iter(mdata.Prefetcher(endless(), depth=int(os.environ.get("FEED_DEPTH", "3")), device=dev))
+if os.environ.get("FEED_PREFILL", "0") == "1":
+    # every batch of the run produced BEFORE the loop (events and all): the loop then shares the interpreter with nobody
+    src = iter(mdata.Prefetcher(endless(), depth=3, device=dev))
+    ready = [next(src) for _ in range(340)]
+    torch.cuda.synchronize()
+    del src
+    import gc; gc.collect()
+    time.sleep(0.5)
+    feed = iter(ready)
 pending = [next(feed)]
 T = {"next": 0.0, "hint": 0.0, "step": 0.0}
 def step(i, timed):
@@ -44,6 +74,7 @@ def step(i, timed):
 for i in range(30):
     step(i, False)
 torch.cuda.synchronize()
+P.clear()
 n = 300
 t0 = time.perf_counter()
 for i in range(n):
@@ -51,4 +82,4 @@ for i in range(n):
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
 print(f"rep {REP}: {1e3 * el / n:.3f} ms / step; main thread per step: " + ", ".join(f"{k} {1e3 * v / n:.3f}" for k, v in T.items()),
-      model._engine.prefetch_stats)
+      "| producer side per batch: " + ", ".join(f"{k} {1e3 * v / n:.3f}" for k, v in sorted(P.items(), key=lambda kv: -kv[1])))
