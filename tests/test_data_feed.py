@@ -239,3 +239,4 @@ def test_index_dtype_option_and_int32_gather(tmp_path):
     assert rc == 0 and got.value == ref.nnz
     assert np.array_equal(crow, ref.indptr) and np.array_equal(col[:ref.nnz], ref.indices)
     assert np.array_equal(val[:ref.nnz], ref.data) and (col[ref.nnz:] == -1).all()
+
