@@ -17,6 +17,7 @@ cp $(find gpurun_out/prof_${tag}_refgenes -name "*kernel_stats.csv" | head -1) g
 rm -rf gpurun_out/prof_${tag}_refgenes
 # the conditional model: sequential selection order, then the reference's default ("parallel") with str and with categorical metadata
 python3 tools/bench_conditional.py --engine-only 2> gpurun_out/${tag}_conditional.err | tail -1 > gpurun_out/${tag}_conditional.txt || exit 1
+python3 tools/bench_conditional.py --engine-only --categorical 2>> gpurun_out/${tag}_conditional.err | tail -1 | sed 's/captured engine     :/captured engine, sequential order, categorical metadata:/' >> gpurun_out/${tag}_conditional.txt || exit 1
 python3 tools/bench_conditional.py --parallel 2>> gpurun_out/${tag}_conditional.err | tail -1 >> gpurun_out/${tag}_conditional.txt || exit 1
 python3 tools/bench_conditional.py --parallel --categorical 2>> gpurun_out/${tag}_conditional.err | tail -1 >> gpurun_out/${tag}_conditional.txt || exit 1
 python3 tools/time_conditional_host.py --parallel 2>> gpurun_out/${tag}_conditional.err | tail -2 >> gpurun_out/${tag}_conditional.txt || exit 1
