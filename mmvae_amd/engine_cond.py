@@ -88,8 +88,11 @@ class CondProgram:
             lins = [b.fc_layers[0].lin for b in blocks]
             w_idx = np.array([arena_of(l.weight)[1] for l in lins], dtype=np.int64)
             b_idx = np.array([arena_of(l.bias)[1] for l in lins], dtype=np.int64)
+            # (value -> block caches are shared by every plan of this expert: a second plan -- another batch size, an
+            # evaluation program -- does not start from empty tables)
+            shared = eng.__dict__.setdefault("_cond_lookup", {}).setdefault((eid, key), dict(raw_index={}, cat_maps={}, last=None))
             ent = dict(base=len(w_off), w_idx=w_idx, b_idx=b_idx, layer=layer if isinstance(layer, ConditionalLayer) else None,
-                       raw_index={}, cat_maps={})
+                       raw_index=shared["raw_index"], cat_maps=shared["cat_maps"], shared=shared)
             if ent["layer"] is not None:
                 ent["index"] = {k: i for i, k in enumerate(layer.conditions.keys())}
             w_off += [a.offsets[i] for i in w_idx]
@@ -278,7 +281,13 @@ class CondProgram:
             # layer and step on freshly unpickled strings (a cache miss per cell) in a program whose host side is the limit
             cats = cat.categories
             hit = ent["cat_maps"].get(id(cats))
-            if hit is None or hit[0] is not cats:
+            if (hit is None or hit[0] is not cats) and len(cats) > 64 and ent["shared"]["last"] is not cats:
+                # a big categories object seen for the first time: building its table costs a Python loop over every
+                # category -- worth it for the categories a chunk's row slices share, not for a frame that was
+                # factorised for this batch alone (it takes the per-cell look-ups below; seen again, it gets its table)
+                ent["shared"]["last"] = cats
+                cat = None
+            elif hit is None or hit[0] is not cats:
                 if len(ent["cat_maps"]) > 16:
                     ent["cat_maps"].clear()
                 to_block = self.np.full(len(cats) + 1, -1, dtype=self.np.int32)  # (last entry: code -1 = missing value)
@@ -287,6 +296,7 @@ class CondProgram:
                     if k in ent["index"]:
                         to_block[i] = ent["index"][k]
                 hit = ent["cat_maps"][id(cats)] = (cats, to_block)
+        if cat is not None:
             codes = cat.codes.to_numpy()
             self.np.take(hit[1], codes, out=out, mode="wrap")  # (code -1 wraps to the last entry)
             if (out < 0).any():

@@ -435,9 +435,10 @@ def test_parallel_conditional_layers_batched_per_launch_match_one_launch_per_pos
 def test_categorical_metadata_columns_give_the_same_conditional_step():
     """The conditional programs' host side maps each cell's metadata value to a condition block: str columns through
     dictionary look-ups (csrc/pylookup.c), `category` columns (what the census' obs frames hold) through one category ->
-    block table per categories object and a gather of the codes.  Both must build the same index tables: two steps (one per
-    expert; sequential selection order, shuffled) with the same frames as str and as categorical columns -- bit-identical
-    losses and gradient arenas.  A categorical value no layer knows is refused like a str one."""
+    block table per categories object and a gather of the codes (a big categories object gets its table the second time it
+    is seen; the first time its cells are looked up one by one).  Both must build the same index tables: four steps (two
+    per expert; sequential selection order, shuffled) with the same frames as str and as categorical columns sharing one
+    dtype per key -- bit-identical losses and gradient arenas.  A categorical value no layer knows is refused like a str one."""
     import importlib.util
     import random
     import tempfile
@@ -461,11 +462,13 @@ def test_categorical_metadata_columns_give_the_same_conditional_step():
             rng.reseed(99)
             random.seed(3)
             out = []
-            for i, eid in enumerate(("human", "mouse")):
+            # categories: every label of the key (more than a batch holds), in another order, one dtype object per key
+            dtypes = {k: pd.CategoricalDtype([f"{k}_{j}" for j in reversed(range(n))]) for k, n in BC.SIZES.items()}
+            for i, eid in enumerate(("human", "mouse", "human", "mouse")):
                 md = BC.metadata(B, eid, i)
-                if kind == "category":  # categories: every label of the key (more than the batch holds), in another order
-                    for k, n in BC.SIZES.items():
-                        md[k] = pd.Categorical(md[k], categories=[f"{k}_{j}" for j in reversed(range(n))])
+                if kind == "category":
+                    for k in BC.SIZES:
+                        md[k] = md[k].astype(dtypes[k])
                     md["tissue"] = md["tissue"].astype("category")
                 x = synthetic.synthetic_counts(B, G, seed=3 + i, device="cuda")
                 model.training_step((x, md, eid), i)
@@ -475,10 +478,12 @@ def test_categorical_metadata_columns_give_the_same_conditional_step():
                 out.append((float(model.logged[f"loss/training/{eid}"]), opts["vae"].arena.grad.detach().cpu().clone(),
                             opts["experts"][eid].arena.grad.detach().cpu().clone()))
             if kind == "category":
+                plans = [p for p in model._engine._plans.values() if p.cond is not None]
+                assert all(len(p.cond.entries["donor_id"]["cat_maps"]) == 1 for p in plans)  # the table path was taken
                 bad = BC.metadata(B, "human", 5)
                 bad["assay"] = pd.Categorical(["assay_0"] * (B - 1) + ["unheard of"])
                 with pytest.raises(KeyError):
-                    model.training_step((x, bad, "human"), 2)
+                    model.training_step((x, bad, "human"), 4)
             runs[kind] = out
             model._engine.close()
     for (la, va, ea), (lb, vb, eb) in zip(runs["str"], runs["category"]):
