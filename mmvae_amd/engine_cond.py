@@ -67,8 +67,9 @@ class CondProgram:
 
     def __init__(self, plan, cl, eid: str, train: bool):
         import numpy as np
+        import pandas as pd
 
-        self.np = np
+        self.np, self.pd = np, pd
         self.plan, self.cl, self.eid, self.train = plan, cl, eid, train
         eng = plan.eng
         self.eng = eng
@@ -274,12 +275,13 @@ class CondProgram:
             return
         raw_index, layer = ent["raw_index"], ent["layer"]
         col = metadata[layer.batch_key]
-        cat = getattr(col, "cat", None) if str(col.dtype) == "category" else None
+        arr = col.array  # (the ExtensionArray itself: the `.cat` accessor costs 20 us per column, this 3)
+        cat = arr if isinstance(arr, self.pd.Categorical) else None
         if cat is not None:
             # categorical column (what obs frames of the census hold; row slices of one chunk share the categories object):
             # category -> block once per categories object, then one gather per step -- the look-ups below cost ~0.1 ms per
             # layer and step on freshly unpickled strings (a cache miss per cell) in a program whose host side is the limit
-            cats = cat.categories
+            cats = cat.dtype.categories
             hit = ent["cat_maps"].get(id(cats))
             if (hit is None or hit[0] is not cats) and len(cats) > 64 and ent["shared"]["last"] is not cats:
                 # a big categories object seen for the first time: building its table costs a Python loop over every
@@ -297,8 +299,7 @@ class CondProgram:
                         to_block[i] = ent["index"][k]
                 hit = ent["cat_maps"][id(cats)] = (cats, to_block)
         if cat is not None:
-            codes = cat.codes.to_numpy()
-            self.np.take(hit[1], codes, out=out, mode="wrap")  # (code -1 wraps to the last entry)
+            self.np.take(hit[1], cat.codes, out=out, mode="wrap")  # (code -1 wraps to the last entry)
             if (out < 0).any():
                 bad = col.iloc[int(self.np.flatnonzero(out < 0)[0])]
                 raise KeyError(f"{layer.batch_key}: {bad!r} is not a condition of this layer")
