@@ -570,9 +570,9 @@ class StepEngine:
         if eid_n == plan_eid or eid_n not in m.experts:
             return None
         if getattr(m.vae, "conditionals", None) is not None:
-            # (measured twice, r5: the conditional programs get SLOWER with it -- 1.50 -> 2.2-2.4 ms while their host side
-            # was the limit, 1.20 -> 1.87 ms after it no longer was; the device program itself gains 30 us: the chain's
-            # gather-bound conditional kernels stretch beside the capped GEMM -- profiles/HISTORY.md)
+            # (measured twice, r5: nothing to gain -- the conditional programs' device period is 1.30 ms under the tracer with
+            # and without it: the chain's gather-bound conditional kernels stretch beside the capped GEMM by what the
+            # product saves; profiles/HISTORY.md)
             return None
         if len(m.adversarials) > 0 and not (st.prefetch_adv and self.side_stream2 is not None):
             return None  # (adversarial programs: the product takes the second branch stream, free until the late branch)
