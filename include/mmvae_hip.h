@@ -454,7 +454,8 @@ int mmvae_gemm_f32_sq(int layout, int M, int N, int K, float alpha, const float*
  * because a rows-contiguous planes operand is fetched in whole 16-byte groups.
  *
  * mmvae_gemm_planes_f32 = mmvae_gemm_f32 (sq_partials == NULL) or mmvae_gemm_f32_sq (sq_partials != NULL) with
- * optional planes per operand.  Kernels exist for TN with B or both operands pre-split, for NT / NN with a pre-split A
+ * optional planes per operand.  Kernels exist for TN with A, B or both operands pre-split (late r5: A alone -- the
+ * first layer's weight gradient dY^T x with the batch x read as fp32), for NT / NN with a pre-split A
  * and (r5) for NN with a pre-split B (the weights) against an fp32 A;
  * an operand whose planes cannot be used (other combinations, shapes off the wave-specialised kernel: K % 32 != 0,
  * rows-contiguous leading dimension below the extent rounded up to 8, small outputs, MMVAE_GEMM_PRECISION_F32) is read from its fp32 form when that

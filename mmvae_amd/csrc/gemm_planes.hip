@@ -83,7 +83,9 @@ namespace mmvae_detail {
 bool x3w_planes_combo(int layout, bool a_pl, bool b_pl) {
     // (TN with only B pre-split: dW = dP^T h with the small operand h from its layer tail -- on the 160x256 tile B is
     // 256 of the 416 rows the stagers would otherwise split per k-tile)
-    if (layout == MMVAE_GEMM_TN) return b_pl;
+    // (late r5: TN with only A pre-split -- dW = dY^T x with the small dY from its column kernel and the batch x read as
+    // fp32, split by the stagers: no split pass over x at all)
+    if (layout == MMVAE_GEMM_TN) return a_pl || b_pl;
     // (r5) NN with a pre-split B: the weights of the last decoder layer, split ONCE per step for programs whose products
     // read them from many row tiles (K-sample programs: 20 row tiles of 256 at C3) -- dX = dP . W with dP fp32
     if (layout == MMVAE_GEMM_NN) return a_pl != b_pl;
@@ -133,7 +135,9 @@ int launch_x3w_planes(int layout, int tile_id, bool a_pl, bool b_pl, int epi, co
         else                                                                                                            \
             MMVAE_LAUNCH((gemm_x3w_kernel<AF, BF, 256, 128, 2, 2, EPI_STD, AS, BS>), dim3(nblocks), dim3(512), 0, s, g); \
     } while (0)
-    if (layout == MMVAE_GEMM_TN && a_pl)
+    if (layout == MMVAE_GEMM_TN && a_pl && !b_pl)
+        XWP(FORM_RC, FORM_RC, SRC_PLANES, SRC_F32);
+    else if (layout == MMVAE_GEMM_TN && a_pl)
         XWP(FORM_RC, FORM_RC, SRC_PLANES, SRC_PLANES);
     else if (layout == MMVAE_GEMM_TN)
         XWP(FORM_RC, FORM_RC, SRC_F32, SRC_PLANES);

@@ -57,6 +57,7 @@ class EngineSettings:
     prefetch_adv: int = 86       # MMVAE_PREFETCH_ADV: its cap in adversarial programs (second branch stream, beside the adversaries' lane: 3 rounds of the 256 work items; C4 1.091 -> 1.070 ms, 128: 1.083, 64: 1.094); 0 = off
     prefetch_join: bool = False  # MMVAE_PREFETCH_JOIN=1: join that product ahead of the reconstruction launch (diagnostics)
     cond_batched: bool = True    # MMVAE_COND_BATCHED=0: conditional layers of a "parallel" selection order one launch per position
+    x_planes: bool = False       # MMVAE_X_PLANES=1: the batch pre-split for the first layer's weight gradient even where that GEMM can read it as fp32 (see StepEngine._x_planes)
     prefetch: int = 128          # MMVAE_PREFETCH: workgroup cap of the NEXT step's first forward GEMM beside this step's forward chain (software pipelining across steps, needs the caller's hint); 0 = off
     adv_fused: bool = True       # MMVAE_ADV_FUSED=0: the per-layer adversary program (the path of adversaries with BatchNorm)
     adv_aside: int = 2           # MMVAE_ADV_ASIDE: 0 the fused adversary passes in order; 1 on the branch stream; 2 + the decoder's weight gradient on a second branch from where the first is joined
@@ -79,7 +80,7 @@ class EngineSettings:
             planes=e("MMVAE_PLANES", "1") != "0", side_dw=int(e("MMVAE_SIDE_DW", "125")),
             side_dw2=int(e("MMVAE_SIDE_DW2", "185")), side_dw_dp=int(e("MMVAE_SIDE_DW_DP", "125")),
             side_dw_any=e("MMVAE_SIDE_DW_ANY", "0") != "0", prefetch=int(e("MMVAE_PREFETCH", "128")), prefetch_join=e("MMVAE_PREFETCH_JOIN", "0") == "1",
-            cond_batched=e("MMVAE_COND_BATCHED", "1") != "0", prefetch_adv=int(e("MMVAE_PREFETCH_ADV", "86")),
+            cond_batched=e("MMVAE_COND_BATCHED", "1") != "0", x_planes=e("MMVAE_X_PLANES", "0") == "1", prefetch_adv=int(e("MMVAE_PREFETCH_ADV", "86")),
             adv_fused=e("MMVAE_ADV_FUSED", "1") != "0",
             adv_aside=int(e("MMVAE_ADV_ASIDE", "2")),
             dp_overlap=None if ov == "" else ov != "0", dp_shard=e("MMVAE_DP_SHARD", "1") != "0", dp_kernels=kernels,
@@ -453,7 +454,19 @@ class StepEngine:
         # (K-sample programs run the encoder once over the B cells: the same product as at K = 1)
         return bool(self.planes and train and not iwae and self.lib.mmvae_gemm_get_precision() == 1
                     and l0_out % 8 == 0 and has_bn
-                    and self.lib.mmvae_gemm_planes_supported(TN, l0_out, l0_in, (B + 31) // 32 * 32, 1, 1, 1))
+                    and self.lib.mmvae_gemm_planes_supported(TN, l0_out, l0_in, (B + 31) // 32 * 32, 1,
+                                                             int(self._x_planes(l0_in, B)), 1))
+
+    def _x_planes(self, l0_in: int, B: int) -> bool:
+        """Is the BATCH pre-split for the first layer's weight gradient dW1 = dY^T x (True), or does that GEMM read it as
+        fp32 and split it in its stagers, with only dY pre-split (False)?  Late r5: the split pass over x -- 41 MB in, 61 MB
+        out, riding on the forward chain's tail launches -- costs that chain 27 us since the pipelined product runs beside
+        it, and buys the GEMM 6 us (145 -> 151 us): fp32 wins at every configuration (C2 0.900 -> 0.888 ms, C3 3.452 ->
+        3.405, C4 1.078 -> 1.063, C5 5.096 -> 5.039, CSR-fed 0.951 -> 0.934; HISTORY.md).  Planes stay where the fp32 batch
+        could not be read in place: a gene count off a multiple of 4 or a batch off a multiple of 32 (rows-contiguous
+        16-byte groups / whole k-tiles: the batch would have to be staged with slack every step -- the reference's
+        60 530 / 52 437 genes)."""
+        return bool(self.settings.x_planes or l0_in % 4 != 0 or B % 32 != 0)
 
     def _select_input(self, x: torch.Tensor, base_key: tuple, needs_slack: bool = True):
         """Plan selection: graphs are keyed by the input pointer once a pointer has been seen twice (resident
@@ -832,7 +845,11 @@ class _Plan(PlanEmit, PlanAdversaries, PlanRun):
         self.pl_dec_w = bool(pl_on and R >= 2048 and lastl.n_in % 8 == 0
                              and lib.mmvae_gemm_planes_supported(NN, R, lastl.n_in, (G + 31) // 32 * 32, 0, 0, 1))
         self.wp = _PlaneBuf(eng, f"wp.{G}.{lastl.n_in}", G, lastl.n_in) if self.pl_dec_w else None
-        if self.pl_enc:
+        # (late r5) the batch itself stays fp32 wherever the weight-gradient GEMM can read it in place: StepEngine._x_planes
+        self.x_fp32_dw1 = bool(self.pl_enc and not eng._x_planes(l0.n_in, B))
+        if self.x_fp32_dw1:
+            self.xp = None
+        if self.pl_enc and not self.x_fp32_dw1:
             # The split of x is piggy-backed on the tail launches of the forward chain (extra workgroups of
             # fc_fwd_apply), a third of the rows each: those launches are latency-bound (5-13 us with the memory system
             # idle), 20 MB of streaming beside each is nearly free -- as one pass beside the first tail it cost 12 us, as a

@@ -482,7 +482,8 @@ class PlanEmit:
         its input -- both operands of its weight-gradient GEMM.  row_scale: per-row factor of the incoming gradient
         (the K-sample bound's weights, applied where the slabs are summed)."""
         rows = l.rows
-        dw_planes = (dz_planes, inp_planes) if (dz_planes is not None and inp_planes is not None) else None
+        dw_planes = (dz_planes, inp_planes) if (dz_planes is not None and (inp_planes is not None or
+                                                                         getattr(self, "x_fp32_dw1", False))) else None
         plan = self
         relu_src = l.a if l.a is not None else l.d
         has_bn = l.bn is not None

@@ -66,11 +66,15 @@ def test_full_size_engine_steps_match_reference(name):
         """Follow-on check of the forward-only program: eval-mode validation on the last batch.  The state it runs on is
         the engine's own after the training steps (the reference's to ~1e-5), so the tolerance is wider: 1e-3."""
         x, eps, metadata, eid = last
-        # every training program of a full-size case reads the operands of its first-layer weight gradient from bf16 planes
-        # -- at any gene count (r5: mid_odd's 10 001 / 8 190 take a leading dimension rounded up to 8)
+        # every training program of a full-size case reads dY of its first-layer weight gradient from bf16 planes -- at any
+        # gene count -- and the batch itself either as fp32 in place (gene count a multiple of 4, batch of 32) or from planes
+        # whose leading dimension is rounded up to 8 (r5: mid_odd's 10 001 / 8 190)
         train_plans = [p for k, p in model._engine._plans.items() if str(k[0]).startswith("train")]
-        assert train_plans and all(p.pl_enc and p.xp.ld % 8 == 0 for p in train_plans), [(p.G, p.pl_enc) for p in train_plans]
-        seen["planes_ld_pad"] = float(max(p.xp.ld - p.xp.cols for p in train_plans))
+        assert train_plans and all(p.pl_enc and p.dYp is not None for p in train_plans), [(p.G, p.pl_enc) for p in train_plans]
+        for p in train_plans:
+            in_place = p.G % 4 == 0 and p.B % 32 == 0
+            assert (p.xp is None) == in_place and (in_place or p.xp.ld % 8 == 0), (p.G, p.B)
+        seen["planes_ld_pad"] = float(max([p.xp.ld - p.xp.cols for p in train_plans if p.xp is not None] or [0]))
         model.eval()
         model.trainer.set_stage("validation")
         model.module.vae.encoder.explicit_eps = eps.cuda()

@@ -63,6 +63,9 @@ CASES = [
     (TN, 2000, 5008, 480, "ab", False),   # ragged tiles (extents % 8 == 0 only), K padded to 512 over the slack rows
     (TN, 20000, 1024, 512, "b", False),   # the same product with only h pre-split (A = dP split in the kernel)
     (TN, 2000, 5008, 480, "b", False),
+    (TN, 1024, 20000, 512, "a", False),   # (late r5) dW of the first layer with only dY pre-split: the batch x stays fp32
+    (TN, 1024, 30000, 1024, "a", False),  # ... at C5's width and batch
+    (TN, 2000, 5008, 480, "a", False),
     # gene counts off a multiple of 8 (r5; human_only.yaml:90, adversarial-conditional.yaml:107): planes with a padded ld
     (TN, 1024, 60530, 512, "ab", False),  # dW of the first layer at the reference's human width
     (TN, 1024, 52437, 512, "ab", False),  # ... and the mouse width (odd)
