@@ -1,5 +1,5 @@
 """Launches the five G-wide GEMMs of the C2 step in the operand forms the engine uses (the expert encoder's first
-layer: forward, weight gradient from pre-split planes; the decoder's last layer: fused forward + reconstruction, input
+layer: forward, weight gradient with dY pre-split; the decoder's last layer: fused forward + reconstruction, input
 gradient, weight gradient with h pre-split) a few times each, for rocprofv3 --pmc passes (one counter group per run):
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out -o p -- python3 tools/roofline_kernel.py
 usage: roofline_kernel.py [family | fwd | dw | dw_planes | fwd_half]
@@ -45,7 +45,9 @@ for _ in range(8):
         ops.decoder_recon(h, W4, b4, X, want_xhat=False, dP=dP.clone(), se_part=sep)  # fused last layer + recon
         ops.gemm_slabs(ops.GEMM_NN, dP, W4)  # dX[B, 1024] = dP . W4
         ops.gemm_planes(ops.GEMM_TN, dP, None, b_planes=hp, out=dW4, want_sq=True)  # dW4[G, 1024] = dP^T . h  (h pre-split)
-    if which in ("family", "dw_planes"):  # dW1[1024, G] = dY^T . X from pre-split planes (LDS-DMA stagers)
+    if which == "family":  # dW1[1024, G] = dY^T . X with dY pre-split and the batch read as fp32 (the engine's form since late r5)
+        ops.gemm_planes(ops.GEMM_TN, None, X, a_planes=dYp, out=dW1, want_sq=True)
+    if which == "dw_planes":  # ... from pre-split planes of both (LDS-DMA stagers; gene counts off a multiple of 4)
         ops.gemm_planes(ops.GEMM_TN, None, None, a_planes=dYp, b_planes=Xp, out=dW1, want_sq=True)
     if which == "fwd_half":
         ops.gemm_slabs(ops.GEMM_NT, X[:, : G // 2], W1[:, : G // 2])
